@@ -1,0 +1,126 @@
+/*
+ * lvg_ops.h -- C ABI of liblvg_hip.so, the MI355X (gfx950) kernel library behind
+ * the torch_utils.ops hot path of LongVideoGAN.
+ *
+ * Every entry point replaces one pybind function of the reference plugins
+ * (paths relative to the reference repo):
+ *
+ *   lvg_bias_act            <- bias_act()            torch_utils/ops/bias_act.cpp:32
+ *   lvg_upfirdn2d           <- upfirdn2d()           torch_utils/ops/upfirdn2d.cpp:16
+ *   lvg_filtered_lrelu      <- filtered_lrelu()      torch_utils/ops/filtered_lrelu.cpp:16
+ *   lvg_filtered_lrelu_act  <- filtered_lrelu_act_() torch_utils/ops/filtered_lrelu.cpp:213
+ *
+ * Contract (differs from the pybind ABI on purpose):
+ *   - plain pointers and sizes only; the caller owns every buffer (outputs are
+ *     allocated by the host language, e.g. torch.empty), nothing is allocated,
+ *     freed or synchronised inside the library;
+ *   - every launch goes to the hipStream_t passed as `stream` (0 = the null
+ *     stream); the library holds no global device state (the reference's global
+ *     filter buffers, filtered_lrelu.cu:77-78, are gone), so calls on different
+ *     streams may overlap;
+ *   - return value: 0 = launched, LVG_ERR_* < 0 = refused, nothing launched.
+ *     LVG_ERR_UNSUPPORTED from lvg_filtered_lrelu is the reference's
+ *     "return code -1": no fused kernel for these parameters, the caller must
+ *     take the generic path (filtered_lrelu.py:223-229);
+ *   - lvg_last_error() returns a thread-local message for the last refusal.
+ *   - strides are in ELEMENTS, shapes are NCHW order [n, c, h, w].
+ */
+#ifndef LVG_OPS_H
+#define LVG_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVG_ABI_VERSION 1
+
+/* element types of activations; filters are always float32 */
+enum { LVG_F32 = 0, LVG_F16 = 1, LVG_BF16 = 2, LVG_F64 = 3 };
+
+/* activation ids: identical to `cuda_idx` of bias_act.activation_funcs (bias_act.py:21-31) */
+enum {
+    LVG_ACT_LINEAR = 1, LVG_ACT_RELU = 2, LVG_ACT_LRELU = 3, LVG_ACT_TANH = 4, LVG_ACT_SIGMOID = 5,
+    LVG_ACT_ELU = 6, LVG_ACT_SELU = 7, LVG_ACT_SOFTPLUS = 8, LVG_ACT_SWISH = 9
+};
+
+enum {
+    LVG_OK = 0,
+    LVG_ERR_INVALID = -1,      /* bad argument (the reference raises via TORCH_CHECK) */
+    LVG_ERR_UNSUPPORTED = -2,  /* no specialised kernel: take the generic path       */
+    LVG_ERR_LAUNCH = -3        /* hipLaunchKernel / hipGetLastError reported a failure */
+};
+
+/* sign-tensor modes of filtered_lrelu */
+enum { LVG_SIGNS_NONE = 0, LVG_SIGNS_WRITE = 1, LVG_SIGNS_READ = 2 };
+
+int lvg_abi_version(void);
+const char* lvg_last_error(void);
+
+/*
+ * y = clamp(act(x + b[(i / stepB) % sizeB]) * gain)                      grad == 0
+ * y = x(=dy) * act'(.) * gain,     zeroed where |yref| >= clamp          grad == 1
+ * y = x(=d_dx) * act''(.) * gain * dy, same mask                         grad == 2
+ * All tensors are dense with identical layout, n elements; b/xref/yref/dy may be NULL.
+ * clamp < 0 disables clamping. Reference: bias_act.cpp:32-90, bias_act.cu:23-147.
+ */
+int lvg_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy,
+                 void* y, int64_t n, int64_t sizeB, int64_t stepB, int dtype, int grad, int act,
+                 float alpha, float gain, float clamp, void* stream);
+
+/*
+ * upsample (zero insertion) -> pad/crop -> FIR -> decimate, per channel.
+ * Exactly one of {f2d} or {fx, fy} describes the filter:
+ *   f2d != NULL : dense 2-D taps, f2d[fy_i * fstride_y + fx_i * fstride_x], size fh x fw
+ *                 (reference plugin form, upfirdn2d.cpp:16);
+ *   f2d == NULL : separable; fx (fw taps, may be NULL = identity) along W and
+ *                 fy (fh taps, may be NULL = identity) along H, applied as ONE fused
+ *                 pass (the reference issues two plugin calls, upfirdn2d.py:241-245).
+ * out size = (in*up + pad0 + pad1 - f + down) / down (upfirdn2d.cpp:35-36); the caller
+ * passes it in yshape. gain multiplies the result. flip != 0 means correlation.
+ */
+int lvg_upfirdn2d(const void* x, void* y, const float* f2d, const float* fx, const float* fy,
+                  const int64_t xshape[4], const int64_t xstride[4],
+                  const int64_t yshape[4], const int64_t ystride[4],
+                  int fw, int fh, int64_t fstride_x, int64_t fstride_y,
+                  int upx, int upy, int downx, int downy,
+                  int padx0, int pady0, int flip, float gain, int dtype, void* stream);
+
+/*
+ * Fused bias -> up-FIR (x up^2) -> gain -> leaky ReLU -> clamp -> down-FIR, one pass
+ * (filtered_lrelu.cpp:16-209). fu/fd are separable 1-D float32 taps (fu_n / fd_n of
+ * them); the 1x1 case is fu_n == fd_n == 1 with up == down == 1.
+ * sign_mode WRITE: s receives 2 bits per up-sampled pixel (bit0 negative, bit1 clamped),
+ *   4 pixels per byte, rows of sshape[1] bytes, sshape[0] rows, per (n, c) plane;
+ * sign_mode READ: slope/zero decisions come from s at offset (sofs_x, sofs_y) instead
+ *   of from the data (backward pass, filtered_lrelu.py:239-268).
+ * Returns LVG_ERR_UNSUPPORTED when (up, down, taps, dtype) has no fused kernel.
+ */
+int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t* s,
+                       const float* fu, const float* fd,
+                       const int64_t xshape[4], const int64_t xstride[4],
+                       const int64_t yshape[4], const int64_t ystride[4],
+                       int fu_n, int fd_n, int up, int down, int px0, int py0,
+                       const int64_t sshape[2], int sofs_x, int sofs_y, int sw_active,
+                       float gain, float slope, float clamp, int flip, int sign_mode,
+                       int dtype, void* stream);
+
+/* 1 if lvg_filtered_lrelu has a fused kernel for these parameters, else 0 (no launch). */
+int lvg_filtered_lrelu_supported(int fu_n, int fd_n, int up, int down, int dtype);
+
+/*
+ * In-place middle step of the generic filtered_lrelu path: x = clamp(lrelu(x * gain))
+ * with sign write / read (filtered_lrelu.cpp:213-290, filtered_lrelu.cu:1105-1211).
+ * sshape = {bytes per row, rows}; with WRITE the sign plane covers x exactly
+ * (width rounded up to 16 pixels).
+ */
+int lvg_filtered_lrelu_act(void* x, uint8_t* s, const int64_t xshape[4], const int64_t xstride[4],
+                           const int64_t sshape[2], int sofs_x, int sofs_y,
+                           float gain, float slope, float clamp, int sign_mode,
+                           int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVG_OPS_H */

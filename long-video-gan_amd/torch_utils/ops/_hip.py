@@ -1,0 +1,84 @@
+"""ctypes marshalling between torch tensors and the C ABI of liblvg_hip.so (include/lvg_ops.h).
+
+The host side allocates every output with torch (caching allocator, current device) and hands
+raw device pointers, element strides and the CURRENT torch stream to the library; nothing here
+synchronises. All failures raise -- a GPU tensor never silently takes a PyTorch fallback."""
+
+import ctypes
+
+import torch
+
+from .. import custom_ops
+
+F32, F16, BF16, F64 = 0, 1, 2, 3
+_DTYPE_CODES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.float64: F64}
+
+SIGNS_NONE, SIGNS_WRITE, SIGNS_READ = 0, 1, 2
+ERR_UNSUPPORTED = -2
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+_i64x4 = ctypes.c_int64 * 4
+_i64x2 = ctypes.c_int64 * 2
+
+_SIGNATURES = {
+    'lvg_bias_act': [_vp] * 6 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
+    'lvg_upfirdn2d': [_vp] * 5 + [_i64x4] * 4 + [_i32, _i32, _i64, _i64] + [_i32] * 4 + [_i32, _i32, _i32, _f32, _i32, _vp],
+    'lvg_filtered_lrelu': [_vp] * 6 + [_i64x4] * 4 + [_i32] * 6 + [_i64x2, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _vp],
+    'lvg_filtered_lrelu_supported': [_i32] * 5,
+    'lvg_filtered_lrelu_act': [_vp, _vp, _i64x4, _i64x4, _i64x2, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library with argtypes installed; raises custom_ops.PluginUnavailable if
+    liblvg_hip.so is absent."""
+    global _lib
+    if _lib is None:
+        handle = custom_ops.load_library()
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = handle
+    return _lib
+
+
+def dtype_code(dtype):
+    code = _DTYPE_CODES.get(dtype)
+    if code is None:
+        raise TypeError(f'dtype {dtype} is not supported by the HIP ops (float32/float16/bfloat16/float64)')
+    return code
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors (the reference plugin
+    convention: numel()==0 means "absent")."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def shape4(t):
+    return _i64x4(*t.shape)
+
+
+def stride4(t):
+    return _i64x4(*t.stride())
+
+
+def pair(a, b):
+    return _i64x2(a, b)
+
+
+def check(rc, what):
+    """Raise for a negative return code (RuntimeError mirrors TORCH_CHECK in the reference)."""
+    if rc < 0:
+        msg = lib().lvg_last_error()
+        raise RuntimeError(f'{what}: {msg.decode() if msg else "error"} (code {rc})')
+    return rc

@@ -1,0 +1,197 @@
+"""numpy front end of the CPU oracle (oracle/lvg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of lvg_oracle.c. Importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never from long-video-gan_amd/.
+
+Parity status: PINNED against tests/golden/ (fixtures generated from the reference's own
+impl='ref' Python path by tests/golden/make_golden.py; checked by tests/test_oracle_golden.py).
+
+All functions take/return numpy arrays. Arithmetic is float64 inside; results are returned as
+float64 (callers cast/compare at the tolerance of the dtype under test)."""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'liblvg_oracle.so')
+_lib = None
+
+ACT_IDS = dict(linear=1, relu=2, lrelu=3, tanh=4, sigmoid=5, elu=6, selu=7, softplus=8, swish=9)
+ACT_DEFAULTS = dict(  # (def_alpha, def_gain) -- reference bias_act.py:21-31
+    linear=(0, 1), relu=(0, np.sqrt(2)), lrelu=(0.2, np.sqrt(2)), tanh=(0, 1), sigmoid=(0, 1),
+    elu=(0, 1), selu=(0, 1), softplus=(0, 1), swish=(0, np.sqrt(2)))
+
+
+def build(force=False):
+    """Compile lvg_oracle.c with gcc (seconds). Building the checker is not using it."""
+    src = os.path.join(_HERE, 'lvg_oracle.c')
+    if force or not os.path.isfile(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(['make', '-C', _HERE, '-s'], check=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.float64)
+
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, grad=0, xref=None, yref=None, dy=None):
+    """grad=0: forward. grad=1: x is dy. grad=2: x is d_dx and `dy` the first-order cotangent."""
+    x = _f64(x)
+    def_alpha, def_gain = ACT_DEFAULTS[act]
+    alpha = float(def_alpha if alpha is None else alpha)
+    gain = float(def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    y = np.empty_like(x)
+    b64 = _f64(b)
+    step = int(np.prod(x.shape[dim + 1:])) if b is not None else 1
+    size_b = b64.shape[0] if b is not None else 1
+    xr, yr, dyv = _f64(xref), _f64(yref), _f64(dy)
+    rc = lib().orc_bias_act(_dp(x), _dp(b64), _dp(xr), _dp(yr), _dp(dyv), _dp(y),
+                            ctypes.c_int64(x.size), ctypes.c_int64(size_b), ctypes.c_int64(step),
+                            ctypes.c_int(grad), ctypes.c_int(ACT_IDS[act]),
+                            ctypes.c_double(alpha), ctypes.c_double(gain), ctypes.c_double(clamp))
+    assert rc == 0, rc
+    return y
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _pad4(p):
+    if isinstance(p, int):
+        p = [p, p]
+    p = list(p)
+    if len(p) == 2:
+        p = [p[0], p[0], p[1], p[1]]
+    return p
+
+
+def _filter2d(f):
+    """None -> 1x1 identity; 1-D -> outer product (separable, upfirdn2d.py:205-207)."""
+    if f is None:
+        return np.ones([1, 1], dtype=np.float64)
+    f = _f64(f)
+    if f.ndim == 1:
+        f = np.outer(f, f)
+    return np.ascontiguousarray(f)
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    x = _f64(x)
+    n, c, ih, iw = x.shape
+    upx, upy = _pair(up)
+    downx, downy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    f2 = _filter2d(f)
+    fh, fw = f2.shape
+    ow = (iw * upx + px0 + px1 - fw + downx) // downx
+    oh = (ih * upy + py0 + py1 - fh + downy) // downy
+    assert ow >= 1 and oh >= 1
+    y = np.empty([n, c, oh, ow], dtype=np.float64)
+    rc = lib().orc_upfirdn2d(_dp(x), _dp(f2), _dp(y), ctypes.c_int64(n * c), ih, iw, fh, fw,
+                             upx, upy, downx, downy, px0, px1, py0, py1, int(bool(flip_filter)),
+                             ctypes.c_double(gain), oh, ow)
+    assert rc == 0, rc
+    return y
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
+    """Padding rule of upfirdn2d.py:339-348."""
+    upx, upy = _pair(up)
+    px0, px1, py0, py1 = _pad4(padding)
+    f2 = _filter2d(f)
+    fh, fw = f2.shape
+    p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1):
+    """Padding rule of upfirdn2d.py:378-387."""
+    downx, downy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    f2 = _filter2d(f)
+    fh, fw = f2.shape
+    p = [px0 + (fw - downx + 1) // 2, px1 + (fw - downx) // 2, py0 + (fh - downy + 1) // 2, py1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain)
+
+
+def sign_shape(oh, ow, down, fdh, fdw):
+    """Rows and bytes-per-row of the sign plane (filtered_lrelu.cpp:87-94)."""
+    sw_active = ow * down - (down - 1) + (fdw - 1)
+    sh = oh * down - (down - 1) + (fdh - 1)
+    return sh, ((sw_active + 15) & ~15) >> 2, sw_active
+
+
+def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None,
+                   flip_filter=False, signs=None, sign_ofs=(0, 0), write_signs=False):
+    """Returns y, or (y, s) with write_signs. `signs` (uint8 [n,c,sh,swb]) switches to READ mode."""
+    x = _f64(x)
+    n, c, ih, iw = x.shape
+    fu2, fd2 = _filter2d(fu), _filter2d(fd)
+    px0, px1, py0, py1 = _pad4(padding)
+    cw = iw * up + px0 + px1 - (fu2.shape[1] - 1)
+    ch = ih * up + py0 + py1 - (fu2.shape[0] - 1)
+    ow = (cw - (fd2.shape[1] - 1) + (down - 1)) // down
+    oh = (ch - (fd2.shape[0] - 1) + (down - 1)) // down
+    y = np.empty([n, c, oh, ow], dtype=np.float64)
+    mode, s, sh, swb = 0, None, 0, 0
+    if signs is not None:
+        mode, s = 2, np.ascontiguousarray(signs, dtype=np.uint8)
+        sh, swb = s.shape[2], s.shape[3]
+    elif write_signs:
+        sh, swb, _ = sign_shape(oh, ow, down, fd2.shape[0], fd2.shape[1])
+        mode, s = 1, np.zeros([n, c, sh, swb], dtype=np.uint8)
+    clamp_v = float('inf') if clamp is None else float(clamp)
+    b64 = _f64(b)
+    rc = lib().orc_filtered_lrelu(
+        _dp(x), _dp(fu2), _dp(fd2), _dp(b64), _dp(y),
+        None if s is None else s.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+        ctypes.c_int64(n), ctypes.c_int64(c), ih, iw, fu2.shape[0], fu2.shape[1], fd2.shape[0], fd2.shape[1],
+        up, down, px0, px1, py0, py1, int(sign_ofs[0]), int(sign_ofs[1]), sh, swb,
+        ctypes.c_double(gain), ctypes.c_double(slope), ctypes.c_double(clamp_v), int(bool(flip_filter)), mode, oh, ow)
+    assert rc == 0, rc
+    return (y, s) if write_signs else y
+
+
+def filtered_lrelu_act(x, gain, slope, clamp, signs=None, sign_ofs=(0, 0), write_signs=False):
+    x = _f64(x).copy()
+    n, c, h, w = x.shape
+    mode, s, sh, swb = 0, None, 0, 0
+    if signs is not None:
+        mode, s = 2, np.ascontiguousarray(signs, dtype=np.uint8)
+        sh, swb = s.shape[2], s.shape[3]
+    elif write_signs:
+        sh, swb = h, ((w + 15) & ~15) >> 2
+        mode, s = 1, np.zeros([n, c, sh, swb], dtype=np.uint8)
+    clamp_v = float('inf') if clamp is None else float(clamp)
+    rc = lib().orc_filtered_lrelu_act(
+        _dp(x), None if s is None else s.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+        ctypes.c_int64(n * c), h, w, int(sign_ofs[0]), int(sign_ofs[1]), sh, swb,
+        ctypes.c_double(gain), ctypes.c_double(slope), ctypes.c_double(clamp_v), mode)
+    assert rc == 0, rc
+    return (x, s) if write_signs else x
+
+
+def fma(a, b, c):
+    a, b, c = np.broadcast_arrays(_f64(a), _f64(b), _f64(c))
+    a, b, c = (np.ascontiguousarray(v) for v in (a, b, c))
+    y = np.empty_like(a)
+    rc = lib().orc_fma(_dp(a), _dp(b), _dp(c), _dp(y), ctypes.c_int64(a.size))
+    assert rc == 0
+    return y

@@ -1,0 +1,56 @@
+import ast
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'long-video-gan_amd')
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu through gpurun)')
+
+
+def load_golden(name):
+    """dict of arrays from tests/golden/<name>.npz; '*_spec' entries are parsed back to dicts."""
+    raw = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    out = {}
+    for k in raw.files:
+        v = raw[k]
+        if k.endswith('spec'):
+            txt = str(v)
+            txt = txt.replace('np.float64(', '(').replace('np.float32(', '(')
+            out[k] = ast.literal_eval(txt)
+        else:
+            out[k] = v
+    return out
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when no device is visible, so `pytest tests/` on the
+    # CPU container stays green; `-m gpu` on the MI355X box runs them for real.
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason='no GPU visible')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,121 @@
+"""HIP filtered_lrelu (fused kernel where available, generic path otherwise) vs the oracle and
+the golden fixtures, including the sign-mask round trip used by the backward pass."""
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from torch_utils.ops import filtered_lrelu
+
+DEV = 'cuda'
+TOL = {torch.float32: dict(rtol=5e-5, atol=5e-6), torch.float64: dict(rtol=1e-10, atol=1e-11),
+       torch.float16: dict(rtol=5e-3, atol=5e-3), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+
+
+def dev(a, dtype, grad=False):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV, requires_grad=grad)
+
+
+def host(t):
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_golden_forward_backward(dtype):
+    g = load_golden('filtered_lrelu')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        for i in range(int(g['num_cases'])):
+            p = f'c{i}_'
+            sp = g[p + 'spec']
+            fu = torch.tensor(g[p + 'fu'], device=DEV) if p + 'fu' in g else None
+            fd = torch.tensor(g[p + 'fd'], device=DEV) if p + 'fd' in g else None
+            x, b = dev(g[p + 'x'], dtype, True), dev(g[p + 'b'], dtype, True)
+            y = filtered_lrelu.filtered_lrelu(x, fu, fd, b, **sp['kw'])
+            tol = TOL[dtype] if sp['kw']['up'] in (1, 2, 4) or dtype == torch.float32 else dict(rtol=2e-6, atol=2e-7)
+            np.testing.assert_allclose(host(y), g[p + 'y'], err_msg=str(sp), **tol)
+            dx, db = torch.autograd.grad(y, [x, b], dev(g[p + 'dy'], dtype))
+            # float32: a pre-activation within rounding of 0 or of the clamp may flip its mask bit;
+            # such elements are measure-zero, allow a handful of outliers.
+            err = np.abs(host(dx) - g[p + 'dx'])
+            lim = tol['atol'] * 10 + tol['rtol'] * 10 * np.abs(g[p + 'dx'])
+            assert (err > lim).mean() <= (0.0 if dtype == torch.float64 else 2e-3), (str(sp), float(err.max()))
+            np.testing.assert_allclose(host(db), g[p + 'db'], rtol=1e-3 if dtype == torch.float32 else 1e-8, atol=1e-3 if dtype == torch.float32 else 1e-8)
+
+
+def test_sign_mask_bit_exact_with_exact_arithmetic(oracle):
+    """Integer inputs and dyadic taps make float32 and float64 arithmetic both exact, so the
+    2-bit mask written by the GPU must equal the oracle's byte for byte (active region)."""
+    rs = np.random.RandomState(11)
+    x = rs.randint(-8, 9, size=(2, 3, 10, 13)).astype(np.float32)
+    b = rs.randint(-2, 3, size=(3,)).astype(np.float32)
+    f = np.array([0.125, 0.375, 0.375, 0.125], dtype=np.float32)
+    kw = dict(up=2, down=2, padding=[3, 2, 3, 2], gain=2.0, slope=0.25, clamp=4.0)
+    xt = dev(x, torch.float32, True)
+    ft = torch.tensor(f, device=DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        y = filtered_lrelu.filtered_lrelu(xt, ft, ft, dev(b, torch.float32), **kw)
+    yo, so = oracle.filtered_lrelu(x, f, f, b, write_signs=True, **kw)
+    np.testing.assert_array_equal(host(y), yo)
+    s_gpu = y.grad_fn.saved_tensors[0].cpu().numpy()
+    assert s_gpu.shape == so.shape
+    sh, swb, sw_active = oracle.sign_shape(yo.shape[2], yo.shape[3], 2, 4, 4)
+    for xx in range(sw_active):
+        got = (s_gpu[..., xx >> 2] >> ((xx & 3) * 2)) & 3
+        want = (so[..., xx >> 2] >> ((xx & 3) * 2)) & 3
+        np.testing.assert_array_equal(got, want)
+    dy = rs.randint(-4, 5, size=yo.shape).astype(np.float32)
+    (dx,) = torch.autograd.grad(y, xt, dev(dy, torch.float32))
+    pp = [3 + 3 - 3, x.shape[3] * 2 - yo.shape[3] * 2 + 3 - 1, 3 + 3 - 3, x.shape[2] * 2 - yo.shape[2] * 2 + 3 - 1]
+    dxo = oracle.filtered_lrelu(dy, f, f, None, up=2, down=2, padding=pp, gain=2.0, slope=0.25, clamp=None,
+                                flip_filter=True, signs=so, sign_ofs=(-3 + 3, -3 + 3))
+    np.testing.assert_array_equal(host(dx), dxo)
+
+
+SRES = [
+    # (name, x shape, up, down, fu taps, fd taps, padding)
+    ('L0_like', [2, 16, 31, 38], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('up4', [2, 8, 31, 38], 4, 2, 24, 12, [-6, -9, -6, -9]),
+    ('bwd_shape_up2_down4', [2, 8, 40, 44], 2, 4, 12, 24, [11, 10, 11, 10]),
+    ('final_crop', [1, 8, 60, 70], 2, 2, 12, 12, [-11, -12, -11, -12]),
+    ('odd', [1, 3, 17, 23], 2, 2, 12, 12, [9, 8, 9, 8]),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('case', SRES, ids=[s[0] for s in SRES])
+def test_sres_layer_shapes_vs_oracle(case, dtype, oracle):
+    import scipy.signal
+    name, shape, up, down, nu, nd, pad = case
+    fu = scipy.signal.firwin(numtaps=nu, cutoff=0.9 / up, width=0.6 / up, fs=2.0).astype(np.float32)
+    fd = scipy.signal.firwin(numtaps=nd, cutoff=0.9 / down, width=0.6 / down, fs=2.0).astype(np.float32)
+    rs = np.random.RandomState(6)
+    x = dev(rs.randn(*shape), dtype, True)
+    b = dev(rs.randn(shape[1]) * 0.3, dtype, True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        y = filtered_lrelu.filtered_lrelu(x, torch.tensor(fu, device=DEV), torch.tensor(fd, device=DEV), b,
+                                          up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=256)
+        ref = oracle.filtered_lrelu(host(x), fu, fd, host(b), up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=256)
+        assert tuple(y.shape) == ref.shape and y.dtype == dtype
+        np.testing.assert_allclose(host(y), ref, err_msg=name, **TOL[dtype])
+        if dtype == torch.float32:
+            dy = torch.randn_like(y)
+            dx, db = torch.autograd.grad(y, [x, b], dy)
+            assert dx.shape == x.shape and db.shape == b.shape and torch.isfinite(dx).all()
+
+
+def test_no_grad_writes_no_mask_and_torgb_1x1(oracle):
+    rs = np.random.RandomState(8)
+    x = dev(rs.randn(2, 5, 9, 11), torch.float32)
+    b = dev(rs.randn(5), torch.float32)
+    y = filtered_lrelu.filtered_lrelu(x, None, None, b, up=1, down=1, gain=1, slope=1, clamp=256)
+    assert y.grad_fn is None
+    np.testing.assert_allclose(host(y), oracle.filtered_lrelu(host(x), None, None, host(b), gain=1, slope=1, clamp=256), rtol=1e-6, atol=1e-6)
