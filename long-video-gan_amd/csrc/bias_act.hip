@@ -26,7 +26,9 @@ struct BiasActArgs
     int64_t     stepB;
     int         sizeB;
     int         grad;
-    int         biasMode; // 0 none, 1 one bias per 16-byte vector, 2 contiguous biases (stepB == 1)
+    int         biasMode; // 0 none, 1 one bias per row, 2 contiguous biases along the row (stepB == 1)
+    int64_t     rows;     // vector-kernel view: rows x rowVecs 16-byte vectors
+    int64_t     rowVecs;
     float       alpha;
     float       gain;
     float       clamp;
@@ -46,8 +48,8 @@ template <> __device__ __forceinline__ float  lvg_tanh<float>(float v)   { retur
 template <> __device__ __forceinline__ double lvg_tanh<double>(double v) { return tanh(v); }
 
 // One element. `in` is x (grad 0), dy (grad 1) or d_dx (grad 2); `bias` is already resolved.
-template <class A, int ACT>
-__device__ __forceinline__ A bias_act_elem(int G, A in, A bias, A xr, A yr, A dyv, A alpha, A gain, A clamp)
+template <class A, int ACT, int G>
+__device__ __forceinline__ A bias_act_elem(A in, A bias, A xr, A yr, A dyv, A alpha, A gain, A clamp)
 {
     const A one = (A)1, two = (A)2, zero = (A)0;
     const A kExpRange = (A)80, kHalfExpRange = (A)40;
@@ -56,7 +58,17 @@ __device__ __forceinline__ A bias_act_elem(int G, A in, A bias, A xr, A yr, A dy
 
     A v = in;
     if (G == 0) v += bias; else xr += bias;
-    const A yy = (gain != zero) ? yr / gain : zero; // forward activation value recovered from the saved output
+    // Forward activation value recovered from the saved output. relu / lrelu only need its sign,
+    // which spares the IEEE division on the hot path.
+    A yy = zero;
+    bool yyPos = false;
+    if (G > 0)
+    {
+        if (ACT == LVG_ACT_RELU || ACT == LVG_ACT_LRELU)
+            yyPos = (gain > zero) ? (yr > zero) : ((gain < zero) ? (yr < zero) : false);
+        else
+            yy = (gain != zero) ? yr / gain : zero;
+    }
     A r = zero;
 
     if (ACT == LVG_ACT_LINEAR)
@@ -66,12 +78,12 @@ __device__ __forceinline__ A bias_act_elem(int G, A in, A bias, A xr, A yr, A dy
     else if (ACT == LVG_ACT_RELU)
     {
         if (G == 0) r = (v > zero) ? v : zero;
-        else if (G == 1) r = (yy > zero) ? v : zero;
+        else if (G == 1) r = yyPos ? v : zero;
     }
     else if (ACT == LVG_ACT_LRELU)
     {
         if (G == 0) r = (v > zero) ? v : v * alpha;
-        else if (G == 1) r = (yy > zero) ? v : v * alpha;
+        else if (G == 1) r = yyPos ? v : v * alpha;
     }
     else if (ACT == LVG_ACT_TANH)
     {
@@ -127,69 +139,68 @@ __device__ __forceinline__ A bias_act_elem(int G, A in, A bias, A xr, A yr, A dy
     return r;
 }
 
-// 16 bytes per lane per access, kUnroll accesses per lane.
-template <class T, int ACT>
+// Vector kernel: 16 bytes per lane per access, UNROLL independent accesses per lane.
+// The tensor is viewed as `rows` x `rowVecs` 16-byte vectors such that the bias is resolved
+// without any per-element integer division:
+//   biasMode 1 (stepB % V == 0): a row = one bias segment of stepB elements, bias = b[row % sizeB];
+//   biasMode 2 (stepB == 1, sizeB % V == 0): a row = sizeB elements, bias = b[col*V .. col*V+V-1];
+//   biasMode 0: a single row.
+// grid = (ceil(rowVecs / (UNROLL*kThreads)), rowsY, rowsZ), row = z * rowsY + y.
+template <class T, int ACT, int G, int UNROLL>
 __global__ __launch_bounds__(kThreads) void bias_act_vec_kernel(BiasActArgs p)
 {
     typedef typename Elem<T>::acc_t A;
     constexpr int V = Elem<T>::kVec;
-    const int64_t nvec = p.n / V;
     const A alpha = (A)p.alpha, gain = (A)p.gain, clamp = (A)p.clamp;
-    const int G = p.grad;
 
-    const T* __restrict__ xp  = (const T*)p.x;
+    const int64_t row = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+    if (row >= p.rows) return;
+    const int64_t rowBase = row * p.rowVecs * V; // first element of this row
+
+    const T* __restrict__ xp  = (const T*)p.x + rowBase;
     const T* __restrict__ bp  = (const T*)p.b;
-    const T* __restrict__ xrp = (const T*)p.xref;
-    const T* __restrict__ yrp = (const T*)p.yref;
-    const T* __restrict__ dyp = (const T*)p.dy;
-    T* __restrict__ yp = (T*)p.y;
+    const T* __restrict__ xrp = p.xref ? (const T*)p.xref + rowBase : nullptr;
+    const T* __restrict__ yrp = p.yref ? (const T*)p.yref + rowBase : nullptr;
+    const T* __restrict__ dyp = p.dy ? (const T*)p.dy + rowBase : nullptr;
+    T* __restrict__ yp = (T*)p.y + rowBase;
 
-    const int64_t base = (int64_t)blockIdx.x * (kUnroll * kThreads) + threadIdx.x;
+    const int64_t col0 = (int64_t)blockIdx.x * (UNROLL * kThreads) + threadIdx.x;
 
-    Vec16<T> vx[kUnroll], vxr[kUnroll], vyr[kUnroll], vdy[kUnroll];
+    Vec16<T> vx[UNROLL], vxr[UNROLL], vyr[UNROLL], vdy[UNROLL];
     #pragma unroll
-    for (int u = 0; u < kUnroll; u++)
+    for (int u = 0; u < UNROLL; u++)
     {
-        const int64_t iv = base + (int64_t)u * kThreads;
-        if (iv < nvec)
+        const int64_t col = col0 + (int64_t)u * kThreads;
+        if (col < p.rowVecs)
         {
-            vx[u] = load_vec16<T>(xp + iv * V);
-            if (xrp) vxr[u] = load_vec16<T>(xrp + iv * V);
-            if (yrp) vyr[u] = load_vec16<T>(yrp + iv * V);
-            if (dyp) vdy[u] = load_vec16<T>(dyp + iv * V);
+            vx[u] = load_vec16<T>(xp + col * V);
+            if (G > 0 && ACT == LVG_ACT_SWISH) vxr[u] = load_vec16<T>(xrp + col * V);
+            if (G > 0 && ACT != LVG_ACT_SWISH && ACT != LVG_ACT_LINEAR) vyr[u] = load_vec16<T>(yrp + col * V);
+            if (G > 0 && ACT == LVG_ACT_LINEAR && yrp) vyr[u] = load_vec16<T>(yrp + col * V);
+            if (G == 2) vdy[u] = load_vec16<T>(dyp + col * V);
         }
     }
 
+    A rowBias = (A)0;
+    if (p.biasMode == 1) rowBias = (A)to_acc(bp[row % p.sizeB]);
+
     #pragma unroll
-    for (int u = 0; u < kUnroll; u++)
+    for (int u = 0; u < UNROLL; u++)
     {
-        const int64_t iv = base + (int64_t)u * kThreads;
-        if (iv >= nvec) continue;
-        const int64_t i0 = iv * V;
+        const int64_t col = col0 + (int64_t)u * kThreads;
+        if (col >= p.rowVecs) continue;
 
         A bias[V];
-        if (p.biasMode == 1)
+        if (p.biasMode == 2)
         {
-            int c;
-            if (p.n <= 0x7fffffffLL) c = (int)(((uint32_t)i0 / (uint32_t)p.stepB) % (uint32_t)p.sizeB);
-            else                     c = (int)((i0 / p.stepB) % p.sizeB);
-            const A bv = (A)to_acc(bp[c]);
-            #pragma unroll
-            for (int k = 0; k < V; k++) bias[k] = bv;
-        }
-        else if (p.biasMode == 2)
-        {
-            int c0;
-            if (p.n <= 0x7fffffffLL) c0 = (int)((uint32_t)i0 % (uint32_t)p.sizeB);
-            else                     c0 = (int)(i0 % p.sizeB);
-            Vec16<T> vb = load_vec16<T>(bp + c0);
+            Vec16<T> vb = load_vec16<T>(bp + col * V);
             #pragma unroll
             for (int k = 0; k < V; k++) bias[k] = (A)to_acc(vb.v[k]);
         }
         else
         {
             #pragma unroll
-            for (int k = 0; k < V; k++) bias[k] = (A)0;
+            for (int k = 0; k < V; k++) bias[k] = rowBias;
         }
 
         Vec16<T> out;
@@ -197,12 +208,12 @@ __global__ __launch_bounds__(kThreads) void bias_act_vec_kernel(BiasActArgs p)
         for (int k = 0; k < V; k++)
         {
             const A in  = (A)to_acc(vx[u].v[k]);
-            const A xr  = xrp ? (A)to_acc(vxr[u].v[k]) : (A)0;
-            const A yr  = yrp ? (A)to_acc(vyr[u].v[k]) : (A)0;
-            const A dyv = dyp ? (A)to_acc(vdy[u].v[k]) : (A)1;
-            out.v[k] = from_acc<T>(bias_act_elem<A, ACT>(G, in, bias[k], xr, yr, dyv, alpha, gain, clamp));
+            const A xr  = (G > 0 && ACT == LVG_ACT_SWISH) ? (A)to_acc(vxr[u].v[k]) : (A)0;
+            const A yr  = (G > 0 && ACT != LVG_ACT_SWISH && (ACT != LVG_ACT_LINEAR || yrp)) ? (A)to_acc(vyr[u].v[k]) : (A)0;
+            const A dyv = (G == 2) ? (A)to_acc(vdy[u].v[k]) : (A)1;
+            out.v[k] = from_acc<T>(bias_act_elem<A, ACT, G>(in, bias[k], xr, yr, dyv, alpha, gain, clamp));
         }
-        store_vec16<T>(yp + i0, out);
+        store_vec16<T>(yp + col * V, out);
     }
 }
 
@@ -220,26 +231,46 @@ __global__ __launch_bounds__(kThreads) void bias_act_scalar_kernel(BiasActArgs p
     const A xr  = p.xref ? (A)to_acc(((const T*)p.xref)[i]) : (A)0;
     const A yr  = p.yref ? (A)to_acc(((const T*)p.yref)[i]) : (A)0;
     const A dyv = p.dy   ? (A)to_acc(((const T*)p.dy)[i])   : (A)1;
-    ((T*)p.y)[i] = from_acc<T>(bias_act_elem<A, ACT>(p.grad, in, bias, xr, yr, dyv, (A)p.alpha, (A)p.gain, (A)p.clamp));
+    const A alpha = (A)p.alpha, gain = (A)p.gain, clamp = (A)p.clamp;
+    A r;
+    if (p.grad == 0)      r = bias_act_elem<A, ACT, 0>(in, bias, xr, yr, dyv, alpha, gain, clamp);
+    else if (p.grad == 1) r = bias_act_elem<A, ACT, 1>(in, bias, xr, yr, dyv, alpha, gain, clamp);
+    else                  r = bias_act_elem<A, ACT, 2>(in, bias, xr, yr, dyv, alpha, gain, clamp);
+    ((T*)p.y)[i] = from_acc<T>(r);
+}
+
+template <class T, int ACT, int G>
+int launch_vec(const BiasActArgs& p, hipStream_t stream)
+{
+    // rows are folded over grid y/z (each <= 65535)
+    const int64_t rowsY = p.rows < 65535 ? p.rows : 65535;
+    const int64_t rowsZ = lvg_ceil_div(p.rows, rowsY);
+    LVG_REQUIRE(rowsZ <= 65535, "bias_act: too many bias segments for one launch");
+    if (p.rowVecs <= kThreads)
+    {
+        hipLaunchKernelGGL((bias_act_vec_kernel<T, ACT, G, 1>), dim3(1, (unsigned)rowsY, (unsigned)rowsZ), dim3(kThreads), 0, stream, p);
+    }
+    else
+    {
+        const int64_t bx = lvg_ceil_div(p.rowVecs, (int64_t)kUnroll * kThreads);
+        LVG_REQUIRE(bx <= 0x7fffffffLL, "bias_act: tensor too large for one launch");
+        hipLaunchKernelGGL((bias_act_vec_kernel<T, ACT, G, kUnroll>), dim3((unsigned)bx, (unsigned)rowsY, (unsigned)rowsZ), dim3(kThreads), 0, stream, p);
+    }
+    return lvg_check_launch("bias_act_vec_kernel");
 }
 
 template <class T, int ACT>
 int launch_act(BiasActArgs& p, bool vecOk, hipStream_t stream)
 {
-    constexpr int V = Elem<T>::kVec;
     int64_t done = 0;
-    if (vecOk)
+    if (vecOk && p.rows > 0 && p.rowVecs > 0)
     {
-        const int64_t nvec = p.n / V;
-        if (nvec > 0)
-        {
-            const int64_t blocks = lvg_ceil_div(nvec, (int64_t)kUnroll * kThreads);
-            LVG_REQUIRE(blocks <= 0x7fffffffLL, "bias_act: tensor too large for one launch");
-            hipLaunchKernelGGL((bias_act_vec_kernel<T, ACT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
-            int rc = lvg_check_launch("bias_act_vec_kernel");
-            if (rc) return rc;
-        }
-        done = nvec * V;
+        int rc;
+        if (p.grad == 0)      rc = launch_vec<T, ACT, 0>(p, stream);
+        else if (p.grad == 1) rc = launch_vec<T, ACT, 1>(p, stream);
+        else                  rc = launch_vec<T, ACT, 2>(p, stream);
+        if (rc) return rc;
+        done = p.rows * p.rowVecs * Elem<T>::kVec;
     }
     if (done < p.n)
     {
@@ -296,15 +327,28 @@ extern "C" int lvg_bias_act(const void* x, const void* b, const void* xref, cons
     p.grad = grad;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
 
+    // Operands each grad form needs (bias_act.py:150,179,198 of the reference pass exactly these).
+    if (grad >= 1 && act == LVG_ACT_SWISH) LVG_REQUIRE(xref, "bias_act: swish backward needs xref");
+    if (grad >= 1 && act != LVG_ACT_SWISH && act != LVG_ACT_LINEAR) LVG_REQUIRE(yref, "bias_act: backward needs yref");
+    if (grad >= 1 && clamp >= 0 && act != LVG_ACT_SWISH) LVG_REQUIRE(yref, "bias_act: clamped backward needs yref");
+    if (grad == 2) LVG_REQUIRE(dy, "bias_act: grad 2 needs dy");
+
     const int V = (dtype == LVG_F32) ? 4 : (dtype == LVG_F64) ? 2 : 8;
     bool vecOk = lvg_aligned16(x) && lvg_aligned16(y) && (!xref || lvg_aligned16(xref)) &&
                  (!yref || lvg_aligned16(yref)) && (!dy || lvg_aligned16(dy));
     p.biasMode = 0;
+    p.rows = 1;
+    p.rowVecs = n / V;
     if (b)
     {
-        if (p.stepB % V == 0) p.biasMode = 1;
-        else if (p.stepB == 1 && p.sizeB % V == 0 && lvg_aligned16(b)) p.biasMode = 2;
+        if (p.stepB % V == 0 && n % p.stepB == 0) { p.biasMode = 1; p.rows = n / p.stepB; p.rowVecs = p.stepB / V; }
+        else if (p.stepB == 1 && p.sizeB % V == 0 && n % p.sizeB == 0 && lvg_aligned16(b)) { p.biasMode = 2; p.rows = n / p.sizeB; p.rowVecs = p.sizeB / V; }
         else vecOk = false;
+    }
+    else if (p.rowVecs > (int64_t)0x7fffffff * kUnroll)
+    {
+        // no bias: split a huge stream into rows so the x grid stays in range
+        p.rowVecs = 1 << 24; p.rows = (n / V) / p.rowVecs;
     }
 
     hipStream_t s = (hipStream_t)stream;

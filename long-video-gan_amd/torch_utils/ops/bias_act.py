@@ -143,7 +143,10 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
 
     is_identity = (act == 'linear' and gain == 1 and clamp < 0)
     keep_x = ('x' in spec.ref) or spec.has_2nd_grad
-    keep_y = 'y' in spec.ref
+    # 'linear' saves y only when clamped: the clamp mask of the backward needs the forward output.
+    # (The reference plugin path passes no yref for 'linear' and lets gradients through clamped
+    # elements, unlike its own ref path, bias_act.py:23,151-154; this follows the ref path.)
+    keep_y = ('y' in spec.ref) or (act == 'linear' and clamp >= 0)
     empty = torch.empty([0])
 
     class BiasActCuda(torch.autograd.Function):

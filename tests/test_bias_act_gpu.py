@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 from torch_utils.ops import bias_act
 
 DEV = 'cuda'
-TOL = {torch.float32: dict(rtol=1e-5, atol=1e-6), torch.float64: dict(rtol=1e-12, atol=1e-12),
+# float64: alpha/gain/clamp cross the C ABI as float32 (as in the reference plugin), hence 1e-6.
+TOL = {torch.float32: dict(rtol=1e-5, atol=1e-6), torch.float64: dict(rtol=1e-6, atol=1e-7),
        torch.float16: dict(rtol=2e-3, atol=2e-3), torch.bfloat16: dict(rtol=1.6e-2, atol=1.6e-2)}
 
 
@@ -38,7 +39,7 @@ def test_golden_all_activations_fwd_bwd_bwd2(dtype, oracle):
         np.testing.assert_allclose(host(y), g[p + 'y'], err_msg=str(sp), **tol)
         grads = torch.autograd.grad(y, [x] + ([b] if b is not None else []), dev(g[p + 'dy'], dtype), create_graph=True)
         mask = np.ones_like(g[p + 'dx'], dtype=bool)
-        if dtype == torch.float32 and sp['clamp'] is not None:
+        if sp['clamp'] is not None:
             # clamp boundary decided on the float32 forward output: skip elements within rounding of it
             mask = np.abs(np.abs(g[p + 'y']) - sp['clamp']) > 1e-5
         np.testing.assert_allclose(host(grads[0])[mask], g[p + 'dx'][mask], err_msg='dx ' + str(sp), **tol)
