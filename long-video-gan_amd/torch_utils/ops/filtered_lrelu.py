@@ -120,6 +120,7 @@ def _fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, 
     (fu_t, fu_n), (fd_t, fd_n) = tu, td
     if not lib.lvg_filtered_lrelu_supported(fu_n, fd_n, up, down, _hip.dtype_code(x.dtype)):
         return None, None, -1
+    b = b.contiguous()
     n, c, xh, xw = x.shape
     cw = xw * up + (px0 + px1) - (fu_n - 1)
     ch = xh * up + (py0 + py1) - (fu_n - 1)
