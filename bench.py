@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the low-resolution generator hot path on MI355X.
+
+One "step" = one generator update of train_lres on synthetic input: G forward (B clips of 128
+frames, 36x64, bf16 activations) -> discriminator forward -> softplus(-logits).mean().backward()
+-> data-parallel gradient exchange (RCCL all-reduce, no-op at N=1) -> Adam step. This is
+BASELINE.json configs[1] ("generator_lres 128-frame 36x64 bf16 forward+backward on 1 MI355X"); for
+N>1 every rank runs the same per-GPU batch (weak scaling) and the step includes the gradient
+all-reduce of the 83.2 M generator parameters.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. `roofline` is measured live: every launch of the custom HIP ops in
+the timed region is bracketed by HIP events on the launch stream, and the op with the largest
+total time is reported against the HBM peak with its algorithmic bytes.
+`cpu_baseline` (rank 0, N=1 only) times the CPU restatement of the same step (oracle/cpu_step.py)
+on a bounded 16-frame sample on the host cores."""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'long-video-gan_amd'))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+class OpTimer:
+    """Brackets every lvg_* launch with events on the current (= launch) stream."""
+
+    def __init__(self):
+        self.records = {}     # op -> list of (start_event, end_event, algorithmic_bytes)
+        self.enabled = False
+        self._orig = {}
+
+    def install(self):
+        from torch_utils.ops import bias_act, upfirdn2d
+
+        def wrap(mod, name, op, bytes_fn):
+            orig = getattr(mod, name)
+            self._orig[(mod, name)] = orig
+
+            def timed(*args, **kwargs):
+                if not self.enabled:
+                    return orig(*args, **kwargs)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                out = orig(*args, **kwargs)
+                b.record()
+                self.records.setdefault(op(args), []).append((a, b, bytes_fn(args, out)))
+                return out
+            setattr(mod, name, timed)
+
+        # bias_act._launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp)
+        def ba_bytes(args, out):
+            streams = 2 + sum(1 for t in args[2:5] if t is not None and t.numel() > 0)   # x + y (+xref/yref/dy)
+            return out.numel() * out.element_size() * streams
+        wrap(bias_act, '_launch', lambda a: 'bias_act_fwd' if a[5] == 0 else 'bias_act_bwd', ba_bytes)
+        # upfirdn2d._launch(x, f, upx, ...): (N_in + N_out) * s
+        wrap(upfirdn2d, '_launch', lambda a: 'upfirdn2d', lambda args, out: (args[0].numel() + out.numel()) * out.element_size())
+
+    def summary(self):
+        out = {}
+        for op, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            nbytes = sum(r[2] for r in recs)
+            out[op] = dict(launches=len(recs), total_ms=ms, bytes=nbytes, gbps=(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0)
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch-per-gpu', type=int, default=4)
+    ap.add_argument('--frames', type=int, default=128)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--forward-only', action='store_true', help='time G forward alone (frames/sec/GPU lres-G forward)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', init_method='env://')   # "nccl" = RCCL on ROCm
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from lvg import ddp
+    from lvg.models.lres import VideoDiscriminator, VideoGenerator
+
+    dtype = dict(bf16=torch.bfloat16, fp32=torch.float32, fp16=torch.float16)[args.dtype]
+    dev = torch.device('cuda', local_rank)
+    torch.manual_seed(0)                       # same random-init weights on every rank
+    G = VideoGenerator().to(dev).requires_grad_(True).train()
+    D = VideoDiscriminator(seq_length=args.frames, max_edge=64).to(dev).requires_grad_(False).train()
+    ddp.broadcast_module(G)
+    ddp.broadcast_module(D)
+    opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0, 0.99))
+    sync = ddp.FlatGradSync(G.parameters(), overlap=world > 1)
+    torch.manual_seed(1 + rank)                # per-rank noise stream (train_lres.py:69)
+    B, T = args.batch_per_gpu, args.frames
+
+    timer = OpTimer()
+    timer.install()
+
+    def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return G(B, T, dtype=dtype)
+        sync.zero()
+        if sync.overlap:
+            sync.arm()
+        video = G(B, T, dtype=dtype)
+        logits = D(video, dtype=dtype)
+        F.softplus(-logits).mean().backward()
+        sync.finish()
+        opt.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        ops = timer.summary()
+        dominant = max(ops, key=lambda k: ops[k]['total_ms']) if ops else None
+        roofline = None
+        if dominant is not None:
+            d = ops[dominant]
+            roofline = dict(bound='hbm', kernel=dominant, achieved=round(d['gbps'], 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                            frac=round(d['gbps'] / HBM_PEAK_GBPS, 4), traffic=_pmc_traffic(dominant),
+                            launches=d['launches'], avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
+                            algorithmic_bytes_per_launch=int(d['bytes'] / d['launches']))
+        result = {
+            'metric': 'frames/sec lres-G 128x36x64 ' + ('forward' if args.forward_only else 'forward+backward (generator update)'),
+            'value': round(frames / elapsed, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'generator_lres {T}-frame 36x64 {args.dtype} ' + ('forward' if args.forward_only else 'forward+backward through discriminator_lres, Adam step') + f', batch {B}/GPU',
+                       'global_batch': world * B, 'frames_per_clip': T, 'parallelism': f'dp{world}', 'params_G': 83215939},
+            'roofline': roofline,
+            'ops': {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1)) for k, v in ops.items()},
+            'step_ms_in_custom_ops': round(sum(v['total_ms'] for v in ops.values()) / args.steps, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = _cpu_baseline(forward_only=args.forward_only)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/*traffic*.json), else None."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+def _cpu_baseline(forward_only):
+    from oracle import cpu_step
+    return cpu_step.run(forward_only=forward_only)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,72 @@
+"""DiffAugment for videos ([N, C, T, H, W]): color, translation, cutout with one random draw per
+sample shared by all frames (reference model/diff_augment.py:20-102). Written against the same
+distributions; on-device, no host synchronisation."""
+
+import torch
+import torch.nn.functional as F
+
+
+def _per_sample(x: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    return torch.rand(x.size(0), 1, 1, 1, 1, dtype=x.dtype, device=x.device) * (hi - lo) + lo
+
+
+def color(x: torch.Tensor) -> torch.Tensor:
+    x = x + _per_sample(x, -0.5, 0.5)                                    # brightness
+    mean_c = x.mean(dim=1, keepdim=True)
+    x = (x - mean_c) * _per_sample(x, 0.0, 2.0) + mean_c                 # saturation
+    mean_all = x.mean(dim=(1, 2, 3, 4), keepdim=True)
+    return (x - mean_all) * _per_sample(x, 0.5, 1.5) + mean_all          # contrast
+
+
+def translation(x: torch.Tensor, ratio: float = 0.25) -> torch.Tensor:
+    n, c, t, h, w = x.shape
+    shift = round(max(h, w) * ratio)
+    dy = torch.randint(-shift, shift + 1, (n, 1), device=x.device)
+    dx = torch.randint(-shift, shift + 1, (n, 1), device=x.device)
+    iy = torch.arange(h, device=x.device).unsqueeze(0) + dy              # source row per output row
+    ix = torch.arange(w, device=x.device).unsqueeze(0) + dx
+    ok = ((iy >= 0) & (iy < h)).unsqueeze(2) & ((ix >= 0) & (ix < w)).unsqueeze(1)   # [n, h, w]
+    iy, ix = iy.clamp(0, h - 1), ix.clamp(0, w - 1)
+    flat = (iy.unsqueeze(2) * w + ix.unsqueeze(1)).reshape(n, 1, 1, h * w).expand(n, c, t, h * w)
+    out = x.reshape(n, c, t, h * w).gather(3, flat).reshape(n, c, t, h, w)
+    return out * ok.reshape(n, 1, 1, h, w).to(x.dtype)
+
+
+def cutout(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
+    n, c, t, h, w = x.shape
+    ch, cw = int(h * ratio + 0.5), int(w * ratio + 0.5)
+    oy = torch.randint(0, h + (1 - ch % 2), (n, 1, 1), device=x.device)
+    ox = torch.randint(0, w + (1 - cw % 2), (n, 1, 1), device=x.device)
+    yy = torch.arange(h, device=x.device).reshape(1, h, 1)
+    xx = torch.arange(w, device=x.device).reshape(1, 1, w)
+    # rows/cols the reference clamps into range are exactly those within the window clipped to the image
+    y0, y1 = (oy - ch // 2).clamp(0, h - 1), (oy - ch // 2 + ch - 1).clamp(0, h - 1)
+    x0, x1 = (ox - cw // 2).clamp(0, w - 1), (ox - cw // 2 + cw - 1).clamp(0, w - 1)
+    hole = (yy >= y0) & (yy <= y1) & (xx >= x0) & (xx <= x1)
+    return x * (~hole).reshape(n, 1, 1, h, w).to(x.dtype)
+
+
+_POLICIES = {'color': color, 'translation': translation, 'cutout': cutout}
+
+
+def diff_augment(x: torch.Tensor, policy: str = 'color,translation,cutout') -> torch.Tensor:
+    for name in [p for p in policy.split(',') if p]:
+        x = _POLICIES[name](x)
+    return x.contiguous()
+
+
+def temporal_scale_augment(video: torch.Tensor, seq_length: int, amount: float) -> torch.Tensor:
+    """Per-sample random time stretch by 2**U(-amount, amount) (bilinear along T), then random
+    pad/crop back to seq_length (reference video_gan_lres.py:242-263)."""
+    if amount <= 0:
+        return video
+    out = []
+    for v in video.permute(0, 1, 3, 4, 2):                       # [c, h, w, t] per sample
+        scale = float(2 ** torch.empty(()).uniform_(-amount, amount))
+        v = F.interpolate(v, mode='bilinear', align_corners=False, recompute_scale_factor=False, scale_factor=(1, scale))
+        room = max(0, seq_length - v.size(-1))
+        p0 = int(torch.randint(room + 1, ()))
+        v = F.pad(v, (p0, room - p0))
+        i0 = int(torch.randint(v.size(-1) - seq_length + 1, ()))
+        out.append(v[..., i0:i0 + seq_length])
+    return torch.stack(out).permute(0, 1, 4, 2, 3)

@@ -1,0 +1,164 @@
+"""Data-parallel gradient exchange: the reference's `utils.sync_grads` (utils.py:104-124) for one
+process per GPU over RCCL/xGMI.
+
+Reference behaviour (kept bit-for-bit in `sync_grads`): flatten all existing grads into one
+float vector, all-reduce(SUM) it in equal shards of <= 2**23 elements, divide by world size,
+multiply by `gain`, nan_to_num(nan=0, +-inf=+-1e5), scatter back.
+
+MI355X version (`FlatGradSync`): the flat vector is allocated ONCE and every `param.grad` is a
+view into it, so there is no pack (torch.cat) and no unpack copy per step; buckets are larger
+(xGMI is per-link bound, few big ring collectives beat many small ones) and, with
+`overlap=True`, each bucket's all-reduce is launched from an autograd hook as soon as its last
+gradient of the final micro-batch has been accumulated, overlapping with the rest of backward.
+Same mean / gain / nan_to_num semantics."""
+
+import math
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def sharded_all_mean(tensor: torch.Tensor, shard_size: int = 2 ** 23) -> torch.Tensor:
+    assert tensor.dim() == 1
+    if _world() > 1:
+        for shard in tensor.tensor_split(max(1, math.ceil(tensor.numel() / shard_size))):
+            dist.all_reduce(shard)
+    return tensor / _world()
+
+
+def sync_grads(network: nn.Module, gain: Optional[float] = None) -> None:
+    """Drop-in for the reference's utils.sync_grads (same arithmetic, same result)."""
+    params = [p for p in network.parameters() if p.grad is not None]
+    if not params:
+        return
+    flat = torch.cat([p.grad.flatten() for p in params])
+    flat = sharded_all_mean(flat)
+    if gain is not None:
+        flat = flat * gain
+    torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+    for p, g in zip(params, flat.split([p.numel() for p in params])):
+        p.grad = g.reshape(p.size())
+
+
+class FlatGradSync:
+    """Persistent flat gradient buffer with bucketed (optionally backward-overlapped) all-reduce.
+
+    Usage per optimizer step:
+        sync.zero()                      # instead of opt.zero_grad(set_to_none=True)
+        for micro-batch k: ... loss.backward()   (call sync.arm() before the LAST backward to overlap)
+        sync.finish(gain)                # wait, mean, gain, nan_to_num (in place)
+        opt.step()
+    """
+
+    def __init__(self, params: Iterable[nn.Parameter], bucket_numel: int = 1 << 25, overlap: bool = False):
+        self.params: List[nn.Parameter] = [p for p in params]
+        assert self.params, 'no parameters'
+        dev, dtype = self.params[0].device, self.params[0].dtype
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes), device=dev, dtype=dtype)
+        # Buckets follow REVERSE parameter order (roughly the order gradients become ready).
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += n
+        self.views = [self.flat[o:o + n].view_as(p) for p, o, n in zip(self.params, offs, sizes)]
+        self.buckets = []   # (start, end, [param indices])
+        end, members, count = len(self.flat), [], 0
+        for i in reversed(range(len(self.params))):
+            members.append(i)
+            count += sizes[i]
+            if count >= bucket_numel or i == 0:
+                self.buckets.append((offs[i], end, list(members)))
+                end, members, count = offs[i], [], 0
+        self.bucket_of = {}
+        for b, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self.bucket_of[i] = b
+        self.overlap = overlap
+        self._armed = False
+        self._pending = [0] * len(self.buckets)
+        self._work = []
+        self._hooks = []
+        if overlap:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.zero()
+
+    def _make_hook(self, index: int):
+        def hook(_param):
+            if not self._armed:
+                return
+            b = self.bucket_of[index]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int) -> None:
+        if _world() > 1:
+            s, e, _ = self.buckets[b]
+            self._work.append(dist.all_reduce(self.flat[s:e], async_op=True))
+
+    def zero(self) -> None:
+        """Zero the flat buffer and (re)attach the views as .grad of every parameter."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def arm(self) -> None:
+        """Call before the last backward of the step: buckets reduce as they fill."""
+        assert self.overlap
+        self._armed = True
+        for b, (_, _, mem) in enumerate(self.buckets):
+            self._pending[b] = sum(1 for i in mem if self.params[i].requires_grad)
+        self._launched = set()
+
+    def finish(self, gain: Optional[float] = None) -> None:
+        """Complete the exchange: mean over ranks, * gain, nan_to_num. In place on the flat buffer."""
+        if self._armed:
+            # buckets whose hooks never fired (unused parameters) still have to be reduced
+            for b in range(len(self.buckets)):
+                if self._pending[b] > 0:
+                    self._launch(b)
+            for w in self._work:
+                w.wait()
+            self._work.clear()
+            self._armed = False
+        elif _world() > 1:
+            for b in range(len(self.buckets)):
+                s, e, _ = self.buckets[b]
+                dist.all_reduce(self.flat[s:e])
+        scale = (1.0 / _world()) * (1.0 if gain is None else float(gain))
+        if scale != 1.0:
+            self.flat.mul_(scale)
+        torch.nan_to_num(self.flat, nan=0, posinf=1e5, neginf=-1e5, out=self.flat)
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:      # autograd replaced the view (grad was None during backward)
+                p.grad = v
+
+    def close(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()
+
+
+def broadcast_module(module: nn.Module, src: int = 0) -> None:
+    """Initial weight sync (reference video_gan_lres.py:77-79) as ONE flat broadcast per dtype
+    instead of one per tensor."""
+    if _world() == 1:
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch.cat([t.detach().reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        for t, piece in zip(group, flat.split([t.numel() for t in group])):
+            t.detach().copy_(piece.view_as(t))

