@@ -111,7 +111,7 @@ def main():
     D = VideoDiscriminator(seq_length=args.frames, max_edge=64).to(dev).requires_grad_(False).train()
     ddp.broadcast_module(G)
     ddp.broadcast_module(D)
-    opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0, 0.99))
+    opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0.0, 0.99))
     sync = ddp.FlatGradSync(G.parameters(), overlap=world > 1)
     torch.manual_seed(1 + rank)                # per-rank noise stream (train_lres.py:69)
     B, T = args.batch_per_gpu, args.frames

@@ -47,7 +47,10 @@ struct UpfirdnArgs
     int tileW, tileH;       // output tile
     int tilesX, tilesY;
     int inTW, inTH;         // input tile incl. halo
-    int midTH;              // rows of the row-filtered intermediate (= inTH)
+    int planesPerBlock;     // planes batched into one block (tiny planes)
+    int laneWLog, laneWInLog; // log2 of lanes along x for the output / input tile (fast kernel)
+    int uniformPlanes;      // xs[0] == C * xs[1] (and same for y): plane index * stride addresses a plane
+    int64_t totalPlanes;
 };
 
 constexpr int kGatherThreads = 256;
@@ -96,37 +99,33 @@ __global__ __launch_bounds__(kGatherThreads) void upfirdn2d_gather_kernel(Upfird
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tiled kernel. Block = 256 threads as 64 (x) x 4 (y). One block = one output tile of one plane.
-// LDS layout (floats): [taps X: fwPad][taps Y: fhPad][input tile inTH x inTW]
-//                      [separable only: row-filtered tile inTH x tileW]
-// 2-D filters are stored as fh x fw flipped taps in the tap area.
+// Tiled kernel. Block = 256 threads as 64 (x) x 4 (y). One block = one output tile of P
+// consecutive planes (P > 1 only when a whole plane is one tile: the many tiny planes of the
+// low-resolution layers are batched so that a block still moves a few thousand elements).
+// LDS layout (floats): [taps X][taps Y][input tiles P x inTH x inTW][SEP: row-filtered P x inTH x tileW]
+// MODE: 0 dense 2-D taps, 1 separable (rows then columns), 2 columns only (fw == 1, no resampling in x).
+// Global loads are issued kLd at a time per thread before any LDS write (bytes in flight).
 
-constexpr int kTX = 64, kTY = 4;
+constexpr int kTX = 64, kTY = 4, kLd = 8;
 
-template <class T, int UPX, int UPY, int DOWNX, int DOWNY, bool SEP>
+template <class T, int UPX, int UPY, int DOWNX, int DOWNY, int MODE>
 __global__ __launch_bounds__(kTX * kTY) void upfirdn2d_tiled_kernel(UpfirdnArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * kTX + tx;
+    constexpr bool SEP = (MODE == 1);
 
-    const int nTapX = SEP ? p.fw : p.fw * p.fh;
+    const int nTapX = (MODE == 0) ? p.fw * p.fh : p.fw;
     const int tapPadX = (nTapX + 3) & ~3;
-    const int tapPadY = SEP ? ((p.fh + 3) & ~3) : 0;
+    const int tapPadY = (MODE == 0) ? 0 : ((p.fh + 3) & ~3);
     float* sfx = smem;
     float* sfy = smem + tapPadX;
     float* sin = sfy + tapPadY;
-    float* smid = sin + p.inTH * p.inTW; // SEP only
+    float* smid = sin + p.planesPerBlock * p.inTH * p.inTW; // SEP only
 
     // Flipped taps into LDS.
-    if (SEP)
-    {
-        for (int k = tid; k < p.fw; k += kTX * kTY)
-            sfx[k] = p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f;
-        for (int k = tid; k < p.fh; k += kTX * kTY)
-            sfy[k] = p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f;
-    }
-    else
+    if (MODE == 0)
     {
         for (int k = tid; k < p.fw * p.fh; k += kTX * kTY)
         {
@@ -135,13 +134,18 @@ __global__ __launch_bounds__(kTX * kTY) void upfirdn2d_tiled_kernel(UpfirdnArgs 
             sfx[k] = p.f2d[sy * p.fsy + sx * p.fsx];
         }
     }
+    else
+    {
+        for (int k = tid; k < p.fw; k += kTX * kTY) sfx[k] = p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f;
+        for (int k = tid; k < p.fh; k += kTX * kTY) sfy[k] = p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f;
+    }
 
-    // Which tile / plane.
+    // Which tile / planes.
     int b = blockIdx.x;
     const int tileX = b % p.tilesX; b /= p.tilesX;
     const int tileY = b % p.tilesY; b /= p.tilesY;
-    const int ch = b % p.c;
-    const int nb = b / p.c;
+    const int64_t plane0 = (int64_t)b * p.planesPerBlock;
+    const int nPlanes = (int)((p.totalPlanes - plane0) < p.planesPerBlock ? (p.totalPlanes - plane0) : p.planesPerBlock);
 
     const int outX0 = tileX * p.tileW, outY0 = tileY * p.tileH;
     const int midX0 = outX0 * DOWNX + UPX - 1 - p.padx0;
@@ -149,87 +153,102 @@ __global__ __launch_bounds__(kTX * kTY) void upfirdn2d_tiled_kernel(UpfirdnArgs 
     const int inX0 = lvg_floor_div(midX0, UPX);
     const int inY0 = lvg_floor_div(midY0, UPY);
 
-    // Load the input tile (zero outside the plane), coalesced along W.
-    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1];
-    for (int r = ty; r < p.inTH; r += kTY)
+    // Plane base offsets: planes are (n, c) pairs; with xs[0] == C * xs[1] they are equidistant.
+    const int64_t planeStrideX = p.xs[1], planeStrideY = p.ys[1];
+    const int64_t xBase = p.uniformPlanes ? plane0 * planeStrideX : (plane0 / p.c) * p.xs[0] + (plane0 % p.c) * p.xs[1];
+    const int64_t yBase = p.uniformPlanes ? plane0 * planeStrideY : (plane0 / p.c) * p.ys[0] + (plane0 % p.c) * p.ys[1];
+    const T* xp = (const T*)p.x + xBase;
+    T* yp = (T*)p.y + yBase;
+
+    // Load the input tiles (zero outside the plane). Rows R = plane * inTH + r run over ty.
+    const int totalRows = nPlanes * p.inTH;
+    for (int q0 = 0; q0 < p.inTW; q0 += kTX)
     {
-        const int iy = inY0 + r;
-        const bool rowOk = (iy >= 0) && (iy < p.ih);
-        const T* rowp = xp + (int64_t)iy * p.xs[2];
-        for (int q = tx; q < p.inTW; q += kTX)
+        const int q = q0 + tx;
+        const int ix = inX0 + q;
+        const bool colOk = (q < p.inTW) && ix >= 0 && ix < p.iw;
+        for (int R0 = 0; R0 < totalRows; R0 += kTY * kLd)
         {
-            const int ix = inX0 + q;
-            float v = 0.0f;
-            if (rowOk && ix >= 0 && ix < p.iw) v = (float)to_acc(rowp[(int64_t)ix * p.xs[3]]);
-            sin[r * p.inTW + q] = v;
+            float v[kLd];
+            #pragma unroll
+            for (int k = 0; k < kLd; k++)
+            {
+                const int R = R0 + ty + k * kTY;
+                const int pl = R / p.inTH, r = R - pl * p.inTH;
+                const int iy = inY0 + r;
+                v[k] = 0.0f;
+                if (colOk && R < totalRows && iy >= 0 && iy < p.ih)
+                    v[k] = (float)to_acc(xp[(int64_t)pl * planeStrideX + (int64_t)iy * p.xs[2] + (int64_t)ix * p.xs[3]]);
+            }
+            #pragma unroll
+            for (int k = 0; k < kLd; k++)
+            {
+                const int R = R0 + ty + k * kTY;
+                if (q < p.inTW && R < totalRows) sin[R * p.inTW + q] = v[k];
+            }
         }
     }
     __syncthreads();
 
-    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1];
-
     if (SEP)
     {
-        // Pass 1: rows. smid[r][ox] = sum_k sin[r][relX + k] * sfx[tap0 + k*UPX]
-        for (int r = ty; r < p.inTH; r += kTY)
+        // Pass 1: rows. smid[R][ox] = sum_k sin[R][relX + k] * sfx[tap0 + k*UPX]
+        for (int ox = tx; ox < p.tileW; ox += kTX)
         {
-            for (int ox = tx; ox < p.tileW; ox += kTX)
+            const int midX = midX0 + ox * DOWNX;
+            const int inX = lvg_floor_div(midX, UPX);
+            const int tap0 = (inX + 1) * UPX - midX - 1;
+            for (int R = ty; R < totalRows; R += kTY)
             {
-                const int midX = midX0 + ox * DOWNX;
-                const int inX = lvg_floor_div(midX, UPX);
-                int tap = (inX + 1) * UPX - midX - 1;
-                const float* src = sin + r * p.inTW + (inX - inX0);
+                const float* src = sin + R * p.inTW + (inX - inX0);
                 float acc = 0.0f;
-                for (; tap < p.fw; tap += UPX) acc += (*src++) * sfx[tap];
-                smid[r * p.tileW + ox] = acc;
+                for (int tap = tap0; tap < p.fw; tap += UPX) acc = fmaf(*src++, sfx[tap], acc);
+                smid[R * p.tileW + ox] = acc;
             }
         }
         __syncthreads();
-        // Pass 2: columns.
-        for (int oy = ty; oy < p.tileH; oy += kTY)
-        {
-            const int gy = outY0 + oy;
-            if (gy >= p.oh) break;
-            const int midY = midY0 + oy * DOWNY;
-            const int inY = lvg_floor_div(midY, UPY);
-            const int tapY0 = (inY + 1) * UPY - midY - 1;
-            for (int ox = tx; ox < p.tileW; ox += kTX)
-            {
-                const int gx = outX0 + ox;
-                if (gx >= p.ow) break;
-                const float* src = smid + (inY - inY0) * p.tileW + ox;
-                float acc = 0.0f;
-                for (int tap = tapY0; tap < p.fh; tap += UPY, src += p.tileW) acc += (*src) * sfy[tap];
-                yp[(int64_t)gy * p.ys[2] + (int64_t)gx * p.ys[3]] = from_acc<T>(acc * p.gain);
-            }
-        }
     }
-    else
+
+    const float* colSrc = SEP ? smid : sin;
+    const int colStride = SEP ? p.tileW : p.inTW;
+    const int outRows = nPlanes * p.tileH;
+    for (int ox = tx; ox < p.tileW; ox += kTX)
     {
-        for (int oy = ty; oy < p.tileH; oy += kTY)
+        const int gx = outX0 + ox;
+        if (gx >= p.ow) break;
+        int relX = ox, tapX0 = 0;
+        if (MODE != 1)
         {
+            const int midX = midX0 + ox * DOWNX;
+            const int inX = lvg_floor_div(midX, UPX);
+            tapX0 = (inX + 1) * UPX - midX - 1;
+            relX = inX - inX0;
+        }
+        for (int RO = ty; RO < outRows; RO += kTY)
+        {
+            const int pl = RO / p.tileH, oy = RO - pl * p.tileH;
             const int gy = outY0 + oy;
-            if (gy >= p.oh) break;
+            if (gy >= p.oh) continue;
             const int midY = midY0 + oy * DOWNY;
             const int inY = lvg_floor_div(midY, UPY);
             const int tapY0 = (inY + 1) * UPY - midY - 1;
-            for (int ox = tx; ox < p.tileW; ox += kTX)
+            const float* src = colSrc + (pl * p.inTH + (inY - inY0)) * colStride + relX;
+            float acc = 0.0f;
+            if (MODE == 0)
             {
-                const int gx = outX0 + ox;
-                if (gx >= p.ow) break;
-                const int midX = midX0 + ox * DOWNX;
-                const int inX = lvg_floor_div(midX, UPX);
-                const int tapX0 = (inX + 1) * UPX - midX - 1;
-                const float* srow = sin + (inY - inY0) * p.inTW + (inX - inX0);
-                float acc = 0.0f;
-                for (int tyy = tapY0; tyy < p.fh; tyy += UPY, srow += p.inTW)
+                for (int tyy = tapY0; tyy < p.fh; tyy += UPY, src += colStride)
                 {
-                    const float* src = srow;
+                    const float* s2 = src;
                     const float* frow = sfx + tyy * p.fw;
-                    for (int txx = tapX0; txx < p.fw; txx += UPX) acc += (*src++) * frow[txx];
+                    for (int txx = tapX0; txx < p.fw; txx += UPX) acc = fmaf(*s2++, frow[txx], acc);
                 }
-                yp[(int64_t)gy * p.ys[2] + (int64_t)gx * p.ys[3]] = from_acc<T>(acc * p.gain);
             }
+            else
+            {
+                for (int tap = tapY0; tap < p.fh; tap += UPY, src += colStride) acc = fmaf(*src, sfy[tap], acc);
+                if (MODE == 2) acc *= sfx[0];
+            }
+            yp[(int64_t)pl * planeStrideY + (int64_t)gy * p.ys[2] + (int64_t)gx * p.ys[3]] = from_acc<T>(acc * p.gain);
         }
     }
 }
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(kTX * kTY) void upfirdn2d_tiled_kernel(UpfirdnArgs 
 // ---------------------------------------------------------------------------------------------
 // Host side.
 
-constexpr int kMaxLdsBytes = 64 * 1024; // per block: keeps >= 2 blocks per CU resident (160 KiB LDS)
+constexpr int kMaxLdsBytes = 40 * 1024; // per block: >= 4 blocks per CU resident (160 KiB LDS)
 
 inline int in_extent(int outExtent, int up, int down, int taps)
 {
@@ -247,18 +266,17 @@ inline int in_extent(int outExtent, int up, int down, int taps)
 template <class T, int UPX, int UPY, int DOWNX, int DOWNY>
 int launch_tiled(UpfirdnArgs& p, bool sep, hipStream_t stream)
 {
-    // Output tile: as much of the plane as fits, W first (coalescing), bounded by LDS.
+    const int mode = !sep ? 0 : ((p.fw == 1 && UPX == 1 && DOWNX == 1) ? 2 : 1);
+    const int64_t tapWords = (mode == 0) ? ((p.fw * p.fh + 3) & ~3) : (((p.fw + 3) & ~3) + ((p.fh + 3) & ~3));
     // Balanced split so the last tile of a row/column is not a sliver.
     int maxW = 128, maxH = 64;
     for (;;)
     {
-        const int tileW = (p.ow + (p.ow + maxW - 1) / maxW - 1) / ((p.ow + maxW - 1) / maxW);
-        const int tileH = (p.oh + (p.oh + maxH - 1) / maxH - 1) / ((p.oh + maxH - 1) / maxH);
-        p.tileW = tileW; p.tileH = tileH;
-        p.inTW = in_extent(tileW, UPX, DOWNX, p.fw);
-        p.inTH = in_extent(tileH, UPY, DOWNY, p.fh);
-        const int64_t taps = sep ? (((p.fw + 3) & ~3) + ((p.fh + 3) & ~3)) : ((p.fw * p.fh + 3) & ~3);
-        const int64_t words = taps + (int64_t)p.inTH * p.inTW + (sep ? (int64_t)p.inTH * tileW : 0);
+        const int nx = (p.ow + maxW - 1) / maxW, ny = (p.oh + maxH - 1) / maxH;
+        p.tileW = (p.ow + nx - 1) / nx; p.tileH = (p.oh + ny - 1) / ny;
+        p.inTW = in_extent(p.tileW, UPX, DOWNX, p.fw);
+        p.inTH = in_extent(p.tileH, UPY, DOWNY, p.fh);
+        const int64_t words = tapWords + (int64_t)p.inTH * p.inTW + (mode == 1 ? (int64_t)p.inTH * p.tileW : 0);
         if (words * 4 <= kMaxLdsBytes) break;
         if (maxH > 8) maxH /= 2;
         else if (maxW > 32) maxW /= 2;
@@ -266,15 +284,629 @@ int launch_tiled(UpfirdnArgs& p, bool sep, hipStream_t stream)
     }
     p.tilesX = (p.ow + p.tileW - 1) / p.tileW;
     p.tilesY = (p.oh + p.tileH - 1) / p.tileH;
-    const int64_t blocks = (int64_t)p.tilesX * p.tilesY * p.n * p.c;
+    p.totalPlanes = (int64_t)p.n * p.c;
+    p.uniformPlanes = (p.n == 1) || (p.xs[0] == (int64_t)p.c * p.xs[1] && p.ys[0] == (int64_t)p.c * p.ys[1]);
+    // Batch small planes: aim for >= 4096 outputs per block within the LDS budget.
+    p.planesPerBlock = 1;
+    if (p.tilesX == 1 && p.tilesY == 1 && p.uniformPlanes)
+    {
+        const int64_t perPlaneWords = (int64_t)p.inTH * p.inTW + (mode == 1 ? (int64_t)p.inTH * p.tileW : 0);
+        int64_t want = 4096 / ((int64_t)p.oh * p.ow);
+        const int64_t fit = (kMaxLdsBytes / 4 - tapWords) / perPlaneWords;
+        if (want > fit) want = fit;
+        if (want > 64) want = 64;
+        if (want > p.totalPlanes) want = p.totalPlanes;
+        if (want > 1) p.planesPerBlock = (int)want;
+    }
+    const int64_t planeBlocks = (p.totalPlanes + p.planesPerBlock - 1) / p.planesPerBlock;
+    const int64_t blocks = (int64_t)p.tilesX * p.tilesY * planeBlocks;
     if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
-    const int64_t taps = sep ? (((p.fw + 3) & ~3) + ((p.fh + 3) & ~3)) : ((p.fw * p.fh + 3) & ~3);
-    const size_t lds = (size_t)(taps + (int64_t)p.inTH * p.inTW + (sep ? (int64_t)p.inTH * p.tileW : 0)) * 4;
-    if (sep)
-        hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, true>), dim3((unsigned)blocks), dim3(kTX, kTY), lds, stream, p);
-    else
-        hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, false>), dim3((unsigned)blocks), dim3(kTX, kTY), lds, stream, p);
+    const size_t lds = (size_t)(tapWords + (int64_t)p.planesPerBlock * ((int64_t)p.inTH * p.inTW + (mode == 1 ? (int64_t)p.inTH * p.tileW : 0))) * 4;
+    const dim3 grid((unsigned)blocks), block(kTX, kTY);
+    if (mode == 0)      hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, 0>), grid, block, lds, stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, 1>), grid, block, lds, stream, p);
+    else                hipLaunchKernelGGL((upfirdn2d_tiled_kernel<T, UPX, UPY, DOWNX, DOWNY, 2>), grid, block, lds, stream, p);
     return lvg_check_launch("upfirdn2d_tiled_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast kernel for short filters (<= FPX x FPY taps, the 4-tap [1,3,3,1] family that carries the
+// low-resolution generator/discriminator): same tiling as above, but tap counts are compile-time,
+// taps live in registers, loops are fully unrolled, planes are an outer (wave-uniform) loop so no
+// per-element integer division is left, and offsets inside a plane are 32-bit.
+// MODE 0 (dense 2-D) is only instantiated without upsampling.
+
+template <int UP, int FP>
+__device__ __forceinline__ float tap_for_phase(const float (&f)[FP], int ph, int k)
+{
+    // f[(UP - 1 - ph) + k * UP] with a compile-time k and a runtime phase in [0, UP)
+    float r = f[(UP - 1) + k * UP];
+    #pragma unroll
+    for (int q = 1; q < UP; q++) r = (ph == q) ? f[(UP - 1 - q) + k * UP] : r;
+    return r;
+}
+
+template <class T, int UPX, int UPY, int DOWNX, int DOWNY, int MODE, int FPX, int FPY>
+__global__ __launch_bounds__(kTX * kTY) void upfirdn2d_fast_kernel(UpfirdnArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NKX = FPX / UPX, NKY = FPY / UPY;
+    constexpr bool SEP = (MODE == 1);
+    // Thread mapping: LW lanes along x (power of two <= 64 covering the tile width), the rest along
+    // rows -- narrow planes (W = 4..32) keep every lane of a wave busy.
+    const int tid = threadIdx.y * kTX + threadIdx.x;
+    const int lwLog = p.laneWLog, lwInLog = p.laneWInLog;
+    const int LW = 1 << lwLog, LH = (kTX * kTY) >> lwLog;
+    const int tx = tid & (LW - 1), ty = tid >> lwLog;
+    const int LWI = 1 << lwInLog, LHI = (kTX * kTY) >> lwInLog;
+    const int txi = tid & (LWI - 1), tyi = tid >> lwInLog;
+    float* sin = smem;
+    float* smid = sin + p.planesPerBlock * p.inTH * p.inTW;
+
+    // Flipped, zero-padded taps in registers (wave-uniform loads).
+    float fxr[FPX], fyr[FPY], f2[(MODE == 0) ? FPY * FPX : 1];
+    if (MODE == 0)
+    {
+        #pragma unroll
+        for (int ky = 0; ky < FPY; ky++)
+            #pragma unroll
+            for (int kx = 0; kx < FPX; kx++)
+            {
+                const int sy = p.flip ? ky : p.fh - 1 - ky, sx = p.flip ? kx : p.fw - 1 - kx;
+                f2[ky * FPX + kx] = (ky < p.fh && kx < p.fw) ? p.f2d[sy * p.fsy + sx * p.fsx] : 0.0f;
+            }
+    }
+    else
+    {
+        #pragma unroll
+        for (int k = 0; k < FPX; k++) fxr[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        #pragma unroll
+        for (int k = 0; k < FPY; k++) fyr[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+
+    int b = blockIdx.x;
+    const int tileX = b % p.tilesX; b /= p.tilesX;
+    const int tileY = b % p.tilesY; b /= p.tilesY;
+    const int64_t plane0 = (int64_t)b * p.planesPerBlock;
+    const int nPlanes = (int)((p.totalPlanes - plane0) < p.planesPerBlock ? (p.totalPlanes - plane0) : p.planesPerBlock);
+
+    const int outX0 = tileX * p.tileW, outY0 = tileY * p.tileH;
+    const int midX0 = outX0 * DOWNX + UPX - 1 - p.padx0;
+    const int midY0 = outY0 * DOWNY + UPY - 1 - p.pady0;
+    const int inX0 = lvg_floor_div(midX0, UPX);
+    const int inY0 = lvg_floor_div(midY0, UPY);
+
+    const int64_t xBase = p.uniformPlanes ? plane0 * p.xs[1] : (plane0 / p.c) * p.xs[0] + (plane0 % p.c) * p.xs[1];
+    const int64_t yBase = p.uniformPlanes ? plane0 * p.ys[1] : (plane0 / p.c) * p.ys[0] + (plane0 % p.c) * p.ys[1];
+    const int xs2 = (int)p.xs[2], xs3 = (int)p.xs[3], ys2 = (int)p.ys[2], ys3 = (int)p.ys[3];
+    const int inTW = p.inTW, inTH = p.inTH, tileW = p.tileW, tileH = p.tileH;
+
+    // ---- load (zero outside the plane), kLd loads in flight per thread ----
+    for (int pl = 0; pl < nPlanes; pl++)
+    {
+        const T* xp = (const T*)p.x + xBase + (int64_t)pl * p.xs[1];
+        float* dstPlane = sin + pl * inTH * inTW;
+        for (int q0 = 0; q0 < inTW; q0 += LWI)
+        {
+            const int q = q0 + txi;
+            const int ix = inX0 + q;
+            const bool colOk = (q < inTW) && ix >= 0 && ix < p.iw;
+            const int colOff = ix * xs3;
+            for (int r0 = 0; r0 < inTH; r0 += LHI * kLd)
+            {
+                float v[kLd];
+                #pragma unroll
+                for (int k = 0; k < kLd; k++)
+                {
+                    const int r = r0 + tyi + k * LHI;
+                    const int iy = inY0 + r;
+                    v[k] = 0.0f;
+                    if (colOk && r < inTH && iy >= 0 && iy < p.ih) v[k] = (float)to_acc(xp[iy * xs2 + colOff]);
+                }
+                #pragma unroll
+                for (int k = 0; k < kLd; k++)
+                {
+                    const int r = r0 + tyi + k * LHI;
+                    if (q < inTW && r < inTH) dstPlane[r * inTW + q] = v[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int totalRows = nPlanes * inTH;
+    if (SEP)
+    {
+        for (int ox = tx; ox < tileW; ox += LW)
+        {
+            const int midX = midX0 + ox * DOWNX;
+            const int inX = lvg_floor_div(midX, UPX);
+            const int ph = midX - inX * UPX;
+            float tv[NKX];
+            #pragma unroll
+            for (int k = 0; k < NKX; k++) tv[k] = tap_for_phase<UPX, FPX>(fxr, ph, k);
+            const float* src0 = sin + (inX - inX0);
+            for (int R = ty; R < totalRows; R += LH)
+            {
+                const float* src = src0 + R * inTW;
+                float acc = 0.0f;
+                #pragma unroll
+                for (int k = 0; k < NKX; k++) acc = fmaf(src[k], tv[k], acc);
+                smid[R * tileW + ox] = acc;
+            }
+        }
+        __syncthreads();
+    }
+
+    const float* colSrc = SEP ? smid : sin;
+    const int colStride = SEP ? tileW : inTW;
+    for (int ox = tx; ox < tileW; ox += LW)
+    {
+        const int gx = outX0 + ox;
+        if (gx >= p.ow) break;
+        int relX = ox;
+        if (MODE != 1) relX = lvg_floor_div(midX0 + ox * DOWNX, UPX) - inX0;   // UPX == 1 for MODE 0 / 2
+        const float scaleX = (MODE == 2) ? fxr[0] * p.gain : p.gain;
+        for (int pl = 0; pl < nPlanes; pl++)
+        {
+            T* yp = (T*)p.y + yBase + (int64_t)pl * p.ys[1];
+            const float* planeSrc = colSrc + pl * inTH * colStride + relX;
+            for (int oy = ty; oy < tileH; oy += LH)
+            {
+                const int gy = outY0 + oy;
+                if (gy >= p.oh) break;
+                const int midY = midY0 + oy * DOWNY;
+                const int inY = lvg_floor_div(midY, UPY);
+                const int phY = midY - inY * UPY;
+                const float* src = planeSrc + (inY - inY0) * colStride;
+                float acc = 0.0f;
+                if (MODE == 0)
+                {
+                    #pragma unroll
+                    for (int ky = 0; ky < FPY; ky++)
+                        #pragma unroll
+                        for (int kx = 0; kx < FPX; kx++) acc = fmaf(src[ky * colStride + kx], f2[ky * FPX + kx], acc);
+                }
+                else
+                {
+                    #pragma unroll
+                    for (int k = 0; k < NKY; k++) acc = fmaf(src[k * colStride], tap_for_phase<UPY, FPY>(fyr, phY, k), acc);
+                }
+                yp[gy * ys2 + gx * ys3] = from_acc<T>(acc * scaleX);
+            }
+        }
+    }
+}
+
+template <class T, int UPX, int UPY, int DOWNX, int DOWNY, int FP>
+int launch_fast(UpfirdnArgs& p, bool sep, hipStream_t stream)
+{
+    const int mode = !sep ? 0 : ((p.fw == 1 && UPX == 1 && DOWNX == 1) ? 2 : 1);
+    if (mode == 0 && (UPX != 1 || UPY != 1)) return LVG_ERR_UNSUPPORTED;
+    // Tile: the runtime geometry code is shared with the generic tiled kernel, but extents use the
+    // PADDED tap counts because the unrolled loops read FP / UP samples per output.
+    const int fwReal = p.fw, fhReal = p.fh;
+    const int fwPad = (mode == 2) ? 1 : FP, fhPad = FP;
+    int maxW = 128, maxH = 64;
+    int64_t perPlaneWords = 0;
+    for (;;)
+    {
+        const int nx = (p.ow + maxW - 1) / maxW, ny = (p.oh + maxH - 1) / maxH;
+        p.tileW = (p.ow + nx - 1) / nx; p.tileH = (p.oh + ny - 1) / ny;
+        p.inTW = in_extent(p.tileW, UPX, DOWNX, fwPad);
+        p.inTH = in_extent(p.tileH, UPY, DOWNY, fhPad);
+        perPlaneWords = (int64_t)p.inTH * p.inTW + (mode == 1 ? (int64_t)p.inTH * p.tileW : 0);
+        if (perPlaneWords * 4 <= kMaxLdsBytes) break;
+        if (maxH > 8) maxH /= 2;
+        else if (maxW > 32) maxW /= 2;
+        else return LVG_ERR_UNSUPPORTED;
+    }
+    (void)fwReal; (void)fhReal;
+    p.tilesX = (p.ow + p.tileW - 1) / p.tileW;
+    p.tilesY = (p.oh + p.tileH - 1) / p.tileH;
+    p.totalPlanes = (int64_t)p.n * p.c;
+    p.uniformPlanes = (p.n == 1) || (p.xs[0] == (int64_t)p.c * p.xs[1] && p.ys[0] == (int64_t)p.c * p.ys[1]);
+    p.planesPerBlock = 1;
+    if (p.tilesX == 1 && p.tilesY == 1 && p.uniformPlanes)
+    {
+        int64_t want = 4096 / ((int64_t)p.oh * p.ow);
+        const int64_t fit = (kMaxLdsBytes / 4) / perPlaneWords;
+        if (want > fit) want = fit;
+        if (want > 64) want = 64;
+        if (want > p.totalPlanes) want = p.totalPlanes;
+        if (want > 1) p.planesPerBlock = (int)want;
+    }
+    // 32-bit offsets inside a plane
+    const int64_t xExtent = (int64_t)(p.ih - 1) * (p.xs[2] < 0 ? -p.xs[2] : p.xs[2]) + (int64_t)(p.iw - 1) * (p.xs[3] < 0 ? -p.xs[3] : p.xs[3]);
+    const int64_t yExtent = (int64_t)(p.oh - 1) * p.ys[2] + (int64_t)(p.ow - 1) * p.ys[3];
+    if (xExtent >= 0x7fffffffLL || yExtent >= 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    const int64_t planeBlocks = (p.totalPlanes + p.planesPerBlock - 1) / p.planesPerBlock;
+    const int64_t blocks = (int64_t)p.tilesX * p.tilesY * planeBlocks;
+    if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    p.laneWLog = 0; while ((1 << p.laneWLog) < p.tileW && p.laneWLog < 6) p.laneWLog++;
+    p.laneWInLog = 0; while ((1 << p.laneWInLog) < p.inTW && p.laneWInLog < 6) p.laneWInLog++;
+    const size_t lds = (size_t)((int64_t)p.planesPerBlock * perPlaneWords) * 4;
+    const dim3 grid((unsigned)blocks), block(kTX, kTY);
+    if (mode == 0)      { if constexpr (UPX == 1 && UPY == 1) hipLaunchKernelGGL((upfirdn2d_fast_kernel<T, UPX, UPY, DOWNX, DOWNY, 0, FP, FP>), grid, block, lds, stream, p); }
+    else if (mode == 1) hipLaunchKernelGGL((upfirdn2d_fast_kernel<T, UPX, UPY, DOWNX, DOWNY, 1, FP, FP>), grid, block, lds, stream, p);
+    else                { if constexpr (UPX == 1 && DOWNX == 1) hipLaunchKernelGGL((upfirdn2d_fast_kernel<T, UPX, UPY, DOWNX, DOWNY, 2, 1, FP>), grid, block, lds, stream, p); }
+    return lvg_check_launch("upfirdn2d_fast_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-streaming kernels for the workhorse of the low-resolution networks: separable <= 4-tap
+// filters with x2 up- or down-sampling on NARROW planes (W <= 64: every [N, (C T), H, W] view of
+// generator_lres / discriminator_lres). No LDS memory and no barriers:
+//   * a row of a plane lives across the lanes of a wave (one lane per column; planes narrower than
+//     64 are packed side by side, 64 / GW planes per wave);
+//   * the row (x) taps are gathered from neighbouring lanes with wave shuffles;
+//   * the column (y) taps run over a sliding window of row results kept in registers while the wave
+//     streams down the plane, kRows input rows in flight per lane.
+// Every input element is loaded exactly once and every output element stored once.
+
+constexpr int kWaveThreads = 256;
+
+struct WaveGeom { int gwLog; };
+
+template <class T>
+__device__ __forceinline__ float wave_load(const T* rowp, int x, bool ok) { return ok ? (float)to_acc(rowp[x]) : 0.0f; }
+
+// Down: y[oy][ox] = gain * sum_ky sum_kx x[2 oy - pady0 + ky][2 ox - padx0 + kx] * ffy[ky] * ffx[kx]
+template <class T>
+__global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_kernel(UpfirdnArgs p)
+{
+    constexpr int kRows = 8;                       // input rows per batch -> 4 output rows
+    const int gw = 1 << p.laneWLog;                // lanes per plane row (>= iw)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> p.laneWLog, x = lane & (gw - 1);
+    const int planesPerWave = 64 >> p.laneWLog;
+    const int64_t plane = ((int64_t)blockIdx.x * (kWaveThreads / 64) + wave) * planesPerWave + grp;
+    const bool planeOk = plane < p.totalPlanes;
+    const int64_t pc = planeOk ? plane : 0;
+    const int nb = (int)(pc / p.c), ch = (int)(pc - (int64_t)nb * p.c);
+    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1];
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1];
+    const int xs2 = (int)p.xs[2], ys2 = (int)p.ys[2];
+
+    // flipped, zero-padded taps (uniform)
+    float fx[4], fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    // Source lanes of the 4 row taps of output column ox = x.
+    const int laneBase = lane - x;
+    int src[4]; bool srcOk[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int ix = 2 * x - p.padx0 + k;
+        srcOk[k] = ix >= 0 && ix < p.iw;
+        src[k] = laneBase + (srcOk[k] ? ix : 0);
+    }
+    const bool colLoad = planeOk && x < p.iw;
+    const bool colOut = planeOk && x < p.ow;
+
+    // Row-filtered value of input row iy for this lane's output column.
+    auto hrow = [&](float v) -> float {
+        float acc = 0.0f;
+        #pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const float t = __shfl(v, src[k]);
+            acc = fmaf(srcOk[k] ? t : 0.0f, fx[k], acc);
+        }
+        return acc;
+    };
+
+    // prologue: the two rows above the first batch
+    const int base0 = -p.pady0;
+    float c0, c1;
+    {
+        const int iy0 = base0, iy1 = base0 + 1;
+        const float v0 = wave_load(xp + (int64_t)iy0 * xs2, x, colLoad && iy0 >= 0 && iy0 < p.ih);
+        const float v1 = wave_load(xp + (int64_t)iy1 * xs2, x, colLoad && iy1 >= 0 && iy1 < p.ih);
+        c0 = hrow(v0); c1 = hrow(v1);
+    }
+    for (int oy0 = 0; oy0 < p.oh; oy0 += kRows / 2)
+    {
+        const int rbase = 2 * oy0 - p.pady0 + 2;      // first new input row of this batch
+        float v[kRows];
+        #pragma unroll
+        for (int r = 0; r < kRows; r++)
+        {
+            const int iy = rbase + r;
+            v[r] = wave_load(xp + (int64_t)iy * xs2, x, colLoad && iy >= 0 && iy < p.ih);
+        }
+        float h[kRows + 2];
+        h[0] = c0; h[1] = c1;
+        #pragma unroll
+        for (int r = 0; r < kRows; r++) h[r + 2] = hrow(v[r]);
+        #pragma unroll
+        for (int j = 0; j < kRows / 2; j++)
+        {
+            const int oy = oy0 + j;
+            float acc = 0.0f;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) acc = fmaf(h[2 * j + k], fy[k], acc);
+            if (colOut && oy < p.oh) yp[(int64_t)oy * ys2 + x] = from_acc<T>(acc * p.gain);
+        }
+        c0 = h[kRows]; c1 = h[kRows + 1];
+    }
+}
+
+// Up: zero insertion x2. Row taps: out_h[ox] = in[i0] * ffx[t0] + in[i0 + 1] * ffx[t0 + 2],
+// m = ox + 1 - padx0, i0 = floor(m / 2), t0 = 1 - (m mod 2); columns alike.
+template <class T>
+__global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_up2_kernel(UpfirdnArgs p)
+{
+    constexpr int kRows = 4;                       // input rows per batch -> 8 output rows
+    const int gw = 1 << p.laneWLog;                // lanes per plane row (>= ow >= iw)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> p.laneWLog, x = lane & (gw - 1);
+    const int planesPerWave = 64 >> p.laneWLog;
+    const int64_t plane = ((int64_t)blockIdx.x * (kWaveThreads / 64) + wave) * planesPerWave + grp;
+    const bool planeOk = plane < p.totalPlanes;
+    const int64_t pc = planeOk ? plane : 0;
+    const int nb = (int)(pc / p.c), ch = (int)(pc - (int64_t)nb * p.c);
+    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1];
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1];
+    const int xs2 = (int)p.xs[2], ys2 = (int)p.ys[2];
+
+    float fx[4], fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    const int laneBase = lane - x;
+    const int mX = x + 1 - p.padx0;
+    const int i0 = lvg_floor_div(mX, 2);
+    const int phX = mX - 2 * i0;                    // 0 -> taps 1,3 ; 1 -> taps 0,2
+    const float tA = phX ? fx[0] : fx[1], tB = phX ? fx[2] : fx[3];
+    const bool okA = i0 >= 0 && i0 < p.iw, okB = (i0 + 1) >= 0 && (i0 + 1) < p.iw;
+    const int srcA = laneBase + (okA ? i0 : 0), srcB = laneBase + (okB ? i0 + 1 : 0);
+    const bool colLoad = planeOk && x < p.iw;
+    const bool colOut = planeOk && x < p.ow;
+    const float g = p.gain;
+
+    auto hrow = [&](float v) -> float {
+        const float a = __shfl(v, srcA), b = __shfl(v, srcB);
+        return fmaf(okA ? a : 0.0f, tA, (okB ? b : 0.0f) * tB);
+    };
+
+    // Output rows produced by the input-row pair (j, j + 1): oyA = 2 j - 1 + pady0 (taps 1, 3) and oyA + 1 (taps 0, 2).
+    const int jMin = lvg_floor_div(1 - p.pady0, 2);            // j of output row 0
+    const int jMax = lvg_floor_div(p.oh - p.pady0, 2);         // j of output row oh - 1
+    float hPrev;
+    {
+        const int iy = jMin;
+        hPrev = hrow(wave_load(xp + (int64_t)iy * xs2, x, colLoad && iy >= 0 && iy < p.ih));
+    }
+    for (int j0 = jMin; j0 <= jMax; j0 += kRows)
+    {
+        float v[kRows];
+        #pragma unroll
+        for (int r = 0; r < kRows; r++)
+        {
+            const int iy = j0 + 1 + r;
+            v[r] = wave_load(xp + (int64_t)iy * xs2, x, colLoad && iy >= 0 && iy < p.ih);
+        }
+        #pragma unroll
+        for (int r = 0; r < kRows; r++)
+        {
+            const float hCur = hrow(v[r]);
+            const int j = j0 + r;
+            const int oyA = 2 * j - 1 + p.pady0;
+            const float oa = fmaf(hPrev, fy[1], hCur * fy[3]) * g;
+            const float ob = fmaf(hPrev, fy[0], hCur * fy[2]) * g;
+            if (colOut && j <= jMax)
+            {
+                if (oyA >= 0 && oyA < p.oh) yp[(int64_t)oyA * ys2 + x] = from_acc<T>(oa);
+                if (oyA + 1 >= 0 && oyA + 1 < p.oh) yp[(int64_t)(oyA + 1) * ys2 + x] = from_acc<T>(ob);
+            }
+            hPrev = hCur;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column-only streaming kernel: <= 4 taps, x2 up or down along H, nothing along W (fw == 1) -- the
+// time-axis resamplers on [N, C, T, (H W)] views. A lane owns VB bytes (one vector) of a row and
+// walks down a chunk of rows with the same sliding window as the wave kernels; lanes of a wave
+// cover consecutive vectors, so every load/store is a full coalesced line.
+
+template <class T, int VB> struct VecIO
+{
+    static constexpr int V = VB / (int)sizeof(T);
+    struct alignas(VB) Raw { T v[V]; };
+    static __device__ __forceinline__ void load(const T* p, bool ok, float (&o)[V])
+    {
+        if (ok) { const Raw r = *reinterpret_cast<const Raw*>(p);
+                  #pragma unroll
+                  for (int i = 0; i < V; i++) o[i] = (float)to_acc(r.v[i]); }
+        else    {
+                  #pragma unroll
+                  for (int i = 0; i < V; i++) o[i] = 0.0f; }
+    }
+    static __device__ __forceinline__ void store(T* p, const float (&o)[V], float g)
+    {
+        Raw r;
+        #pragma unroll
+        for (int i = 0; i < V; i++) r.v[i] = from_acc<T>(o[i] * g);
+        *reinterpret_cast<Raw*>(p) = r;
+    }
+};
+
+constexpr int kColChunk = 32;   // output rows per thread (down: 32, up: 32)
+
+template <class T, int VB, bool UP2>
+__global__ __launch_bounds__(256) void upfirdn2d_col_kernel(UpfirdnArgs p)
+{
+    typedef VecIO<T, VB> IO;
+    constexpr int V = IO::V;
+    const int vecsPerRow = p.iw / V;                        // ow == iw
+    const int chunks = (p.oh + kColChunk - 1) / kColChunk;
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int xv = (int)(t % vecsPerRow); t /= vecsPerRow;
+    const int chunk = (int)(t % chunks); t /= chunks;
+    if (t >= p.totalPlanes) return;
+    const int nb = (int)(t / p.c), ch = (int)(t - (int64_t)nb * p.c);
+    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1] + xv * V;
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1] + xv * V;
+    const int xs2 = (int)p.xs[2], ys2 = (int)p.ys[2];
+    float fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    const float g = p.gain * (p.fx ? p.fx[0] : 1.0f);
+    const int oyBeg = chunk * kColChunk;
+    const int oyEnd = (oyBeg + kColChunk < p.oh) ? oyBeg + kColChunk : p.oh;
+
+    if (!UP2)
+    {
+        // out[oy] = sum_k in[2 oy - pady0 + k] * fy[k]
+        constexpr int kRows = 8;
+        float c0[V], c1[V];
+        {
+            const int iy0 = 2 * oyBeg - p.pady0, iy1 = iy0 + 1;
+            IO::load(xp + (int64_t)iy0 * xs2, iy0 >= 0 && iy0 < p.ih, c0);
+            IO::load(xp + (int64_t)iy1 * xs2, iy1 >= 0 && iy1 < p.ih, c1);
+        }
+        for (int oy0 = oyBeg; oy0 < oyEnd; oy0 += kRows / 2)
+        {
+            const int rbase = 2 * oy0 - p.pady0 + 2;
+            float h[kRows + 2][V];
+            #pragma unroll
+            for (int i = 0; i < V; i++) { h[0][i] = c0[i]; h[1][i] = c1[i]; }
+            #pragma unroll
+            for (int r = 0; r < kRows; r++)
+            {
+                const int iy = rbase + r;
+                IO::load(xp + (int64_t)iy * xs2, iy >= 0 && iy < p.ih && (oy0 + r / 2) < oyEnd + 1, h[r + 2]);
+            }
+            #pragma unroll
+            for (int j = 0; j < kRows / 2; j++)
+            {
+                const int oy = oy0 + j;
+                if (oy < oyEnd)
+                {
+                    float acc[V];
+                    #pragma unroll
+                    for (int i = 0; i < V; i++)
+                    {
+                        float a = 0.0f;
+                        #pragma unroll
+                        for (int k = 0; k < 4; k++) a = fmaf(h[2 * j + k][i], fy[k], a);
+                        acc[i] = a;
+                    }
+                    IO::store(yp + (int64_t)oy * ys2, acc, g);
+                }
+            }
+            #pragma unroll
+            for (int i = 0; i < V; i++) { c0[i] = h[kRows][i]; c1[i] = h[kRows + 1][i]; }
+        }
+    }
+    else
+    {
+        // pair (j, j+1) -> rows oyA = 2 j - 1 + pady0 (taps 1, 3) and oyA + 1 (taps 0, 2)
+        constexpr int kRows = 4;
+        const int jMin = lvg_floor_div(oyBeg + 1 - p.pady0, 2);
+        const int jMax = lvg_floor_div(oyEnd - p.pady0, 2);
+        float hPrev[V];
+        IO::load(xp + (int64_t)jMin * xs2, jMin >= 0 && jMin < p.ih, hPrev);
+        for (int j0 = jMin; j0 <= jMax; j0 += kRows)
+        {
+            float v[kRows][V];
+            #pragma unroll
+            for (int r = 0; r < kRows; r++)
+            {
+                const int iy = j0 + 1 + r;
+                IO::load(xp + (int64_t)iy * xs2, iy >= 0 && iy < p.ih && (j0 + r) <= jMax, v[r]);
+            }
+            #pragma unroll
+            for (int r = 0; r < kRows; r++)
+            {
+                const int j = j0 + r;
+                const int oyA = 2 * j - 1 + p.pady0;
+                if (j <= jMax)
+                {
+                    float oa[V], ob[V];
+                    #pragma unroll
+                    for (int i = 0; i < V; i++)
+                    {
+                        oa[i] = fmaf(hPrev[i], fy[1], v[r][i] * fy[3]);
+                        ob[i] = fmaf(hPrev[i], fy[0], v[r][i] * fy[2]);
+                    }
+                    if (oyA >= oyBeg && oyA < oyEnd) IO::store(yp + (int64_t)oyA * ys2, oa, g);
+                    if (oyA + 1 >= oyBeg && oyA + 1 < oyEnd) IO::store(yp + (int64_t)(oyA + 1) * ys2, ob, g);
+                }
+                #pragma unroll
+                for (int i = 0; i < V; i++) hPrev[i] = v[r][i];
+            }
+        }
+    }
+}
+
+template <class T, int VB>
+int launch_col_vb(UpfirdnArgs& p, bool up2, hipStream_t stream)
+{
+    constexpr int V = VB / (int)sizeof(T);
+    const int64_t chunks = (p.oh + kColChunk - 1) / kColChunk;
+    const int64_t threads = p.totalPlanes * chunks * (p.iw / V);
+    const int64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    if (up2) hipLaunchKernelGGL((upfirdn2d_col_kernel<T, VB, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    else     hipLaunchKernelGGL((upfirdn2d_col_kernel<T, VB, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return lvg_check_launch("upfirdn2d_col_kernel");
+}
+
+template <class T>
+int launch_col(UpfirdnArgs& p, hipStream_t stream)
+{
+    if (p.f2d || p.fw != 1 || p.fh > 4 || p.upx != 1 || p.downx != 1 || p.iw != p.ow) return LVG_ERR_UNSUPPORTED;
+    const bool up2 = p.upy == 2 && p.downy == 1, down2 = p.upy == 1 && p.downy == 2;
+    if (!up2 && !down2) return LVG_ERR_UNSUPPORTED;
+    if (p.xs[3] != 1 || p.ys[3] != 1) return LVG_ERR_UNSUPPORTED;
+    if ((int64_t)(p.ih + 16) * (p.xs[2] < 0 ? -p.xs[2] : p.xs[2]) >= 0x7fffffffLL || (int64_t)(p.oh + 16) * p.ys[2] >= 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    p.totalPlanes = (int64_t)p.n * p.c;
+    // widest vector such that every row of every plane starts on a vector boundary
+    auto fits = [&](int vb) {
+        const int v = vb / (int)sizeof(T);
+        if (v < 1 || p.iw % v) return false;
+        if (((uintptr_t)p.x % vb) || ((uintptr_t)p.y % vb)) return false;
+        for (int i = 0; i < 3; i++) if ((p.xs[i] % v) || (p.ys[i] % v)) return false;
+        return true;
+    };
+    if (fits(16)) return launch_col_vb<T, 16>(p, up2, stream);
+    if (fits(8))  return launch_col_vb<T, 8>(p, up2, stream);
+    if (fits(4))  return launch_col_vb<T, 4>(p, up2, stream);
+    return LVG_ERR_UNSUPPORTED;
+}
+
+// Returns LVG_ERR_UNSUPPORTED when the shape is not one the wave kernels take.
+template <class T>
+int launch_wave(UpfirdnArgs& p, hipStream_t stream)
+{
+    if (p.f2d || p.fw > 4 || p.fh > 4) return LVG_ERR_UNSUPPORTED;
+    if (p.xs[3] != 1 || p.ys[3] != 1) return LVG_ERR_UNSUPPORTED;
+    const bool up2 = p.upx == 2 && p.upy == 2 && p.downx == 1 && p.downy == 1;
+    const bool down2 = p.upx == 1 && p.upy == 1 && p.downx == 2 && p.downy == 2;
+    if (!up2 && !down2) return LVG_ERR_UNSUPPORTED;
+    const int wmax = (p.iw > p.ow) ? p.iw : p.ow;
+    if (wmax > 64) return LVG_ERR_UNSUPPORTED;
+    // rows must be addressable with 32-bit offsets inside a plane
+    if ((int64_t)(p.ih + 16) * (p.xs[2] < 0 ? -p.xs[2] : p.xs[2]) >= 0x7fffffffLL || (int64_t)(p.oh + 16) * p.ys[2] >= 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    p.laneWLog = 0; while ((1 << p.laneWLog) < wmax) p.laneWLog++;
+    p.totalPlanes = (int64_t)p.n * p.c;
+    const int planesPerBlock = (kWaveThreads / 64) * (64 >> p.laneWLog);
+    const int64_t blocks = (p.totalPlanes + planesPerBlock - 1) / planesPerBlock;
+    if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    if (up2) hipLaunchKernelGGL((upfirdn2d_wave_up2_kernel<T>), dim3((unsigned)blocks), dim3(kWaveThreads), 0, stream, p);
+    else     hipLaunchKernelGGL((upfirdn2d_wave_down2_kernel<T>), dim3((unsigned)blocks), dim3(kWaveThreads), 0, stream, p);
+    return lvg_check_launch("upfirdn2d_wave_kernel");
 }
 
 template <class T>
@@ -288,7 +920,11 @@ int launch_gather(UpfirdnArgs& p, hipStream_t stream)
 }
 
 #define LVG_UPFIRDN_CASE(ux, uy, dx, dy) \
-    if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy) return launch_tiled<T, ux, uy, dx, dy>(p, sep, stream);
+    if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy) { \
+        if (p.fw <= 4 && p.fh <= 4 && 4 % ux == 0 && 4 % uy == 0) { \
+            int rcf = launch_fast<T, ux, uy, dx, dy, 4>(p, sep, stream); \
+            if (rcf != LVG_ERR_UNSUPPORTED) return rcf; } \
+        return launch_tiled<T, ux, uy, dx, dy>(p, sep, stream); }
 
 template <class T>
 int dispatch_tiled(UpfirdnArgs& p, bool sep, hipStream_t stream)
@@ -313,8 +949,12 @@ int run(UpfirdnArgs& p, hipStream_t stream)
     // The tiled kernel wants W to be the fast axis of the input; otherwise gather.
     // (float64 always gathers: the tiles are staged in LDS as float32.)
     const bool wFast = (p.xs[3] == 1) || p.iw == 1;
-    if (wFast && sizeof(T) <= 4)
+    if constexpr (sizeof(T) <= 4) if (wFast)
     {
+        int rcw = launch_wave<T>(p, stream);
+        if (rcw != LVG_ERR_UNSUPPORTED) return rcw;
+        rcw = launch_col<T>(p, stream);
+        if (rcw != LVG_ERR_UNSUPPORTED) return rcw;
         int rc = dispatch_tiled<T>(p, sep, stream);
         if (rc != LVG_ERR_UNSUPPORTED) return rc;
     }
@@ -353,7 +993,8 @@ extern "C" int lvg_upfirdn2d(const void* x, void* y, const float* f2d, const flo
     p.fw = fw; p.fh = fh;
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy;
     p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
-    p.tileW = p.tileH = p.tilesX = p.tilesY = p.inTW = p.inTH = p.midTH = 0;
+    p.tileW = p.tileH = p.tilesX = p.tilesY = p.inTW = p.inTH = 0;
+    p.planesPerBlock = 1; p.uniformPlanes = 0; p.totalPlanes = (int64_t)p.n * p.c; p.laneWLog = p.laneWInLog = 6;
 
     hipStream_t s = (hipStream_t)stream;
     switch (dtype)

@@ -149,6 +149,16 @@ class FullyConnectedLayer(nn.Module):
         return bias_act.bias_act(x.matmul(w), b, act=self.activation)
 
 
+def _dense_conv3d(x: torch.Tensor, weight: torch.Tensor, padding) -> torch.Tensor:
+    """conv3d on the path that maps best to MI355X: a 1x1x1 kernel is a plain (batched) GEMM over
+    channels on the NCTHW tensor itself -- no im2col buffer; everything else goes to MIOpen."""
+    if weight.shape[2:] == (1, 1, 1):
+        n, c, t, h, w = x.shape
+        y = torch.matmul(weight.reshape(weight.shape[0], c), x.reshape(n, c, t * h * w))
+        return y.reshape(n, weight.shape[0], t, h, w)
+    return F.conv3d(x, weight, padding=padding)
+
+
 def modulated_conv3d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, input_gain: Optional[torch.Tensor],
                      padding, demodulate: bool, compute_dtype: torch.dtype) -> torch.Tensor:
     """Per-(sample, frame) style-modulated conv3d (reference generator_lres.py:83-125).
@@ -161,11 +171,34 @@ def modulated_conv3d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
     weight = weight * (1.0 / math.sqrt(weight[0].numel()))
     mod = style if input_gain is None else style * input_gain
     x = x * mod.to(x.dtype)[:, :, :, None, None]
-    y = F.conv3d(x.to(compute_dtype), weight.to(compute_dtype), padding=padding)
+    y = _dense_conv3d(x.to(compute_dtype), weight.to(compute_dtype), padding)
     if demodulate:
         w2 = weight.square().sum(dim=(2, 3, 4))                      # [Co, Ci]
         demod = torch.matmul(w2, style.square()).add(1e-8).rsqrt()   # [N, Co, T]
         y = y * demod.to(y.dtype)[:, :, :, None, None]
+    return y
+
+
+def modulated_conv2d_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, input_gain: Optional[torch.Tensor],
+                            padding, demodulate: bool, compute_dtype: torch.dtype) -> torch.Tensor:
+    """Same operator for a kernel without temporal extent, in FRAMES-AS-BATCH layout.
+
+    A [Co, Ci, 1, kh, kw] kernel never mixes frames, so the layer is a per-frame 2-D convolution:
+    x [(N T), Ci, H, W], style [N, T, Ci]. MIOpen's 2-D kernels are implicit-GEMM on MFMA, whereas
+    its NCDHW 3-D path materialises an im2col buffer (measured on MI355X: Im3d2Col + Col2Im3d were
+    39 % of the generator step). Arithmetic is identical to `modulated_conv3d`."""
+    n, t, ci = style.shape
+    if demodulate:
+        weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
+        style = style / style.abs().amax(dim=(1, 2), keepdim=True)
+    weight = weight * (1.0 / math.sqrt(weight[0].numel()))
+    mod = style if input_gain is None else style * input_gain
+    x = x * mod.reshape(n * t, ci, 1, 1).to(x.dtype)
+    y = F.conv2d(x.to(compute_dtype), weight[:, :, 0].to(compute_dtype), padding=padding)
+    if demodulate:
+        w2 = weight.square().sum(dim=(2, 3, 4))                                   # [Co, Ci]
+        demod = torch.matmul(style.square(), w2.t()).add(1e-8).rsqrt()            # [N, T, Co]
+        y = y * demod.reshape(n * t, -1, 1, 1).to(y.dtype)
     return y
 
 
@@ -206,8 +239,10 @@ class BlurredNoise(nn.Module):
     def blur(self, noise: torch.Tensor) -> torch.Tensor:
         n, c, t = noise.shape
         assert c == self.noise_channels
-        x = noise.reshape(n * c, 1, t).expand(n * c, self.blur_widths, t)
-        y = F.conv1d(x, self.blur_filters, groups=self.blur_widths)
+        # The filter bank as one GEMM over sliding windows of the noise: [n c, T_out, K] @ [K, widths].
+        # (The reference's grouped conv1d with 5000-tap kernels lands on MIOpen's naive direct kernel.)
+        win = noise.reshape(n * c, t).unfold(1, self.kernel_size, 1)
+        y = torch.matmul(win, self.blur_filters[:, 0, :].t()).transpose(1, 2)
         if self.normalize_per_filter > 0:
             y = y * (1 + self.normalize_per_filter * (self.output_scale - 1))
         return y.reshape(n, c * self.blur_widths, y.size(2))
@@ -289,7 +324,7 @@ class Synthesis3dResBlock(nn.Module):
         gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
         h = modulated_conv3d(h, self.weight_1, style_1, gain_1, self.padding, True, dtype)
 
-        skip = F.conv3d(x, (self.weight_skip * self.weight_skip_gain).to(dtype))
+        skip = _dense_conv3d(x, (self.weight_skip * self.weight_skip_gain).to(dtype), (0, 0, 0))
         h = (skip + h) * SQRT_HALF
 
         if self.temporal_up:
@@ -298,6 +333,38 @@ class Synthesis3dResBlock(nn.Module):
         if self.spatial_up:
             h = self.spatial_upsample(h)
         h = crop_center(h, width=self.out_width, height=self.out_height)
+        return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
+
+
+    def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
+                       dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """Same layer on x [(N T), C, H, W] (frames as batch); only for blocks without temporal extent."""
+        assert self.weight_0.shape[2] == 1 and not self.temporal_up
+        if dtype is None:
+            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+        n, c, t = latent.shape
+        lat = latent.permute(0, 2, 1).reshape(n * t, c)
+        x = x.to(dtype)
+        pad2 = self.padding[1:]
+        style_0 = self.affine_0(lat).reshape(n, t, -1)
+        gain_0 = self.input_magnitude_ema_0(x, magnitude_ema_beta) if self.magnitude_ema else None
+        if gain_0 is not None:
+            x = x * gain_0.to(dtype)
+        h = modulated_conv2d_frames(x, self.weight_0, style_0, None, pad2, True, dtype)
+        h = bias_act.bias_act(h, self.bias_0.to(dtype), act=self.activation, clamp=self.activation_clamp)
+        style_1 = self.affine_1(lat).reshape(n, t, -1)
+        gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
+        h = modulated_conv2d_frames(h, self.weight_1, style_1, gain_1, pad2, True, dtype)
+        skip = F.conv2d(x, (self.weight_skip[:, :, 0] * self.weight_skip_gain).to(dtype))
+        h = (skip + h) * SQRT_HALF
+        if self.spatial_up:
+            h = upfirdn2d.upsample2d(h, self.spatial_upsample.filter, up=self.spatial_upsample.scale)
+        if self.out_width is not None:
+            x0 = (h.size(3) - self.out_width) // 2
+            h = h[:, :, :, x0:x0 + self.out_width]
+        if self.out_height is not None:
+            y0 = (h.size(2) - self.out_height) // 2
+            h = h[:, :, y0:y0 + self.out_height]
         return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
 
 
@@ -321,6 +388,16 @@ class ToRGB(nn.Module):
         x = x.to(dtype)
         gain = self.input_magnitude_ema(x, magnitude_ema_beta) if self.magnitude_ema else None
         y = modulated_conv3d(x, self.weight, style, gain, (0, 0, 0), False, dtype)
+        return bias_act.bias_act(y, self.bias.to(dtype), act='linear', clamp=self.activation_clamp)
+
+    def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        if dtype is None:
+            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+        n, c, t = latent.shape
+        style = self.affine(latent.permute(0, 2, 1).reshape(n * t, c)).reshape(n, t, -1)
+        x = x.to(dtype)
+        gain = self.input_magnitude_ema(x, magnitude_ema_beta) if self.magnitude_ema else None
+        y = modulated_conv2d_frames(x, self.weight, style, gain, (0, 0), False, dtype)
         return bias_act.bias_act(y, self.bias.to(dtype), act='linear', clamp=self.activation_clamp)
 
 
@@ -416,11 +493,20 @@ class VideoGenerator(nn.Module):
             x = layer(x, latent_ws[wi], magnitude_ema_beta, length, dtype=dtype)
             feats.append(x)
             wi += 1
+        # Spatial stage: no layer mixes frames any more, so it runs per frame ([(N T), C, H, W]).
+        n, c, t, h, w = x.shape
+        x = x.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w)
+
+        def as_video(f):
+            return f.reshape(n, t, *f.shape[1:]).permute(0, 2, 1, 3, 4)
+
         for layer in self.spatial_layers:
-            x = layer(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
-            feats.append(x)
+            x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
+            if return_features:
+                feats.append(as_video(x))
             wi += 1
-        video = self.to_rgb(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype).float() * self.output_scale
+        rgb = self.to_rgb.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
+        video = as_video(rgb.float() * self.output_scale).contiguous()
         if return_features:
             return feats + [video]
         return video
@@ -482,9 +568,18 @@ class Conv3dLayer(nn.Module):
             self.downsample = Downsample3d(spatial_down, temporal_down)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = F.conv3d(x, (self.weight * self.weight_gain).to(x.dtype), padding=self.padding)
+        y = _dense_conv3d(x, (self.weight * self.weight_gain).to(x.dtype), self.padding)
         if self.has_down:
             y = self.downsample(y)
+        b = self._bias.to(x.dtype) if self._bias is not None else None
+        return bias_act.bias_act(y, b, act=self.activation, clamp=self.conv_clamp)
+
+    def forward_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """x [(N T), C, H, W]; only for kernels without temporal extent and no temporal downsampling."""
+        assert self.weight.shape[2] == 1 and not (self.has_down and self.downsample.temporal_down)
+        y = F.conv2d(x, (self.weight[:, :, 0] * self.weight_gain).to(x.dtype), padding=self.padding[1:])
+        if self.has_down:
+            y = upfirdn2d.downsample2d(y, self.downsample._downsample_filter, down=2)
         b = self._bias.to(x.dtype) if self._bias is not None else None
         return bias_act.bias_act(y, b, act=self.activation, clamp=self.conv_clamp)
 
@@ -536,6 +631,20 @@ class DiscriminatorBlock(nn.Module):
         h = self.conv_0(x)
         skip = self.conv_skip(x)
         h = self.conv_1(h)
+        return (h + skip) * SQRT_HALF
+
+    @property
+    def per_frame(self) -> bool:
+        """True when no layer of the block mixes or resamples frames."""
+        return self.conv_0.weight.shape[2] == 1 and self.conv_1.weight.shape[2] == 1 and not self.temporal_down
+
+    def forward_frames(self, x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        x = x.to(dtype if dtype is not None else (torch.float16 if self.use_fp16 else torch.float32))
+        if self.vid_channels > 0:
+            x = self.conv_vid.forward_frames(x)
+        h = self.conv_0.forward_frames(x)
+        skip = self.conv_skip.forward_frames(x)
+        h = self.conv_1.forward_frames(h)
         return (h + skip) * SQRT_HALF
 
 
@@ -606,6 +715,13 @@ class VideoDiscriminator(nn.Module):
         px = (self.max_edge - videos.size(4)) // 2
         py = (self.max_edge - videos.size(3)) // 2
         f = F.pad(videos, (px, px, py, py))
-        for block in self.blocks:
+        blocks = list(self.blocks)
+        if blocks[0].per_frame:
+            # The first block has no temporal extent: run it per frame on MIOpen's 2-D kernels.
+            n, c, t, h, w = f.shape
+            f = blocks[0].forward_frames(f.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w), dtype=dtype)
+            f = f.reshape(n, t, *f.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
+            blocks = blocks[1:]
+        for block in blocks:
             f = block(f, dtype=dtype)
         return self.epilogue(f)

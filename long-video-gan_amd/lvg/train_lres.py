@@ -34,8 +34,8 @@ class LowResTrainer:
         for net in (self.G, self.D):
             ddp.broadcast_module(net, src=0)
         self.G_ema = copy.deepcopy(self.G).eval() if with_ema else None
-        self.G_opt = torch.optim.Adam(self.G.parameters(), lr=G_lrate, betas=(0, G_beta2))
-        self.D_opt = torch.optim.Adam(self.D.parameters(), lr=D_lrate, betas=(0, D_beta2))
+        self.G_opt = torch.optim.Adam(self.G.parameters(), lr=G_lrate, betas=(0.0, G_beta2))
+        self.D_opt = torch.optim.Adam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
         self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
 

@@ -11,15 +11,22 @@ warnings.simplefilter('ignore')
 
 
 def timeit(fn, iters=20, warm=3):
+    """GPU time per call: `iters` launches queued back to back between two events (a single
+    launch between events would include the host's launch latency when the GPU is idle)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in evs:
-        a.record(); fn(); b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
-    return ts[len(ts) // 2] * 1e-3
+    best = None
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) * 1e-3 / iters
+        best = t if best is None else min(best, t)
+    return best
 
 
 def report(name, secs, nbytes):
@@ -57,10 +64,18 @@ def main():
         kw = dict(up=(1, 2), padding=[0, 0, 2, 1], gain=2)
         y = upfirdn2d.upfirdn2d(x, ft, **kw)
         report(f'temporal_up2[4,256,80,144]{dtype}', timeit(lambda: upfirdn2d.upfirdn2d(x, ft, **kw)), (x.numel() + y.numel()) * s)
+        x = torch.randn(4, 4096, 32, 32, device=dev).to(dtype)
+        y = upfirdn2d.upsample2d(x, f)
+        report(f'upsample2d_Dbwd[4,4096,32,32]{dtype}', timeit(lambda: upfirdn2d.upsample2d(x, f)), (x.numel() + y.numel()) * s)
+        x = torch.randn(4, 16384, 3, 4, device=dev).to(dtype)
+        y = upfirdn2d.upsample2d(x, f)
+        report(f'upsample2d_tiny[4,16384,3,4]{dtype}', timeit(lambda: upfirdn2d.upsample2d(x, f)), (x.numel() + y.numel()) * s)
         x = torch.randn(4, 128, 128, 256, device=dev).to(dtype)
         kw = dict(down=(1, 2), padding=[0, 0, 1, 1])
         y = upfirdn2d.upfirdn2d(x, ft, **kw)
         report(f'temporal_down2[4,128,128,256]{dtype}', timeit(lambda: upfirdn2d.upfirdn2d(x, ft, **kw)), (x.numel() + y.numel()) * s)
+    if '--quick' in sys.argv:
+        return
     import scipy.signal
     k12 = torch.tensor(scipy.signal.firwin(numtaps=12, cutoff=0.45, width=0.3, fs=2.0).astype(np.float32), device=dev)
     k24 = torch.tensor(scipy.signal.firwin(numtaps=24, cutoff=0.22, width=0.15, fs=2.0).astype(np.float32), device=dev)
