@@ -179,26 +179,72 @@ def modulated_conv3d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
     return y
 
 
-def modulated_conv2d_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, input_gain: Optional[torch.Tensor],
-                            padding, demodulate: bool, compute_dtype: torch.dtype) -> torch.Tensor:
-    """Same operator for a kernel without temporal extent, in FRAMES-AS-BATCH layout.
+# --------------------------------------------------------------------------------------------------
+# TIME-MAJOR FRAMES layout: a video batch is stored as [(T N), C, H, W] (frame index f = t * N + n).
+#
+# Why (measured on MI355X, tools/conv_probe.py / conv2d_probe.py, bf16): MIOpen's NCDHW conv3d is an explicit
+# Im3d2Col + GEMM (+ Col2Im3dU backward) at 35-230 TFLOP/s, its 2-D convs are implicit-GEMM MFMA kernels at
+# 230-510 TFLOP/s. A kernel [Co, Ci, kt, kh, kw] is the sum over its kt temporal taps of 2-D convolutions of
+# time-shifted frames, and with time OUTERMOST a time shift is a contiguous slice of the frame axis: no
+# padding copy, no im2col buffer. Per-frame layers (styles, bias_act, spatial resampling) do not care about
+# the frame order; resampling along time sees the tensor as [T, (N C H W)] rows.
 
-    A [Co, Ci, 1, kh, kw] kernel never mixes frames, so the layer is a per-frame 2-D convolution:
-    x [(N T), Ci, H, W], style [N, T, Ci]. MIOpen's 2-D kernels are implicit-GEMM on MFMA, whereas
-    its NCDHW 3-D path materialises an im2col buffer (measured on MI355X: Im3d2Col + Col2Im3d were
-    39 % of the generator step). Arithmetic is identical to `modulated_conv3d`."""
-    n, t, ci = style.shape
+def frames_from_video(video: torch.Tensor) -> torch.Tensor:
+    """[N, C, T, H, W] -> [(T N), C, H, W]"""
+    n, c, t, h, w = video.shape
+    return video.permute(2, 0, 1, 3, 4).reshape(t * n, c, h, w)
+
+
+def video_from_frames(frames: torch.Tensor, n: int) -> torch.Tensor:
+    """[(T N), C, H, W] -> [N, C, T, H, W] (a permuted view)"""
+    tn, c, h, w = frames.shape
+    return frames.reshape(tn // n, n, c, h, w).permute(1, 2, 0, 3, 4)
+
+
+def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw) -> torch.Tensor:
+    """conv3d with 'same' zero padding in time, as kt 2-D convolutions. x [(T N), Ci, H, W] and
+    weight [Co, Ci, kt, kh, kw] in the compute dtype."""
+    kt = weight.shape[2]
+    pt = kt // 2
+    total = x.shape[0]
+    y = F.conv2d(x, weight[:, :, pt], padding=padding_hw)
+    for k in range(kt):
+        shift = (k - pt) * n                       # output frame t reads input frame t + (k - pt)
+        if shift == 0 or abs(shift) >= total:
+            continue
+        if shift < 0:
+            y[-shift:] += F.conv2d(x[:shift], weight[:, :, k], padding=padding_hw)
+        else:
+            y[:-shift] += F.conv2d(x[shift:], weight[:, :, k], padding=padding_hw)
+    return y
+
+
+def resample_time_frames(x: torch.Tensor, taps: torch.Tensor, n: int, up: int = 1, down: int = 1) -> torch.Tensor:
+    """x2 up/down-sampling along time of [(T N), C, H, W]: the frame axis is H of a [1, 1, T, (N C H W)] view."""
+    tn, c, h, w = x.shape
+    rows = x.reshape(1, 1, tn // n, n * c * h * w)
+    if up > 1:
+        y = upfirdn2d.upsample2d(rows, taps.unsqueeze(1), up=(1, up))
+    else:
+        y = upfirdn2d.downsample2d(rows, taps.unsqueeze(1), down=(1, down))
+    return y.reshape(y.size(2) * n, c, h, w)
+
+
+def modulated_conv_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, input_gain: Optional[torch.Tensor],
+                          padding, demodulate: bool, compute_dtype: torch.dtype) -> torch.Tensor:
+    """`modulated_conv3d` in time-major frames layout. x [(T N), Ci, H, W]; style [T, N, Ci] float32."""
+    t, n, ci = style.shape
     if demodulate:
         weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
-        style = style / style.abs().amax(dim=(1, 2), keepdim=True)
+        style = style / style.abs().amax(dim=(0, 2), keepdim=True)       # per sample, over channels and time
     weight = weight * (1.0 / math.sqrt(weight[0].numel()))
     mod = style if input_gain is None else style * input_gain
-    x = x * mod.reshape(n * t, ci, 1, 1).to(x.dtype)
-    y = F.conv2d(x.to(compute_dtype), weight[:, :, 0].to(compute_dtype), padding=padding)
+    x = x * mod.reshape(t * n, ci, 1, 1).to(x.dtype)
+    y = temporal_conv_frames(x.to(compute_dtype), weight.to(compute_dtype), n, padding[1:])
     if demodulate:
-        w2 = weight.square().sum(dim=(2, 3, 4))                                   # [Co, Ci]
-        demod = torch.matmul(style.square(), w2.t()).add(1e-8).rsqrt()            # [N, T, Co]
-        y = y * demod.reshape(n * t, -1, 1, 1).to(y.dtype)
+        w2 = weight.square().sum(dim=(2, 3, 4))                               # [Co, Ci]
+        demod = torch.matmul(style.square(), w2.t()).add(1e-8).rsqrt()        # [T, N, Co]
+        y = y * demod.reshape(t * n, -1, 1, 1).to(y.dtype)
     return y
 
 
@@ -337,26 +383,30 @@ class Synthesis3dResBlock(nn.Module):
 
 
     def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
-                       dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """Same layer on x [(N T), C, H, W] (frames as batch); only for blocks without temporal extent."""
-        assert self.weight_0.shape[2] == 1 and not self.temporal_up
+                       out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """Same layer in time-major frames layout: x [(T N), C, H, W], latent [N, L, T]."""
         if dtype is None:
             dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
         n, c, t = latent.shape
-        lat = latent.permute(0, 2, 1).reshape(n * t, c)
+        lat = latent.permute(2, 0, 1).reshape(t * n, c)                         # rows ordered (t n), like the frames
         x = x.to(dtype)
-        pad2 = self.padding[1:]
-        style_0 = self.affine_0(lat).reshape(n, t, -1)
+        style_0 = self.affine_0(lat).reshape(t, n, -1)
         gain_0 = self.input_magnitude_ema_0(x, magnitude_ema_beta) if self.magnitude_ema else None
         if gain_0 is not None:
             x = x * gain_0.to(dtype)
-        h = modulated_conv2d_frames(x, self.weight_0, style_0, None, pad2, True, dtype)
+        h = modulated_conv_frames(x, self.weight_0, style_0, None, self.padding, True, dtype)
         h = bias_act.bias_act(h, self.bias_0.to(dtype), act=self.activation, clamp=self.activation_clamp)
-        style_1 = self.affine_1(lat).reshape(n, t, -1)
+        style_1 = self.affine_1(lat).reshape(t, n, -1)
         gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
-        h = modulated_conv2d_frames(h, self.weight_1, style_1, gain_1, pad2, True, dtype)
+        h = modulated_conv_frames(h, self.weight_1, style_1, gain_1, self.padding, True, dtype)
         skip = F.conv2d(x, (self.weight_skip[:, :, 0] * self.weight_skip_gain).to(dtype))
         h = (skip + h) * SQRT_HALF
+        if self.temporal_up:
+            h = resample_time_frames(h, self.temporal_upsample.filter, n, up=self.temporal_upsample.scale)
+        if out_seq_length is not None:
+            t_now = h.shape[0] // n
+            t0 = (t_now - out_seq_length) // 2
+            h = h[t0 * n:(t0 + out_seq_length) * n]
         if self.spatial_up:
             h = upfirdn2d.upsample2d(h, self.spatial_upsample.filter, up=self.spatial_upsample.scale)
         if self.out_width is not None:
@@ -394,10 +444,10 @@ class ToRGB(nn.Module):
         if dtype is None:
             dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
         n, c, t = latent.shape
-        style = self.affine(latent.permute(0, 2, 1).reshape(n * t, c)).reshape(n, t, -1)
+        style = self.affine(latent.permute(2, 0, 1).reshape(t * n, c)).reshape(t, n, -1)
         x = x.to(dtype)
         gain = self.input_magnitude_ema(x, magnitude_ema_beta) if self.magnitude_ema else None
-        y = modulated_conv2d_frames(x, self.weight, style, gain, (0, 0), False, dtype)
+        y = modulated_conv_frames(x, self.weight, style, gain, (0, 0, 0), False, dtype)
         return bias_act.bias_act(y, self.bias.to(dtype), act='linear', clamp=self.activation_clamp)
 
 
@@ -486,27 +536,24 @@ class VideoGenerator(nn.Module):
                          magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None, return_features: bool = False):
         in_len, lengths = self.compute_seq_lengths(seq_length)
         assert temporal_input.shape[1:] == (512, in_len)
-        x = (temporal_input[:, :, :, None, None] + self.spatial_input) * SQRT_HALF
+        n = temporal_input.shape[0]
+        # time-major frames: [(T N), C, H, W]
+        x = (temporal_input.permute(2, 0, 1)[:, :, :, None, None] + self.spatial_input[0, :, 0]) * SQRT_HALF
+        x = x.reshape(in_len * n, 512, x.shape[3], x.shape[4])
         feats = []
         wi = 0
         for layer, length in zip(self.temporal_layers, lengths):
-            x = layer(x, latent_ws[wi], magnitude_ema_beta, length, dtype=dtype)
-            feats.append(x)
+            x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, length, dtype=dtype)
+            if return_features:
+                feats.append(video_from_frames(x, n))
             wi += 1
-        # Spatial stage: no layer mixes frames any more, so it runs per frame ([(N T), C, H, W]).
-        n, c, t, h, w = x.shape
-        x = x.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w)
-
-        def as_video(f):
-            return f.reshape(n, t, *f.shape[1:]).permute(0, 2, 1, 3, 4)
-
         for layer in self.spatial_layers:
             x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
             if return_features:
-                feats.append(as_video(x))
+                feats.append(video_from_frames(x, n))
             wi += 1
         rgb = self.to_rgb.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
-        video = as_video(rgb.float() * self.output_scale).contiguous()
+        video = video_from_frames(rgb.float() * self.output_scale, n).contiguous()
         if return_features:
             return feats + [video]
         return video
@@ -574,12 +621,14 @@ class Conv3dLayer(nn.Module):
         b = self._bias.to(x.dtype) if self._bias is not None else None
         return bias_act.bias_act(y, b, act=self.activation, clamp=self.conv_clamp)
 
-    def forward_frames(self, x: torch.Tensor) -> torch.Tensor:
-        """x [(N T), C, H, W]; only for kernels without temporal extent and no temporal downsampling."""
-        assert self.weight.shape[2] == 1 and not (self.has_down and self.downsample.temporal_down)
-        y = F.conv2d(x, (self.weight[:, :, 0] * self.weight_gain).to(x.dtype), padding=self.padding[1:])
+    def forward_frames(self, x: torch.Tensor, n: int) -> torch.Tensor:
+        """Time-major frames layout: x [(T N), C, H, W]."""
+        y = temporal_conv_frames(x, (self.weight * self.weight_gain).to(x.dtype), n, self.padding[1:])
         if self.has_down:
-            y = upfirdn2d.downsample2d(y, self.downsample._downsample_filter, down=2)
+            if self.downsample.spatial_down:
+                y = upfirdn2d.downsample2d(y, self.downsample._downsample_filter, down=2)
+            if self.downsample.temporal_down:
+                y = resample_time_frames(y, self.downsample._downsample_filter, n, down=2)
         b = self._bias.to(x.dtype) if self._bias is not None else None
         return bias_act.bias_act(y, b, act=self.activation, clamp=self.conv_clamp)
 
@@ -633,18 +682,13 @@ class DiscriminatorBlock(nn.Module):
         h = self.conv_1(h)
         return (h + skip) * SQRT_HALF
 
-    @property
-    def per_frame(self) -> bool:
-        """True when no layer of the block mixes or resamples frames."""
-        return self.conv_0.weight.shape[2] == 1 and self.conv_1.weight.shape[2] == 1 and not self.temporal_down
-
-    def forward_frames(self, x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    def forward_frames(self, x: torch.Tensor, n: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         x = x.to(dtype if dtype is not None else (torch.float16 if self.use_fp16 else torch.float32))
         if self.vid_channels > 0:
-            x = self.conv_vid.forward_frames(x)
-        h = self.conv_0.forward_frames(x)
-        skip = self.conv_skip.forward_frames(x)
-        h = self.conv_1.forward_frames(h)
+            x = self.conv_vid.forward_frames(x, n)
+        h = self.conv_0.forward_frames(x, n)
+        skip = self.conv_skip.forward_frames(x, n)
+        h = self.conv_1.forward_frames(h, n)
         return (h + skip) * SQRT_HALF
 
 
@@ -714,14 +758,9 @@ class VideoDiscriminator(nn.Module):
         assert videos.size(3) == self.max_edge or videos.size(4) == self.max_edge
         px = (self.max_edge - videos.size(4)) // 2
         py = (self.max_edge - videos.size(3)) // 2
-        f = F.pad(videos, (px, px, py, py))
-        blocks = list(self.blocks)
-        if blocks[0].per_frame:
-            # The first block has no temporal extent: run it per frame on MIOpen's 2-D kernels.
-            n, c, t, h, w = f.shape
-            f = blocks[0].forward_frames(f.permute(0, 2, 1, 3, 4).reshape(n * t, c, h, w), dtype=dtype)
-            f = f.reshape(n, t, *f.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
-            blocks = blocks[1:]
-        for block in blocks:
-            f = block(f, dtype=dtype)
+        n = videos.shape[0]
+        f = frames_from_video(F.pad(videos, (px, px, py, py)))
+        for block in self.blocks:
+            f = block.forward_frames(f, n, dtype=dtype)
+        f = video_from_frames(f, n)
         return self.epilogue(f)
