@@ -36,45 +36,67 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s me
 
 
 class OpTimer:
-    """Brackets every lvg_* launch with events on the current (= launch) stream."""
+    """Measures the custom HIP ops of one step with HIP events on the launch stream.
+
+    Bracketing single launches inside an eager step over-counts short kernels whenever the stream is
+    empty (the start event fires, then the GPU waits for the host to submit the kernel), so the
+    launches of one step are RECORDED (arguments kept alive) and then each one is re-issued `reps`
+    times back to back between one event pair: elapsed / reps is the kernel's own duration."""
 
     def __init__(self):
-        self.records = {}     # op -> list of (start_event, end_event, algorithmic_bytes)
+        self.calls = []       # (op name, fn, args, kwargs, algorithmic bytes)
         self.enabled = False
-        self._orig = {}
 
     def install(self):
         from torch_utils.ops import bias_act, upfirdn2d
 
         def wrap(mod, name, op, bytes_fn):
             orig = getattr(mod, name)
-            self._orig[(mod, name)] = orig
 
-            def timed(*args, **kwargs):
-                if not self.enabled:
-                    return orig(*args, **kwargs)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
+            def recorded(*args, **kwargs):
                 out = orig(*args, **kwargs)
-                b.record()
-                self.records.setdefault(op(args), []).append((a, b, bytes_fn(args, out)))
+                if self.enabled:
+                    self.calls.append((op(args), orig, args, kwargs, bytes_fn(args, out)))
                 return out
-            setattr(mod, name, timed)
+            setattr(mod, name, recorded)
 
-        # bias_act._launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp)
+        # bias_act._launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp): x, y (+ xref / yref / dy)
         def ba_bytes(args, out):
-            streams = 2 + sum(1 for t in args[2:5] if t is not None and t.numel() > 0)   # x + y (+xref/yref/dy)
+            streams = 2 + sum(1 for t in args[2:5] if t is not None and t.numel() > 0)
             return out.numel() * out.element_size() * streams
         wrap(bias_act, '_launch', lambda a: 'bias_act_fwd' if a[5] == 0 else 'bias_act_bwd', ba_bytes)
-        # upfirdn2d._launch(x, f, upx, ...): (N_in + N_out) * s
+        # upfirdn2d._launch(x, f, ...): (N_in + N_out) * s
         wrap(upfirdn2d, '_launch', lambda a: 'upfirdn2d', lambda args, out: (args[0].numel() + out.numel()) * out.element_size())
 
-    def summary(self):
+    def measure(self, reps=5):
+        """Time every recorded launch: `reps` re-issues captured into a hipGraph and replayed between one
+        HIP event pair (a Python-issued launch costs ~20 us of host time, more than many of these kernels
+        take, so back-to-back eager launches would measure the host)."""
         out = {}
-        for op, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            nbytes = sum(r[2] for r in recs)
-            out[op] = dict(launches=len(recs), total_ms=ms, bytes=nbytes, gbps=(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        for op, fn, args, kwargs, nbytes in self.calls:
+            with torch.cuda.stream(side):
+                fn(*args, **kwargs)                              # warm-up outside capture
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    fn(*args, **kwargs)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g.replay()                                           # first replay: upload
+            a.record()
+            g.replay()
+            b.record()
+            b.synchronize()
+            d = out.setdefault(op, dict(launches=0, total_ms=0.0, bytes=0))
+            d['launches'] += 1
+            d['total_ms'] += a.elapsed_time(b) / reps
+            d['bytes'] += nbytes
+            del g
+        for d in out.values():
+            d['gbps'] = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9 if d['total_ms'] > 0 else 0.0
+        self.calls.clear()
         return out
 
 
@@ -166,8 +188,6 @@ def main():
             torch.cuda.synchronize()
     barrier()
 
-    if graph is None:
-        timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if graph is not None:
@@ -176,17 +196,14 @@ def main():
             step()
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # Roofline of the custom ops: record the launches of ONE more step of the same workload, then time
+    # each of them back to back with HIP events on the launch stream (see OpTimer).
+    roofline_steps = 1
+    timer.enabled = True
+    step()
     timer.enabled = False
-    roofline_steps = args.steps
-    if graph is not None:
-        # Per-launch events cannot be recorded inside a replayed graph: bracket the same launches on a
-        # few eager steps right after the timed region (same process, shapes and kernels).
-        roofline_steps = min(args.steps, 2)
-        timer.enabled = True
-        for _ in range(roofline_steps):
-            step()
-        torch.cuda.synchronize()
-        timer.enabled = False
+    ops = timer.measure()
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -195,14 +212,13 @@ def main():
 
     if rank == 0:
         frames = world * B * T * args.steps
-        ops = timer.summary()
         dominant = max(ops, key=lambda k: ops[k]['total_ms']) if ops else None
         roofline = None
         if dominant is not None:
             d = ops[dominant]
             roofline = dict(bound='hbm', kernel=dominant, achieved=round(d['gbps'], 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                             frac=round(d['gbps'] / HBM_PEAK_GBPS, 4), traffic=_pmc_traffic(dominant),
-                            measured_on=('timed region' if graph is None else f'{roofline_steps} eager steps after the timed hipGraph replays'),
+                            measured_on='every custom-op launch of one step, re-issued 5x inside a hipGraph replayed between HIP events on the launch stream, right after the timed region',
                             launches=d['launches'], avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
                             algorithmic_bytes_per_launch=int(d['bytes'] / d['launches']))
         result = {

@@ -886,6 +886,185 @@ int launch_col(UpfirdnArgs& p, hipStream_t stream)
     return LVG_ERR_UNSUPPORTED;
 }
 
+// 16-bit element types: one lane owns a PAIR of adjacent columns (one dword per row), so a wave row
+// covers 128 input columns' worth of planes with 4-byte loads/stores and every lane produces output.
+
+template <class T>
+__device__ __forceinline__ float half_of(uint32_t raw, int hi)
+{
+    T t; t.bits = (uint16_t)(hi ? (raw >> 16) : (raw & 0xffffu));
+    return (float)to_acc(t);
+}
+template <class T>
+__device__ __forceinline__ uint32_t pack2(float a, float b)
+{
+    return (uint32_t)from_acc<T>(a).bits | ((uint32_t)from_acc<T>(b).bits << 16);
+}
+
+template <class T>
+__global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_pair_kernel(UpfirdnArgs p)
+{
+    constexpr int kRows = 8;
+    const int gw = 1 << p.laneWLog;                // lanes per plane row: >= iw / 2 and >= ow
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> p.laneWLog, x = lane & (gw - 1);
+    const int planesPerWave = 64 >> p.laneWLog;
+    const int64_t plane = ((int64_t)blockIdx.x * (kWaveThreads / 64) + wave) * planesPerWave + grp;
+    const bool planeOk = plane < p.totalPlanes;
+    const int64_t pc = planeOk ? plane : 0;
+    const int nb = (int)(pc / p.c), ch = (int)(pc - (int64_t)nb * p.c);
+    const uint32_t* xp = (const uint32_t*)((const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1]);
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1];
+    const int xs2w = (int)(p.xs[2] >> 1), ys2 = (int)p.ys[2];     // input row stride in dwords
+    const int iwPairs = p.iw >> 1;
+
+    float fx[4], fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    const int laneBase = lane - x;
+    int src[4], hi[4]; bool srcOk[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int e = 2 * x - p.padx0 + k;                    // input column of tap k for output column x
+        srcOk[k] = e >= 0 && e < p.iw;
+        const int ec = srcOk[k] ? e : 0;
+        src[k] = laneBase + (ec >> 1);
+        hi[k] = ec & 1;
+    }
+    const bool colLoad = planeOk && x < iwPairs;
+    const bool colOut = planeOk && x < p.ow;
+
+    auto hrow = [&](uint32_t raw) -> float {
+        float acc = 0.0f;
+        #pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint32_t t = (uint32_t)__shfl((int)raw, src[k]);
+            acc = fmaf(srcOk[k] ? half_of<T>(t, hi[k]) : 0.0f, fx[k], acc);
+        }
+        return acc;
+    };
+    auto ld = [&](int iy) -> uint32_t { return (colLoad && iy >= 0 && iy < p.ih) ? xp[(int64_t)iy * xs2w + x] : 0u; };
+
+    float c0 = hrow(ld(-p.pady0)), c1 = hrow(ld(-p.pady0 + 1));
+    for (int oy0 = 0; oy0 < p.oh; oy0 += kRows / 2)
+    {
+        const int rbase = 2 * oy0 - p.pady0 + 2;
+        uint32_t v[kRows];
+        #pragma unroll
+        for (int r = 0; r < kRows; r++) v[r] = ld(rbase + r);
+        float h[kRows + 2];
+        h[0] = c0; h[1] = c1;
+        #pragma unroll
+        for (int r = 0; r < kRows; r++) h[r + 2] = hrow(v[r]);
+        #pragma unroll
+        for (int j = 0; j < kRows / 2; j++)
+        {
+            const int oy = oy0 + j;
+            float acc = 0.0f;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) acc = fmaf(h[2 * j + k], fy[k], acc);
+            if (colOut && oy < p.oh) yp[(int64_t)oy * ys2 + x] = from_acc<T>(acc * p.gain);
+        }
+        c0 = h[kRows]; c1 = h[kRows + 1];
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_up2_pair_kernel(UpfirdnArgs p)
+{
+    constexpr int kRows = 4;
+    const int gw = 1 << p.laneWLog;                // lanes per plane row: >= ow / 2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> p.laneWLog, x = lane & (gw - 1);
+    const int planesPerWave = 64 >> p.laneWLog;
+    const int64_t plane = ((int64_t)blockIdx.x * (kWaveThreads / 64) + wave) * planesPerWave + grp;
+    const bool planeOk = plane < p.totalPlanes;
+    const int64_t pc = planeOk ? plane : 0;
+    const int nb = (int)(pc / p.c), ch = (int)(pc - (int64_t)nb * p.c);
+    const uint32_t* xp = (const uint32_t*)((const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1]);
+    uint32_t* yp = (uint32_t*)((T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1]);
+    const int xs2w = (int)(p.xs[2] >> 1), ys2w = (int)(p.ys[2] >> 1);
+    const int iwPairs = p.iw >> 1, owPairs = p.ow >> 1;
+
+    float fx[4], fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    const int laneBase = lane - x;
+    // two output columns (2x, 2x+1), two taps each
+    int src[4], hi[4]; bool ok[4]; float tap[4];
+    #pragma unroll
+    for (int o = 0; o < 2; o++)
+    {
+        const int m = 2 * x + o + 1 - p.padx0;
+        const int i0 = lvg_floor_div(m, 2);
+        const int ph = m - 2 * i0;
+        #pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const int e = i0 + k;
+            const int q = o * 2 + k;
+            ok[q] = e >= 0 && e < p.iw;
+            const int ec = ok[q] ? e : 0;
+            src[q] = laneBase + (ec >> 1);
+            hi[q] = ec & 1;
+            tap[q] = ph ? fx[2 * k] : fx[2 * k + 1];
+        }
+    }
+    const bool colLoad = planeOk && x < iwPairs;
+    const bool colOut = planeOk && x < owPairs;
+    const float g = p.gain;
+
+    float h0, h1;
+    auto hrow = [&](uint32_t raw) {
+        float v[4];
+        #pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const uint32_t t = (uint32_t)__shfl((int)raw, src[q]);
+            v[q] = ok[q] ? half_of<T>(t, hi[q]) : 0.0f;
+        }
+        h0 = fmaf(v[0], tap[0], v[1] * tap[1]);
+        h1 = fmaf(v[2], tap[2], v[3] * tap[3]);
+    };
+    auto ld = [&](int iy) -> uint32_t { return (colLoad && iy >= 0 && iy < p.ih) ? xp[(int64_t)iy * xs2w + x] : 0u; };
+
+    const int jMin = lvg_floor_div(1 - p.pady0, 2);
+    const int jMax = lvg_floor_div(p.oh - p.pady0, 2);
+    hrow(ld(jMin));
+    float p0 = h0, p1 = h1;
+    for (int j0 = jMin; j0 <= jMax; j0 += kRows)
+    {
+        uint32_t v[kRows];
+        #pragma unroll
+        for (int r = 0; r < kRows; r++) v[r] = ld(j0 + 1 + r);
+        #pragma unroll
+        for (int r = 0; r < kRows; r++)
+        {
+            hrow(v[r]);
+            const int j = j0 + r;
+            const int oyA = 2 * j - 1 + p.pady0;
+            const uint32_t oa = pack2<T>(fmaf(p0, fy[1], h0 * fy[3]) * g, fmaf(p1, fy[1], h1 * fy[3]) * g);
+            const uint32_t ob = pack2<T>(fmaf(p0, fy[0], h0 * fy[2]) * g, fmaf(p1, fy[0], h1 * fy[2]) * g);
+            if (colOut && j <= jMax)
+            {
+                if (oyA >= 0 && oyA < p.oh) yp[(int64_t)oyA * ys2w + x] = oa;
+                if (oyA + 1 >= 0 && oyA + 1 < p.oh) yp[(int64_t)(oyA + 1) * ys2w + x] = ob;
+            }
+            p0 = h0; p1 = h1;
+        }
+    }
+}
+
 // Returns LVG_ERR_UNSUPPORTED when the shape is not one the wave kernels take.
 template <class T>
 int launch_wave(UpfirdnArgs& p, hipStream_t stream)
@@ -899,8 +1078,25 @@ int launch_wave(UpfirdnArgs& p, hipStream_t stream)
     if (wmax > 64) return LVG_ERR_UNSUPPORTED;
     // rows must be addressable with 32-bit offsets inside a plane
     if ((int64_t)(p.ih + 16) * (p.xs[2] < 0 ? -p.xs[2] : p.xs[2]) >= 0x7fffffffLL || (int64_t)(p.oh + 16) * p.ys[2] >= 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
-    p.laneWLog = 0; while ((1 << p.laneWLog) < wmax) p.laneWLog++;
     p.totalPlanes = (int64_t)p.n * p.c;
+    if constexpr (sizeof(T) == 2)
+    {
+        // paired-lane variant: rows must start on dword boundaries
+        const bool even = !(p.iw & 1) && !(p.xs[0] & 1) && !(p.xs[1] & 1) && !(p.xs[2] & 1) && !((uintptr_t)p.x & 3);
+        const bool evenOut = !(p.ow & 1) && !(p.ys[0] & 1) && !(p.ys[1] & 1) && !(p.ys[2] & 1) && !((uintptr_t)p.y & 3);
+        if (even && (down2 || evenOut))
+        {
+            const int need = down2 ? ((p.iw / 2 > p.ow) ? p.iw / 2 : p.ow) : ((p.ow / 2 > p.iw / 2) ? p.ow / 2 : p.iw / 2);
+            p.laneWLog = 0; while ((1 << p.laneWLog) < need) p.laneWLog++;
+            const int ppb = (kWaveThreads / 64) * (64 >> p.laneWLog);
+            const int64_t nblk = (p.totalPlanes + ppb - 1) / ppb;
+            if (nblk > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+            if (up2) hipLaunchKernelGGL((upfirdn2d_wave_up2_pair_kernel<T>), dim3((unsigned)nblk), dim3(kWaveThreads), 0, stream, p);
+            else     hipLaunchKernelGGL((upfirdn2d_wave_down2_pair_kernel<T>), dim3((unsigned)nblk), dim3(kWaveThreads), 0, stream, p);
+            return lvg_check_launch("upfirdn2d_wave_pair_kernel");
+        }
+    }
+    p.laneWLog = 0; while ((1 << p.laneWLog) < wmax) p.laneWLog++;
     const int planesPerBlock = (kWaveThreads / 64) * (64 >> p.laneWLog);
     const int64_t blocks = (p.totalPlanes + planesPerBlock - 1) / planesPerBlock;
     if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;

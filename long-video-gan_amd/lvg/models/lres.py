@@ -101,8 +101,12 @@ class TemporalKaiserDownsample(_FilterHolder):
         super().__init__(torch.tensor(taps, dtype=torch.float32), scale)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # [N, C, T] latents: the time axis is presented as H of an [N, C, T, 1] view (no copy even
-        # when the view is a permutation; the kernel takes element strides).
+        # [N, C, T] latents. The mapping network hands them out as a permuted view of [N, T, C]; present
+        # that memory as planes [N, 1, T, C] so that the channel axis is the coalesced W axis of the kernel.
+        if x.dim() == 3 and x.stride(1) == 1 and x.shape[1] > 1:
+            rows = x.permute(0, 2, 1).unsqueeze(1)
+            y = upfirdn2d.downsample2d(rows, self.filter.unsqueeze(1), down=(1, self.scale))
+            return y.squeeze(1).permute(0, 2, 1)
         y = upfirdn2d.downsample2d(x.unsqueeze(3), self.filter.unsqueeze(1), down=(1, self.scale))
         return y.squeeze(3)
 
