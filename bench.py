@@ -93,6 +93,10 @@ class OpTimer:
             d['launches'] += 1
             d['total_ms'] += a.elapsed_time(b) / reps
             d['bytes'] += nbytes
+            if os.environ.get('LVG_BENCH_VERBOSE'):
+                us = a.elapsed_time(b) / reps * 1e3
+                extra = [x for x in args[2:12] if isinstance(x, (int, float, bool))] if op == 'upfirdn2d' else []
+                print(f'[op] {op:13s} x={tuple(args[0].shape)} strides={tuple(args[0].stride())} {args[0].dtype} {extra} {us:8.1f} us {nbytes / us / 1e3:8.1f} GB/s', file=sys.stderr)
             del g
         for d in out.values():
             d['gbps'] = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9 if d['total_ms'] > 0 else 0.0

@@ -217,6 +217,78 @@ __global__ __launch_bounds__(kThreads) void bias_act_vec_kernel(BiasActArgs p)
     }
 }
 
+// Flat variant for SHORT rows (frames layout: a bias segment is one H*W plane, a few dozen vectors):
+// one 1-D grid over all vectors; a lane finds (row, col) of its first vector with one 32-bit division
+// and steps to its other UNROLL-1 vectors incrementally, so short rows still fill every lane.
+template <class T, int ACT, int G>
+__global__ __launch_bounds__(kThreads) void bias_act_flat_kernel(BiasActArgs p)
+{
+    typedef typename Elem<T>::acc_t A;
+    constexpr int V = Elem<T>::kVec;
+    const A alpha = (A)p.alpha, gain = (A)p.gain, clamp = (A)p.clamp;
+    const uint32_t nvec = (uint32_t)(p.rows * p.rowVecs);
+    const uint32_t rowVecs = (uint32_t)p.rowVecs;
+    const uint32_t idx0 = blockIdx.x * (uint32_t)(kUnroll * kThreads) + threadIdx.x;
+    uint32_t row = idx0 / rowVecs, col = idx0 - row * rowVecs;
+    const uint32_t drow = (uint32_t)kThreads / rowVecs, dcol = (uint32_t)kThreads - drow * rowVecs;
+
+    const T* __restrict__ xp  = (const T*)p.x;
+    const T* __restrict__ bp  = (const T*)p.b;
+    const T* __restrict__ xrp = (const T*)p.xref;
+    const T* __restrict__ yrp = (const T*)p.yref;
+    const T* __restrict__ dyp = (const T*)p.dy;
+    T* __restrict__ yp = (T*)p.y;
+
+    Vec16<T> vx[kUnroll], vxr[kUnroll], vyr[kUnroll], vdy[kUnroll];
+    uint32_t rows[kUnroll], cols[kUnroll];
+    #pragma unroll
+    for (int u = 0; u < kUnroll; u++)
+    {
+        rows[u] = row; cols[u] = col;
+        const uint32_t iv = idx0 + (uint32_t)u * kThreads;
+        if (iv < nvec)
+        {
+            const int64_t e = (int64_t)iv * V;
+            vx[u] = load_vec16<T>(xp + e);
+            if (G > 0 && ACT == LVG_ACT_SWISH) vxr[u] = load_vec16<T>(xrp + e);
+            if (G > 0 && ACT != LVG_ACT_SWISH && (ACT != LVG_ACT_LINEAR || yrp)) vyr[u] = load_vec16<T>(yrp + e);
+            if (G == 2) vdy[u] = load_vec16<T>(dyp + e);
+        }
+        col += dcol; row += drow;
+        if (col >= rowVecs) { col -= rowVecs; row++; }
+    }
+    #pragma unroll
+    for (int u = 0; u < kUnroll; u++)
+    {
+        const uint32_t iv = idx0 + (uint32_t)u * kThreads;
+        if (iv >= nvec) continue;
+        A bias[V];
+        if (p.biasMode == 2)
+        {
+            Vec16<T> vb = load_vec16<T>(bp + (int64_t)cols[u] * V);
+            #pragma unroll
+            for (int k = 0; k < V; k++) bias[k] = (A)to_acc(vb.v[k]);
+        }
+        else
+        {
+            const A rb = (p.biasMode == 1) ? (A)to_acc(bp[rows[u] % (uint32_t)p.sizeB]) : (A)0;
+            #pragma unroll
+            for (int k = 0; k < V; k++) bias[k] = rb;
+        }
+        Vec16<T> out;
+        #pragma unroll
+        for (int k = 0; k < V; k++)
+        {
+            const A in  = (A)to_acc(vx[u].v[k]);
+            const A xr  = (G > 0 && ACT == LVG_ACT_SWISH) ? (A)to_acc(vxr[u].v[k]) : (A)0;
+            const A yr  = (G > 0 && ACT != LVG_ACT_SWISH && (ACT != LVG_ACT_LINEAR || yrp)) ? (A)to_acc(vyr[u].v[k]) : (A)0;
+            const A dyv = (G == 2) ? (A)to_acc(vdy[u].v[k]) : (A)1;
+            out.v[k] = from_acc<T>(bias_act_elem<A, ACT, G>(in, bias[k], xr, yr, dyv, alpha, gain, clamp));
+        }
+        store_vec16<T>(yp + (int64_t)iv * V, out);
+    }
+}
+
 // One element per lane: tails, unaligned views and bias layouts the vector kernel does not take.
 template <class T, int ACT>
 __global__ __launch_bounds__(kThreads) void bias_act_scalar_kernel(BiasActArgs p)
@@ -246,6 +318,13 @@ int launch_vec(const BiasActArgs& p, hipStream_t stream)
     const int64_t rowsY = p.rows < 65535 ? p.rows : 65535;
     const int64_t rowsZ = lvg_ceil_div(p.rows, rowsY);
     LVG_REQUIRE(rowsZ <= 65535, "bias_act: too many bias segments for one launch");
+    if (p.rowVecs < 4 * kThreads && p.rows * p.rowVecs < 0xffffffffLL - kUnroll * kThreads)
+    {
+        // short rows: flat grid (every lane busy)
+        const int64_t bx = lvg_ceil_div(p.rows * p.rowVecs, (int64_t)kUnroll * kThreads);
+        hipLaunchKernelGGL((bias_act_flat_kernel<T, ACT, G>), dim3((unsigned)bx), dim3(kThreads), 0, stream, p);
+        return lvg_check_launch("bias_act_flat_kernel");
+    }
     if (p.rowVecs <= kThreads)
     {
         hipLaunchKernelGGL((bias_act_vec_kernel<T, ACT, G, 1>), dim3(1, (unsigned)rowsY, (unsigned)rowsZ), dim3(kThreads), 0, stream, p);

@@ -24,6 +24,7 @@
 // Roofline: HBM stream, (N_in + N_out) * sizeof(T) algorithmic bytes per call.
 
 #include "lvg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -49,6 +50,7 @@ struct UpfirdnArgs
     int inTW, inTH;         // input tile incl. halo
     int planesPerBlock;     // planes batched into one block (tiny planes)
     int laneWLog, laneWInLog; // log2 of lanes along x for the output / input tile (fast kernel)
+    int rowChunks, chunkRows; // wave kernels: output rows are split into rowChunks chunks of chunkRows (grid y)
     int uniformPlanes;      // xs[0] == C * xs[1] (and same for y): plane index * stride addresses a plane
     int64_t totalPlanes;
 };
@@ -602,7 +604,9 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_kernel(Upfi
     };
 
     // prologue: the two rows above the first batch
-    const int base0 = -p.pady0;
+    const int oyBeg = blockIdx.y * p.chunkRows;
+    const int oyEnd = (oyBeg + p.chunkRows < p.oh) ? oyBeg + p.chunkRows : p.oh;
+    const int base0 = 2 * oyBeg - p.pady0;
     float c0, c1;
     {
         const int iy0 = base0, iy1 = base0 + 1;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_kernel(Upfi
         const float v1 = wave_load(xp + (int64_t)iy1 * xs2, x, colLoad && iy1 >= 0 && iy1 < p.ih);
         c0 = hrow(v0); c1 = hrow(v1);
     }
-    for (int oy0 = 0; oy0 < p.oh; oy0 += kRows / 2)
+    for (int oy0 = oyBeg; oy0 < oyEnd; oy0 += kRows / 2)
     {
         const int rbase = 2 * oy0 - p.pady0 + 2;      // first new input row of this batch
         float v[kRows];
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_kernel(Upfi
             float acc = 0.0f;
             #pragma unroll
             for (int k = 0; k < 4; k++) acc = fmaf(h[2 * j + k], fy[k], acc);
-            if (colOut && oy < p.oh) yp[(int64_t)oy * ys2 + x] = from_acc<T>(acc * p.gain);
+            if (colOut && oy < oyEnd) yp[(int64_t)oy * ys2 + x] = from_acc<T>(acc * p.gain);
         }
         c0 = h[kRows]; c1 = h[kRows + 1];
     }
@@ -679,8 +683,10 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_up2_kernel(Upfird
     };
 
     // Output rows produced by the input-row pair (j, j + 1): oyA = 2 j - 1 + pady0 (taps 1, 3) and oyA + 1 (taps 0, 2).
-    const int jMin = lvg_floor_div(1 - p.pady0, 2);            // j of output row 0
-    const int jMax = lvg_floor_div(p.oh - p.pady0, 2);         // j of output row oh - 1
+    const int oyBeg = blockIdx.y * p.chunkRows;
+    const int oyEnd = (oyBeg + p.chunkRows < p.oh) ? oyBeg + p.chunkRows : p.oh;
+    const int jMin = lvg_floor_div(oyBeg + 1 - p.pady0, 2);    // j of the chunk's first output row
+    const int jMax = lvg_floor_div(oyEnd - p.pady0, 2);        // j of its last output row
     float hPrev;
     {
         const int iy = jMin;
@@ -705,8 +711,8 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_up2_kernel(Upfird
             const float ob = fmaf(hPrev, fy[0], hCur * fy[2]) * g;
             if (colOut && j <= jMax)
             {
-                if (oyA >= 0 && oyA < p.oh) yp[(int64_t)oyA * ys2 + x] = from_acc<T>(oa);
-                if (oyA + 1 >= 0 && oyA + 1 < p.oh) yp[(int64_t)(oyA + 1) * ys2 + x] = from_acc<T>(ob);
+                if (oyA >= oyBeg && oyA < oyEnd) yp[(int64_t)oyA * ys2 + x] = from_acc<T>(oa);
+                if (oyA + 1 >= oyBeg && oyA + 1 < oyEnd) yp[(int64_t)(oyA + 1) * ys2 + x] = from_acc<T>(ob);
             }
             hPrev = hCur;
         }
@@ -741,7 +747,7 @@ template <class T, int VB> struct VecIO
     }
 };
 
-constexpr int kColChunk = 32;   // output rows per thread (down: 32, up: 32)
+constexpr int kColChunk = 8;    // output rows per thread: short chains (one or two load batches), many threads
 
 template <class T, int VB, bool UP2>
 __global__ __launch_bounds__(256) void upfirdn2d_col_kernel(UpfirdnArgs p)
@@ -890,9 +896,10 @@ int launch_col(UpfirdnArgs& p, hipStream_t stream)
 // covers 128 input columns' worth of planes with 4-byte loads/stores and every lane produces output.
 
 template <class T>
-__device__ __forceinline__ float half_of(uint32_t raw, int hi)
+__device__ __forceinline__ float half_of(uint32_t raw, int shift, uint32_t okMask)
 {
-    T t; t.bits = (uint16_t)(hi ? (raw >> 16) : (raw & 0xffffu));
+    // shift = 0 / 16 selects the low / high element; okMask = 0 turns the value into +0.0 (branch-free)
+    T t; t.bits = (uint16_t)(((raw & okMask) >> shift) & 0xffffu);
     return (float)to_acc(t);
 }
 template <class T>
@@ -926,15 +933,16 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_pair_kernel
         fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
     }
     const int laneBase = lane - x;
-    int src[4], hi[4]; bool srcOk[4];
+    int src[4], sh[4]; uint32_t okm[4];
     #pragma unroll
     for (int k = 0; k < 4; k++)
     {
         const int e = 2 * x - p.padx0 + k;                    // input column of tap k for output column x
-        srcOk[k] = e >= 0 && e < p.iw;
-        const int ec = srcOk[k] ? e : 0;
+        const bool ok = e >= 0 && e < p.iw;
+        const int ec = ok ? e : 0;
+        okm[k] = ok ? 0xffffffffu : 0u;
         src[k] = laneBase + (ec >> 1);
-        hi[k] = ec & 1;
+        sh[k] = (ec & 1) * 16;
     }
     const bool colLoad = planeOk && x < iwPairs;
     const bool colOut = planeOk && x < p.ow;
@@ -945,14 +953,16 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_pair_kernel
         for (int k = 0; k < 4; k++)
         {
             const uint32_t t = (uint32_t)__shfl((int)raw, src[k]);
-            acc = fmaf(srcOk[k] ? half_of<T>(t, hi[k]) : 0.0f, fx[k], acc);
+            acc = fmaf(half_of<T>(t, sh[k], okm[k]), fx[k], acc);
         }
         return acc;
     };
     auto ld = [&](int iy) -> uint32_t { return (colLoad && iy >= 0 && iy < p.ih) ? xp[(int64_t)iy * xs2w + x] : 0u; };
 
-    float c0 = hrow(ld(-p.pady0)), c1 = hrow(ld(-p.pady0 + 1));
-    for (int oy0 = 0; oy0 < p.oh; oy0 += kRows / 2)
+    const int oyBeg = blockIdx.y * p.chunkRows;
+    const int oyEnd = (oyBeg + p.chunkRows < p.oh) ? oyBeg + p.chunkRows : p.oh;
+    float c0 = hrow(ld(2 * oyBeg - p.pady0)), c1 = hrow(ld(2 * oyBeg - p.pady0 + 1));
+    for (int oy0 = oyBeg; oy0 < oyEnd; oy0 += kRows / 2)
     {
         const int rbase = 2 * oy0 - p.pady0 + 2;
         uint32_t v[kRows];
@@ -969,99 +979,9 @@ __global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_down2_pair_kernel
             float acc = 0.0f;
             #pragma unroll
             for (int k = 0; k < 4; k++) acc = fmaf(h[2 * j + k], fy[k], acc);
-            if (colOut && oy < p.oh) yp[(int64_t)oy * ys2 + x] = from_acc<T>(acc * p.gain);
+            if (colOut && oy < oyEnd) yp[(int64_t)oy * ys2 + x] = from_acc<T>(acc * p.gain);
         }
         c0 = h[kRows]; c1 = h[kRows + 1];
-    }
-}
-
-template <class T>
-__global__ __launch_bounds__(kWaveThreads) void upfirdn2d_wave_up2_pair_kernel(UpfirdnArgs p)
-{
-    constexpr int kRows = 4;
-    const int gw = 1 << p.laneWLog;                // lanes per plane row: >= ow / 2
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane >> p.laneWLog, x = lane & (gw - 1);
-    const int planesPerWave = 64 >> p.laneWLog;
-    const int64_t plane = ((int64_t)blockIdx.x * (kWaveThreads / 64) + wave) * planesPerWave + grp;
-    const bool planeOk = plane < p.totalPlanes;
-    const int64_t pc = planeOk ? plane : 0;
-    const int nb = (int)(pc / p.c), ch = (int)(pc - (int64_t)nb * p.c);
-    const uint32_t* xp = (const uint32_t*)((const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1]);
-    uint32_t* yp = (uint32_t*)((T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1]);
-    const int xs2w = (int)(p.xs[2] >> 1), ys2w = (int)(p.ys[2] >> 1);
-    const int iwPairs = p.iw >> 1, owPairs = p.ow >> 1;
-
-    float fx[4], fy[4];
-    #pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
-        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
-    }
-    const int laneBase = lane - x;
-    // two output columns (2x, 2x+1), two taps each
-    int src[4], hi[4]; bool ok[4]; float tap[4];
-    #pragma unroll
-    for (int o = 0; o < 2; o++)
-    {
-        const int m = 2 * x + o + 1 - p.padx0;
-        const int i0 = lvg_floor_div(m, 2);
-        const int ph = m - 2 * i0;
-        #pragma unroll
-        for (int k = 0; k < 2; k++)
-        {
-            const int e = i0 + k;
-            const int q = o * 2 + k;
-            ok[q] = e >= 0 && e < p.iw;
-            const int ec = ok[q] ? e : 0;
-            src[q] = laneBase + (ec >> 1);
-            hi[q] = ec & 1;
-            tap[q] = ph ? fx[2 * k] : fx[2 * k + 1];
-        }
-    }
-    const bool colLoad = planeOk && x < iwPairs;
-    const bool colOut = planeOk && x < owPairs;
-    const float g = p.gain;
-
-    float h0, h1;
-    auto hrow = [&](uint32_t raw) {
-        float v[4];
-        #pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            const uint32_t t = (uint32_t)__shfl((int)raw, src[q]);
-            v[q] = ok[q] ? half_of<T>(t, hi[q]) : 0.0f;
-        }
-        h0 = fmaf(v[0], tap[0], v[1] * tap[1]);
-        h1 = fmaf(v[2], tap[2], v[3] * tap[3]);
-    };
-    auto ld = [&](int iy) -> uint32_t { return (colLoad && iy >= 0 && iy < p.ih) ? xp[(int64_t)iy * xs2w + x] : 0u; };
-
-    const int jMin = lvg_floor_div(1 - p.pady0, 2);
-    const int jMax = lvg_floor_div(p.oh - p.pady0, 2);
-    hrow(ld(jMin));
-    float p0 = h0, p1 = h1;
-    for (int j0 = jMin; j0 <= jMax; j0 += kRows)
-    {
-        uint32_t v[kRows];
-        #pragma unroll
-        for (int r = 0; r < kRows; r++) v[r] = ld(j0 + 1 + r);
-        #pragma unroll
-        for (int r = 0; r < kRows; r++)
-        {
-            hrow(v[r]);
-            const int j = j0 + r;
-            const int oyA = 2 * j - 1 + p.pady0;
-            const uint32_t oa = pack2<T>(fmaf(p0, fy[1], h0 * fy[3]) * g, fmaf(p1, fy[1], h1 * fy[3]) * g);
-            const uint32_t ob = pack2<T>(fmaf(p0, fy[0], h0 * fy[2]) * g, fmaf(p1, fy[0], h1 * fy[2]) * g);
-            if (colOut && j <= jMax)
-            {
-                if (oyA >= 0 && oyA < p.oh) yp[(int64_t)oyA * ys2w + x] = oa;
-                if (oyA + 1 >= 0 && oyA + 1 < p.oh) yp[(int64_t)(oyA + 1) * ys2w + x] = ob;
-            }
-            p0 = h0; p1 = h1;
-        }
     }
 }
 
@@ -1079,20 +999,23 @@ int launch_wave(UpfirdnArgs& p, hipStream_t stream)
     // rows must be addressable with 32-bit offsets inside a plane
     if ((int64_t)(p.ih + 16) * (p.xs[2] < 0 ? -p.xs[2] : p.xs[2]) >= 0x7fffffffLL || (int64_t)(p.oh + 16) * p.ys[2] >= 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
     p.totalPlanes = (int64_t)p.n * p.c;
+    // Row chunking (grid y) is wired in but measured slower than one wave per plane on MI355X (the halo
+    // rows cost more than the shorter dependent chains save), so a plane is one chunk.
+    p.chunkRows = 1 << 30;
+    p.rowChunks = 1;
     if constexpr (sizeof(T) == 2)
     {
         // paired-lane variant: rows must start on dword boundaries
         const bool even = !(p.iw & 1) && !(p.xs[0] & 1) && !(p.xs[1] & 1) && !(p.xs[2] & 1) && !((uintptr_t)p.x & 3);
-        const bool evenOut = !(p.ow & 1) && !(p.ys[0] & 1) && !(p.ys[1] & 1) && !(p.ys[2] & 1) && !((uintptr_t)p.y & 3);
-        if (even && (down2 || evenOut))
+        // (a paired-lane up2 variant measured slower than the plain one: fixed ~14 us overhead; not used)
+        if (even && down2)
         {
             const int need = down2 ? ((p.iw / 2 > p.ow) ? p.iw / 2 : p.ow) : ((p.ow / 2 > p.iw / 2) ? p.ow / 2 : p.iw / 2);
             p.laneWLog = 0; while ((1 << p.laneWLog) < need) p.laneWLog++;
             const int ppb = (kWaveThreads / 64) * (64 >> p.laneWLog);
             const int64_t nblk = (p.totalPlanes + ppb - 1) / ppb;
             if (nblk > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
-            if (up2) hipLaunchKernelGGL((upfirdn2d_wave_up2_pair_kernel<T>), dim3((unsigned)nblk), dim3(kWaveThreads), 0, stream, p);
-            else     hipLaunchKernelGGL((upfirdn2d_wave_down2_pair_kernel<T>), dim3((unsigned)nblk), dim3(kWaveThreads), 0, stream, p);
+            hipLaunchKernelGGL((upfirdn2d_wave_down2_pair_kernel<T>), dim3((unsigned)nblk, (unsigned)p.rowChunks), dim3(kWaveThreads), 0, stream, p);
             return lvg_check_launch("upfirdn2d_wave_pair_kernel");
         }
     }
@@ -1100,8 +1023,8 @@ int launch_wave(UpfirdnArgs& p, hipStream_t stream)
     const int planesPerBlock = (kWaveThreads / 64) * (64 >> p.laneWLog);
     const int64_t blocks = (p.totalPlanes + planesPerBlock - 1) / planesPerBlock;
     if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
-    if (up2) hipLaunchKernelGGL((upfirdn2d_wave_up2_kernel<T>), dim3((unsigned)blocks), dim3(kWaveThreads), 0, stream, p);
-    else     hipLaunchKernelGGL((upfirdn2d_wave_down2_kernel<T>), dim3((unsigned)blocks), dim3(kWaveThreads), 0, stream, p);
+    if (up2) hipLaunchKernelGGL((upfirdn2d_wave_up2_kernel<T>), dim3((unsigned)blocks, (unsigned)p.rowChunks), dim3(kWaveThreads), 0, stream, p);
+    else     hipLaunchKernelGGL((upfirdn2d_wave_down2_kernel<T>), dim3((unsigned)blocks, (unsigned)p.rowChunks), dim3(kWaveThreads), 0, stream, p);
     return lvg_check_launch("upfirdn2d_wave_kernel");
 }
 
@@ -1190,7 +1113,7 @@ extern "C" int lvg_upfirdn2d(const void* x, void* y, const float* f2d, const flo
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy;
     p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
     p.tileW = p.tileH = p.tilesX = p.tilesY = p.inTW = p.inTH = 0;
-    p.planesPerBlock = 1; p.uniformPlanes = 0; p.totalPlanes = (int64_t)p.n * p.c; p.laneWLog = p.laneWInLog = 6;
+    p.planesPerBlock = 1; p.uniformPlanes = 0; p.totalPlanes = (int64_t)p.n * p.c; p.laneWLog = p.laneWInLog = 6; p.rowChunks = 1; p.chunkRows = 1 << 30;
 
     hipStream_t s = (hipStream_t)stream;
     switch (dtype)

@@ -49,6 +49,9 @@ def main():
         from torch_utils.ops.bias_act import _launch
         report(f'bias_act_lrelu_bwd[4,64,128,36,64]{dtype}', timeit(lambda: _launch(x2, bb, None, y2, None, 1, 1, 3, 0.2, 1.414, 256.0)), 3 * x2.numel() * s)
         del x2, y2
+        for shp in ([512, 64, 36, 64], [640, 512, 9, 16], [96, 512, 3, 4]):
+            xf = torch.randn(*shp, device=dev).to(dtype); bf_ = torch.randn(shp[1], device=dev).to(dtype)
+            report(f'bias_act_frames{shp}{dtype}', timeit(lambda: bias_act.bias_act(xf, bf_, act='lrelu', clamp=256)), 2 * xf.numel() * s)
         f = torch.tensor([0.125, 0.375, 0.375, 0.125], device=dev)
         x = torch.randn(1, 8192, 18, 32, device=dev).to(dtype)
         y = upfirdn2d.upsample2d(x, f)
