@@ -1028,6 +1028,106 @@ int launch_wave(UpfirdnArgs& p, hipStream_t stream)
     return lvg_check_launch("upfirdn2d_wave_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channels-last (NHWC) kernel: separable <= 4 taps, up/down in {1, 2}. The frames-layout networks
+// keep activations channels-last (MIOpen's MFMA implicit-GEMM convs are NHWC-native; with NCHW tensors
+// every conv is wrapped in two layout-transpose kernels). A lane owns one VB-byte vector of channels
+// of one output pixel; lanes of a wave cover consecutive channel vectors, then consecutive pixels, so
+// every load and store is a fully coalesced 16-byte access. Neighbouring pixels re-read the same input
+// vectors from L1/L2; HBM sees each input once.
+
+template <class T, int UPX, int UPY, int DOWNX, int DOWNY, int VB>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(UpfirdnArgs p)
+{
+    typedef VecIO<T, VB> IO;
+    constexpr int V = IO::V;
+    constexpr int FP = 4;
+    constexpr int NKX = FP / UPX, NKY = FP / UPY;
+    const int cvecs = p.c / V;
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)p.n * p.oh * p.ow * cvecs;
+    if (t >= total) return;
+    const int cv = (int)(t % cvecs); t /= cvecs;
+    const int ox = (int)(t % p.ow); t /= p.ow;
+    const int oy = (int)(t % p.oh);
+    const int nb = (int)(t / p.oh);
+
+    float fx[FP], fy[FP];
+    #pragma unroll
+    for (int k = 0; k < FP; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    const int midX = ox * DOWNX + UPX - 1 - p.padx0, midY = oy * DOWNY + UPY - 1 - p.pady0;
+    const int inX = lvg_floor_div(midX, UPX), inY = lvg_floor_div(midY, UPY);
+    const int phX = midX - inX * UPX, phY = midY - inY * UPY;
+
+    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)cv * V;     // channel stride is 1
+    float acc[V];
+    #pragma unroll
+    for (int i = 0; i < V; i++) acc[i] = 0.0f;
+    #pragma unroll
+    for (int ky = 0; ky < NKY; ky++)
+    {
+        const int iy = inY + ky;
+        const float wy = tap_for_phase<UPY, FP>(fy, phY, ky);
+        const bool rowOk = iy >= 0 && iy < p.ih;
+        float row[V];
+        #pragma unroll
+        for (int i = 0; i < V; i++) row[i] = 0.0f;
+        #pragma unroll
+        for (int kx = 0; kx < NKX; kx++)
+        {
+            const int ix = inX + kx;
+            const float wx = tap_for_phase<UPX, FP>(fx, phX, kx);
+            float v[V];
+            IO::load(xp + (int64_t)iy * p.xs[2] + (int64_t)ix * p.xs[3], rowOk && ix >= 0 && ix < p.iw, v);
+            #pragma unroll
+            for (int i = 0; i < V; i++) row[i] = fmaf(v[i], wx, row[i]);
+        }
+        #pragma unroll
+        for (int i = 0; i < V; i++) acc[i] = fmaf(row[i], wy, acc[i]);
+    }
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)oy * p.ys[2] + (int64_t)ox * p.ys[3] + (int64_t)cv * V;
+    IO::store(yp, acc, p.gain);
+}
+
+template <class T, int VB>
+int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
+{
+    constexpr int V = VB / (int)sizeof(T);
+    const int64_t total = (int64_t)p.n * p.oh * p.ow * (p.c / V);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)blocks), block(256);
+    #define LVG_NHWC_CASE(ux, uy, dx, dy) if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy) { \
+        hipLaunchKernelGGL((upfirdn2d_nhwc_kernel<T, ux, uy, dx, dy, VB>), grid, block, 0, stream, p); return lvg_check_launch("upfirdn2d_nhwc_kernel"); }
+    LVG_NHWC_CASE(2, 2, 1, 1)
+    LVG_NHWC_CASE(1, 1, 2, 2)
+    LVG_NHWC_CASE(1, 1, 1, 1)
+    #undef LVG_NHWC_CASE
+    return LVG_ERR_UNSUPPORTED;
+}
+
+template <class T>
+int launch_nhwc(UpfirdnArgs& p, hipStream_t stream)
+{
+    // channels-last: unit channel stride, pixels C apart, both tensors
+    if (p.f2d || p.fw > 4 || p.fh > 4 || p.c < 2) return LVG_ERR_UNSUPPORTED;
+    if (p.xs[1] != 1 || p.ys[1] != 1 || p.xs[3] != p.c || p.ys[3] != p.c) return LVG_ERR_UNSUPPORTED;
+    auto fits = [&](int vb) {
+        const int v = vb / (int)sizeof(T);
+        if (v < 1 || p.c % v) return false;
+        if (((uintptr_t)p.x % vb) || ((uintptr_t)p.y % vb)) return false;
+        if ((p.xs[0] % v) || (p.xs[2] % v) || (p.ys[0] % v) || (p.ys[2] % v)) return false;
+        return true;
+    };
+    if (fits(16)) return launch_nhwc_vb<T, 16>(p, stream);
+    if (fits(8))  return launch_nhwc_vb<T, 8>(p, stream);
+    return LVG_ERR_UNSUPPORTED;
+}
+
 template <class T>
 int launch_gather(UpfirdnArgs& p, hipStream_t stream)
 {
@@ -1068,6 +1168,11 @@ int run(UpfirdnArgs& p, hipStream_t stream)
     // The tiled kernel wants W to be the fast axis of the input; otherwise gather.
     // (float64 always gathers: the tiles are staged in LDS as float32.)
     const bool wFast = (p.xs[3] == 1) || p.iw == 1;
+    if constexpr (sizeof(T) <= 4)
+    {
+        int rcn = launch_nhwc<T>(p, stream);
+        if (rcn != LVG_ERR_UNSUPPORTED) return rcn;
+    }
     if constexpr (sizeof(T) <= 4) if (wFast)
     {
         int rcw = launch_wave<T>(p, stream);

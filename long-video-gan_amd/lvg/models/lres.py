@@ -16,6 +16,7 @@ re-implementation organised around the HIP custom ops:
 """
 
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -28,6 +29,15 @@ import torch_utils.distributed as dist_utils
 from torch_utils.ops import bias_act, upfirdn2d
 
 SQRT_HALF = math.sqrt(0.5)
+
+# Frames-layout activations are kept channels-last ([(T N), H, W, C] in memory): MIOpen's implicit-GEMM
+# kernels are NHWC-native, NCHW inputs cost two layout-transpose kernels plus copies per convolution
+# (measured: 26 % of the step). The HIP ops take either layout.
+CHANNELS_LAST = os.environ.get('LVG_CHANNELS_LAST', '1') != '0'
+
+
+def _cl(x: torch.Tensor) -> torch.Tensor:
+    return x.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST else x
 
 
 # --------------------------------------------------------------------------------------------------
@@ -205,32 +215,129 @@ def video_from_frames(frames: torch.Tensor, n: int) -> torch.Tensor:
     return frames.reshape(tn // n, n, c, h, w).permute(1, 2, 0, 3, 4)
 
 
+def _tap_slices(k: int, pt: int, n: int, total: int):
+    """(input frame slice, output frame slice) of temporal tap k, or None if the tap never overlaps."""
+    shift = (k - pt) * n                               # output frame t reads input frame t + (k - pt)
+    if abs(shift) >= total:
+        return None
+    if shift == 0:
+        return slice(None), slice(None)
+    if shift < 0:
+        return slice(None, shift), slice(-shift, None)
+    return slice(shift, None), slice(None, -shift)
+
+
+class _TemporalConvFrames(torch.autograd.Function):
+    """conv3d ('same' zero padding in time) as kt 2-D convolutions on time-major frames, with a
+    hand-written backward: each tap's data/weight gradient is one MIOpen call accumulated straight into
+    slices of the result (autograd's own slice backward would materialise a zero-padded full-size tensor
+    per tap, in NCHW, and trigger layout conversions). Backward is built from differentiable ops, so
+    double backward (R1) works."""
+
+    @staticmethod
+    def forward(ctx, x, weight, n, padding_hw):
+        kt = weight.shape[2]
+        pt = kt // 2
+        total = x.shape[0]
+        taps = [_cl(weight[:, :, k]) for k in range(kt)]
+        y = F.conv2d(x, taps[pt], padding=padding_hw)
+        for k in range(kt):
+            sl = _tap_slices(k, pt, n, total)
+            if k == pt or sl is None:
+                continue
+            y[sl[1]] += F.conv2d(x[sl[0]], taps[k], padding=padding_hw)
+        ctx.save_for_backward(x, weight)
+        ctx.n, ctx.padding_hw = n, padding_hw
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        n, pad = ctx.n, list(ctx.padding_hw)
+        kt = weight.shape[2]
+        pt = kt // 2
+        total = x.shape[0]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gy = _cl(gy)
+        gx = None
+        gws = []
+        for k in [pt] + [k for k in range(kt) if k != pt]:
+            sl = _tap_slices(k, pt, n, total)
+            wk = _cl(weight[:, :, k])
+            if sl is None:
+                gws.append((k, torch.zeros_like(wk)))
+                continue
+            gxi, gwi, _ = torch.ops.aten.convolution_backward(
+                gy[sl[1]], x[sl[0]], wk, None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need_x, need_w, False])
+            if need_x:
+                if gx is None:
+                    gx = gxi                       # centre tap first: full frame range
+                else:
+                    gx[sl[0]] = gx[sl[0]] + gxi
+            if need_w:
+                gws.append((k, gwi))
+        gw = None
+        if need_w:
+            gws.sort(key=lambda kv: kv[0])
+            gw = torch.stack([g for _, g in gws], dim=2)
+        return gx, gw, None, None
+
+
 def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw) -> torch.Tensor:
     """conv3d with 'same' zero padding in time, as kt 2-D convolutions. x [(T N), Ci, H, W] and
     weight [Co, Ci, kt, kh, kw] in the compute dtype."""
-    kt = weight.shape[2]
-    pt = kt // 2
-    total = x.shape[0]
-    y = F.conv2d(x, weight[:, :, pt], padding=padding_hw)
-    for k in range(kt):
-        shift = (k - pt) * n                       # output frame t reads input frame t + (k - pt)
-        if shift == 0 or abs(shift) >= total:
-            continue
-        if shift < 0:
-            y[-shift:] += F.conv2d(x[:shift], weight[:, :, k], padding=padding_hw)
-        else:
-            y[:-shift] += F.conv2d(x[shift:], weight[:, :, k], padding=padding_hw)
-    return y
+    return _TemporalConvFrames.apply(x, weight, n, tuple(padding_hw))
+
+
+class _CropFrames(torch.autograd.Function):
+    """Centre crop of frames / rows / columns whose backward writes the gradient into a zero tensor of the
+    INPUT's memory format (autograd's slice backward always produces NCHW-contiguous zeros)."""
+
+    @staticmethod
+    def forward(ctx, x, f0, f1, y0, y1, x0, x1):
+        ctx.shape, ctx.box = x.shape, (f0, f1, y0, y1, x0, x1)
+        ctx.cl = x.dim() == 4 and x.shape[1] > 1 and x.stride(1) == 1
+        out = x[f0:f1, :, y0:y1, x0:x1]
+        return out.contiguous(memory_format=torch.channels_last if ctx.cl else torch.contiguous_format)
+
+    @staticmethod
+    def backward(ctx, g):
+        f0, f1, y0, y1, x0, x1 = ctx.box
+        full = torch.empty(ctx.shape, dtype=g.dtype, device=g.device,
+                           memory_format=torch.channels_last if ctx.cl else torch.contiguous_format).zero_()
+        full[f0:f1, :, y0:y1, x0:x1] = g
+        return full, None, None, None, None, None, None
+
+
+def crop_frames(x: torch.Tensor, n: int, seq_length: Optional[int] = None, height: Optional[int] = None, width: Optional[int] = None) -> torch.Tensor:
+    """Centred crop of [(T N), C, H, W] in time / height / width; no-op (same tensor) when nothing is cut."""
+    tn, _, h, w = x.shape
+    f0, f1, y0, y1, x0, x1 = 0, tn, 0, h, 0, w
+    if seq_length is not None:
+        t0 = (tn // n - seq_length) // 2
+        f0, f1 = t0 * n, (t0 + seq_length) * n
+    if height is not None:
+        y0 = (h - height) // 2
+        y1 = y0 + height
+    if width is not None:
+        x0 = (w - width) // 2
+        x1 = x0 + width
+    if (f0, f1, y0, y1, x0, x1) == (0, tn, 0, h, 0, w):
+        return x
+    return _CropFrames.apply(x, f0, f1, y0, y1, x0, x1)
 
 
 def resample_time_frames(x: torch.Tensor, taps: torch.Tensor, n: int, up: int = 1, down: int = 1) -> torch.Tensor:
     """x2 up/down-sampling along time of [(T N), C, H, W]: the frame axis is H of a [1, 1, T, (N C H W)] view."""
     tn, c, h, w = x.shape
-    rows = x.reshape(1, 1, tn // n, n * c * h * w)
+    nhwc = x.dim() == 4 and c > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+    rows = (x.permute(0, 2, 3, 1) if nhwc else x).reshape(1, 1, tn // n, n * c * h * w)
     if up > 1:
         y = upfirdn2d.upsample2d(rows, taps.unsqueeze(1), up=(1, up))
     else:
         y = upfirdn2d.downsample2d(rows, taps.unsqueeze(1), down=(1, down))
+    if nhwc:
+        return y.reshape(y.size(2) * n, h, w, c).permute(0, 3, 1, 2)
     return y.reshape(y.size(2) * n, c, h, w)
 
 
@@ -403,22 +510,14 @@ class Synthesis3dResBlock(nn.Module):
         style_1 = self.affine_1(lat).reshape(t, n, -1)
         gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
         h = modulated_conv_frames(h, self.weight_1, style_1, gain_1, self.padding, True, dtype)
-        skip = F.conv2d(x, (self.weight_skip[:, :, 0] * self.weight_skip_gain).to(dtype))
+        skip = F.conv2d(x, _cl((self.weight_skip[:, :, 0] * self.weight_skip_gain).to(dtype)))
         h = (skip + h) * SQRT_HALF
         if self.temporal_up:
             h = resample_time_frames(h, self.temporal_upsample.filter, n, up=self.temporal_upsample.scale)
-        if out_seq_length is not None:
-            t_now = h.shape[0] // n
-            t0 = (t_now - out_seq_length) // 2
-            h = h[t0 * n:(t0 + out_seq_length) * n]
+        h = crop_frames(h, n, seq_length=out_seq_length)
         if self.spatial_up:
             h = upfirdn2d.upsample2d(h, self.spatial_upsample.filter, up=self.spatial_upsample.scale)
-        if self.out_width is not None:
-            x0 = (h.size(3) - self.out_width) // 2
-            h = h[:, :, :, x0:x0 + self.out_width]
-        if self.out_height is not None:
-            y0 = (h.size(2) - self.out_height) // 2
-            h = h[:, :, y0:y0 + self.out_height]
+        h = crop_frames(h, n, height=self.out_height, width=self.out_width)
         return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
 
 
@@ -543,7 +642,7 @@ class VideoGenerator(nn.Module):
         n = temporal_input.shape[0]
         # time-major frames: [(T N), C, H, W]
         x = (temporal_input.permute(2, 0, 1)[:, :, :, None, None] + self.spatial_input[0, :, 0]) * SQRT_HALF
-        x = x.reshape(in_len * n, 512, x.shape[3], x.shape[4])
+        x = _cl(x.reshape(in_len * n, 512, x.shape[3], x.shape[4]))
         feats = []
         wi = 0
         for layer, length in zip(self.temporal_layers, lengths):
@@ -763,7 +862,7 @@ class VideoDiscriminator(nn.Module):
         px = (self.max_edge - videos.size(4)) // 2
         py = (self.max_edge - videos.size(3)) // 2
         n = videos.shape[0]
-        f = frames_from_video(F.pad(videos, (px, px, py, py)))
+        f = _cl(frames_from_video(F.pad(videos, (px, px, py, py))))
         for block in self.blocks:
             f = block.forward_frames(f, n, dtype=dtype)
         f = video_from_frames(f, n)

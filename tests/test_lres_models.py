@@ -95,3 +95,40 @@ def test_bf16_forward_close_to_fp32_gpu():
         video = G.synthesize_video(G._temporal_input(ws), ws, T, dtype=torch.bfloat16)
     err = np.abs(video.cpu().numpy() - g['video'])
     assert err.max() < 6e-2 and err.mean() < 6e-3, (float(err.max()), float(err.mean()))
+
+
+def test_temporal_conv_frames_matches_conv3d_to_second_order():
+    """The time-major decomposition (kt 2-D convs + hand-written backward) equals conv3d with zero
+    padding, including the double backward that the R1 penalty needs."""
+    import lvg.models.lres as lres
+    torch.manual_seed(3)
+    for kt, n, t in ((3, 2, 5), (5, 1, 4), (1, 2, 3), (5, 2, 2)):
+        x5 = torch.randn(n, 4, t, 6, 7, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(5, 4, kt, 3, 3, dtype=torch.float64, requires_grad=True)
+        ref = F.conv3d(x5, w, padding=(kt // 2, 1, 1))
+        xf = lres.frames_from_video(x5)
+        got = lres.video_from_frames(lres.temporal_conv_frames(lres._cl(xf), w, n, (1, 1)), n)
+        torch.testing.assert_close(got, ref, rtol=1e-10, atol=1e-10)
+        probe = torch.randn_like(ref)
+        for out in (ref, got):
+            out.backward(probe, retain_graph=True)
+        gx_ref, gw_ref = torch.autograd.grad(ref, [x5, w], probe, create_graph=True)
+        gx_got, gw_got = torch.autograd.grad(got, [x5, w], probe, create_graph=True)
+        torch.testing.assert_close(gx_got, gx_ref, rtol=1e-9, atol=1e-9)
+        torch.testing.assert_close(gw_got, gw_ref, rtol=1e-9, atol=1e-9)
+        # R1-style: d/dw of |d out / d x|^2
+        (pen_ref,) = torch.autograd.grad(gx_ref.square().sum(), w)
+        (pen_got,) = torch.autograd.grad(gx_got.square().sum(), w)
+        torch.testing.assert_close(pen_got, pen_ref, rtol=1e-8, atol=1e-8)
+
+
+def test_crop_frames_backward_keeps_memory_format():
+    import lvg.models.lres as lres
+    x = torch.randn(6, 8, 5, 7, requires_grad=True)
+    xc = x.contiguous(memory_format=torch.channels_last)
+    y = lres.crop_frames(xc, n=2, seq_length=1, height=3, width=4)
+    assert y.shape == (2, 8, 3, 4) and y.is_contiguous(memory_format=torch.channels_last)
+    (g,) = torch.autograd.grad(y.sum(), x)
+    ref = torch.zeros(6, 8, 5, 7)
+    ref[2:4, :, 1:4, 1:5] = 1
+    assert torch.equal(g, ref)

@@ -126,3 +126,25 @@ def test_round_trip_and_linearity_at_full_size():
     lhs = (y.detach() * w).sum().double()
     rhs = (xr.detach() * gx).sum().double()
     assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_channels_last_kernel_vs_oracle(dtype, oracle):
+    """NHWC kernel (frames-layout networks keep activations channels-last)."""
+    rs = np.random.RandomState(9)
+    bil = [0.125, 0.375, 0.375, 0.125]
+    ft = torch.tensor(bil, device=DEV)
+    for shape, kind in (([6, 64, 9, 16], 'up'), ([6, 64, 18, 32], 'down'), ([3, 16, 5, 8], 'up'), ([3, 24, 8, 8], 'down'), ([2, 8, 7, 5], 'blur')):
+        x = dev(rs.randn(*shape), dtype).contiguous(memory_format=torch.channels_last)
+        if kind == 'up':
+            y, ref = upfirdn2d.upsample2d(x, ft, up=2), oracle.upsample2d(host(x), bil, up=2)
+        elif kind == 'down':
+            y, ref = upfirdn2d.downsample2d(x, ft, down=2), oracle.downsample2d(host(x), bil, down=2)
+        else:
+            y, ref = upfirdn2d.filter2d(x, ft), oracle.upfirdn2d(host(x), bil, padding=[2, 1, 2, 1])
+        assert y.is_contiguous(memory_format=torch.channels_last) and tuple(y.shape) == ref.shape
+        np.testing.assert_allclose(host(y), ref, err_msg=f'{shape} {kind}', **TOL[dtype])
+        # cropped view (the networks crop H/W before bias_act) keeps the NHWC path
+        xc = x[:, :, 1:, :-1]
+        yc = upfirdn2d.upsample2d(xc, ft, up=2)
+        np.testing.assert_allclose(host(yc), oracle.upsample2d(host(xc), bil, up=2), **TOL[dtype])
