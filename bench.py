@@ -265,8 +265,17 @@ def _pmc_traffic(kernel):
 
 
 def _cpu_baseline(forward_only):
-    from oracle import cpu_step
-    return cpu_step.run(forward_only=forward_only)
+    """CPU leg in a child process with a hard wall-clock limit, so a slow or oversubscribed host can
+    never stretch the default run (the sample itself is bounded to ~20 s of CPU work)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_step.py')] + (['--forward-only'] if forward_only else [])
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as err:  # pylint: disable=broad-except
+        return {'value': None, 'unit': 'frames/s', 'cores': None, 'kind': 'port',
+                'sample': f'not measured: {type(err).__name__} (limit 150 s)'}
 
 
 if __name__ == '__main__':
