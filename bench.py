@@ -132,8 +132,10 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('LVG_FORCE_DIST'):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', init_method='env://')   # "nccl" = RCCL on ROCm
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -148,26 +150,35 @@ def main():
     D = VideoDiscriminator(seq_length=args.frames, max_edge=64).to(dev).requires_grad_(False).train()
     ddp.broadcast_module(G)
     ddp.broadcast_module(D)
-    opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0.0, 0.99), capturable=(args.graph != 'off'))
-    sync = ddp.FlatGradSync(G.parameters(), overlap=world > 1)
+    opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0.0, 0.99))
+    # Gradient exchange: ONE flat buffer (the .grad tensors are views into it), all-reduced after the
+    # backward pass in 128 MB buckets. The compute part of the step is replayed from a hipGraph; the RCCL
+    # collective and the optimizer stay outside the graph (an RCCL all-reduce inside a captured graph aborts
+    # on this stack), which costs ~2-3 ms of non-overlapped all-reduce per step at N>1.
+    sync = ddp.FlatGradSync(G.parameters(), overlap=False)
     torch.manual_seed(1 + rank)                # per-rank noise stream (train_lres.py:69)
     B, T = args.batch_per_gpu, args.frames
 
     timer = OpTimer()
     timer.install()
 
-    def step():
+    def compute():
         if args.forward_only:
             with torch.no_grad():
                 return G(B, T, dtype=dtype)
         sync.zero()
-        if sync.overlap:
-            sync.arm()
         video = G(B, T, dtype=dtype)
         logits = D(video, dtype=dtype)
         F.softplus(-logits).mean().backward()
-        sync.finish()
-        opt.step()
+
+    def update():
+        if not args.forward_only:
+            sync.finish()          # all-reduce (mean) over ranks, nan_to_num -- no-op collective at N=1
+            opt.step()
+
+    def step():
+        compute()
+        update()
 
     def barrier():
         if world > 1:
@@ -190,8 +201,9 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                step()
+                compute()
             graph.replay()
+            update()
             torch.cuda.synchronize()
         except Exception as err:  # pylint: disable=broad-except
             if args.graph == 'on':
@@ -205,6 +217,7 @@ def main():
     for _ in range(args.steps):
         if graph is not None:
             graph.replay()
+            update()
         else:
             step()
     barrier()
@@ -250,7 +263,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = _cpu_baseline(forward_only=args.forward_only)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

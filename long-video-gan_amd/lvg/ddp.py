@@ -101,7 +101,7 @@ class FlatGradSync:
         return hook
 
     def _launch(self, b: int) -> None:
-        if _world() > 1:
+        if dist.is_available() and dist.is_initialized():
             s, e, _ = self.buckets[b]
             self._work.append(dist.all_reduce(self.flat[s:e], async_op=True))
 
