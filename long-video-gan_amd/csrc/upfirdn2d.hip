@@ -1093,6 +1093,125 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(UpfirdnArgs p)
     IO::store(yp, acc, p.gain);
 }
 
+// Streaming NHWC x2 kernels: a lane owns one channel vector of one OUTPUT COLUMN and walks down the rows
+// of a frame with the sliding window of the wave kernels; the row (x) taps are plain neighbouring-pixel
+// loads (+-C elements: coalesced, L1-resident). Per input row a lane issues 4 (down) / 2 (up) vector loads
+// instead of the 16 / 4 per output pixel of the gather form above.
+
+template <class T, int VB, bool UP2>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_stream_kernel(UpfirdnArgs p)
+{
+    typedef VecIO<T, VB> IO;
+    constexpr int V = IO::V;
+    const int cvecs = p.c / V;
+    const int chunks = p.rowChunks;
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)p.n * chunks * p.ow * cvecs;
+    if (t >= total) return;
+    const int cv = (int)(t % cvecs); t /= cvecs;
+    const int ox = (int)(t % p.ow); t /= p.ow;
+    const int chunk = (int)(t % chunks);
+    const int nb = (int)(t / chunks);
+    const int oyBeg = chunk * p.chunkRows;
+    const int oyEnd = (oyBeg + p.chunkRows < p.oh) ? oyBeg + p.chunkRows : p.oh;
+
+    float fx[4], fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)cv * V;
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ox * p.ys[3] + (int64_t)cv * V;
+    const int64_t xs2 = p.xs[2], xs3 = p.xs[3], ys2 = p.ys[2];
+    const float g = p.gain;
+
+    if (!UP2)
+    {
+        // row-filtered value of input row iy at this output column: sum_k in[iy][2 ox - padx0 + k] * fx[k]
+        const int ix0 = 2 * ox - p.padx0;
+        auto hrow = [&](int iy, float (&h)[V]) {
+            #pragma unroll
+            for (int i = 0; i < V; i++) h[i] = 0.0f;
+            const bool rowOk = iy >= 0 && iy < p.ih;
+            #pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int ix = ix0 + k;
+                float v[V];
+                IO::load(xp + (int64_t)iy * xs2 + (int64_t)ix * xs3, rowOk && ix >= 0 && ix < p.iw, v);
+                #pragma unroll
+                for (int i = 0; i < V; i++) h[i] = fmaf(v[i], fx[k], h[i]);
+            }
+        };
+        constexpr int kRows = (V >= 8) ? 2 : 4;      // input rows per batch (register budget: (kRows+2) x V floats)
+        float w[kRows + 2][V];
+        hrow(2 * oyBeg - p.pady0, w[0]);
+        hrow(2 * oyBeg - p.pady0 + 1, w[1]);
+        for (int oy0 = oyBeg; oy0 < oyEnd; oy0 += kRows / 2)
+        {
+            const int rbase = 2 * oy0 - p.pady0 + 2;
+            #pragma unroll
+            for (int r = 0; r < kRows; r++) hrow(rbase + r, w[r + 2]);
+            #pragma unroll
+            for (int j = 0; j < kRows / 2; j++)
+            {
+                const int oy = oy0 + j;
+                if (oy < oyEnd)
+                {
+                    float acc[V];
+                    #pragma unroll
+                    for (int i = 0; i < V; i++)
+                    {
+                        float a = 0.0f;
+                        #pragma unroll
+                        for (int k = 0; k < 4; k++) a = fmaf(w[2 * j + k][i], fy[k], a);
+                        acc[i] = a;
+                    }
+                    IO::store(yp + (int64_t)oy * ys2, acc, g);
+                }
+            }
+            #pragma unroll
+            for (int i = 0; i < V; i++) { w[0][i] = w[kRows][i]; w[1][i] = w[kRows + 1][i]; }
+        }
+    }
+    else
+    {
+        const int mX = ox + 1 - p.padx0;
+        const int i0 = lvg_floor_div(mX, 2);
+        const int phX = mX - 2 * i0;
+        const float tA = phX ? fx[0] : fx[1], tB = phX ? fx[2] : fx[3];
+        auto hrow = [&](int iy, float (&h)[V]) {
+            const bool rowOk = iy >= 0 && iy < p.ih;
+            float a[V], b[V];
+            IO::load(xp + (int64_t)iy * xs2 + (int64_t)i0 * xs3, rowOk && i0 >= 0 && i0 < p.iw, a);
+            IO::load(xp + (int64_t)iy * xs2 + (int64_t)(i0 + 1) * xs3, rowOk && i0 + 1 >= 0 && i0 + 1 < p.iw, b);
+            #pragma unroll
+            for (int i = 0; i < V; i++) h[i] = fmaf(a[i], tA, b[i] * tB);
+        };
+        const int jMin = lvg_floor_div(oyBeg + 1 - p.pady0, 2);
+        const int jMax = lvg_floor_div(oyEnd - p.pady0, 2);
+        float hPrev[V], hCur[V];
+        hrow(jMin, hPrev);
+        for (int j = jMin; j <= jMax; j++)
+        {
+            hrow(j + 1, hCur);
+            const int oyA = 2 * j - 1 + p.pady0;
+            float oa[V], ob[V];
+            #pragma unroll
+            for (int i = 0; i < V; i++)
+            {
+                oa[i] = fmaf(hPrev[i], fy[1], hCur[i] * fy[3]);
+                ob[i] = fmaf(hPrev[i], fy[0], hCur[i] * fy[2]);
+                hPrev[i] = hCur[i];
+            }
+            if (oyA >= oyBeg && oyA < oyEnd) IO::store(yp + (int64_t)oyA * ys2, oa, g);
+            if (oyA + 1 >= oyBeg && oyA + 1 < oyEnd) IO::store(yp + (int64_t)(oyA + 1) * ys2, ob, g);
+        }
+    }
+}
+
 template <class T, int VB>
 int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
 {
@@ -1103,6 +1222,22 @@ int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
     const dim3 grid((unsigned)blocks), block(256);
     #define LVG_NHWC_CASE(ux, uy, dx, dy) if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy) { \
         hipLaunchKernelGGL((upfirdn2d_nhwc_kernel<T, ux, uy, dx, dy, VB>), grid, block, 0, stream, p); return lvg_check_launch("upfirdn2d_nhwc_kernel"); }
+    const bool up2 = p.upx == 2 && p.upy == 2 && p.downx == 1 && p.downy == 1;
+    const bool down2 = p.upx == 1 && p.upy == 1 && p.downx == 2 && p.downy == 2;
+    if (up2 || down2)
+    {
+        // streaming form: enough lanes even for short frames thanks to row chunks of 16 output rows
+        p.chunkRows = 16;
+        p.rowChunks = (p.oh + p.chunkRows - 1) / p.chunkRows;
+        const int64_t threads = (int64_t)p.n * p.rowChunks * p.ow * (p.c / V);
+        const int64_t nb = (threads + 255) / 256;
+        if (nb <= 0x7fffffffLL)
+        {
+            if (up2) hipLaunchKernelGGL((upfirdn2d_nhwc_stream_kernel<T, VB, true>), dim3((unsigned)nb), block, 0, stream, p);
+            else     hipLaunchKernelGGL((upfirdn2d_nhwc_stream_kernel<T, VB, false>), dim3((unsigned)nb), block, 0, stream, p);
+            return lvg_check_launch("upfirdn2d_nhwc_stream_kernel");
+        }
+    }
     LVG_NHWC_CASE(2, 2, 1, 1)
     LVG_NHWC_CASE(1, 1, 2, 2)
     LVG_NHWC_CASE(1, 1, 1, 1)

@@ -342,7 +342,7 @@ def resample_time_frames(x: torch.Tensor, taps: torch.Tensor, n: int, up: int = 
 
 
 def modulated_conv_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, input_gain: Optional[torch.Tensor],
-                          padding, demodulate: bool, compute_dtype: torch.dtype) -> torch.Tensor:
+                          padding, demodulate: bool, compute_dtype: torch.dtype, return_demod: bool = False):
     """`modulated_conv3d` in time-major frames layout. x [(T N), Ci, H, W]; style [T, N, Ci] float32."""
     t, n, ci = style.shape
     if demodulate:
@@ -355,6 +355,8 @@ def modulated_conv_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Te
     if demodulate:
         w2 = weight.square().sum(dim=(2, 3, 4))                               # [Co, Ci]
         demod = torch.matmul(style.square(), w2.t()).add(1e-8).rsqrt()        # [T, N, Co]
+        if return_demod:
+            return y, demod.reshape(t * n, -1, 1, 1)                          # caller fuses the multiply
         y = y * demod.reshape(t * n, -1, 1, 1).to(y.dtype)
     return y
 
@@ -495,7 +497,12 @@ class Synthesis3dResBlock(nn.Module):
 
     def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
                        out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """Same layer in time-major frames layout: x [(T N), C, H, W], latent [N, L, T]."""
+        """Same layer in time-major frames layout: x [(T N), C, H, W], latent [N, L, T].
+
+        Elementwise passes over the activations are the HBM-bound part of the block, so scalars are folded
+        into small tensors instead of being applied to the activations: the input-magnitude gain goes into
+        the style of conv 0 and into the skip weights (convolution is linear), sqrt(1/2) into the skip
+        weights and the demodulation of conv 1, and (skip + conv1 * demod) is one addcmul."""
         if dtype is None:
             dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
         n, c, t = latent.shape
@@ -503,15 +510,16 @@ class Synthesis3dResBlock(nn.Module):
         x = x.to(dtype)
         style_0 = self.affine_0(lat).reshape(t, n, -1)
         gain_0 = self.input_magnitude_ema_0(x, magnitude_ema_beta) if self.magnitude_ema else None
-        if gain_0 is not None:
-            x = x * gain_0.to(dtype)
-        h = modulated_conv_frames(x, self.weight_0, style_0, None, self.padding, True, dtype)
+        h = modulated_conv_frames(x, self.weight_0, style_0, gain_0, self.padding, True, dtype)
         h = bias_act.bias_act(h, self.bias_0.to(dtype), act=self.activation, clamp=self.activation_clamp)
         style_1 = self.affine_1(lat).reshape(t, n, -1)
         gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
-        h = modulated_conv_frames(h, self.weight_1, style_1, gain_1, self.padding, True, dtype)
-        skip = F.conv2d(x, _cl((self.weight_skip[:, :, 0] * self.weight_skip_gain).to(dtype)))
-        h = (skip + h) * SQRT_HALF
+        y1, demod_1 = modulated_conv_frames(h, self.weight_1, style_1, gain_1, self.padding, True, dtype, return_demod=True)
+        w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
+        if gain_0 is not None:
+            w_skip = w_skip * gain_0
+        skip = F.conv2d(x, _cl(w_skip.to(dtype)))
+        h = torch.addcmul(skip, y1, (demod_1 * SQRT_HALF).to(dtype))
         if self.temporal_up:
             h = resample_time_frames(h, self.temporal_upsample.filter, n, up=self.temporal_upsample.scale)
         h = crop_frames(h, n, seq_length=out_seq_length)

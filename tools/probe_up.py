@@ -23,3 +23,12 @@ for dtype in (torch.bfloat16, torch.float32):
         td = gtime(lambda: upfirdn2d.downsample2d(xd, f))
         nb = (x.numel() * 5) * x.element_size()
         print(f'{dtype} {shp}: up2 {tu:7.1f} us {nb/tu/1e3:7.1f} GB/s | down2 {td:7.1f} us {nb/td/1e3:7.1f} GB/s')
+print('--- channels_last ---')
+for dtype in (torch.bfloat16, torch.float32):
+    for shp in ([1024, 64, 18, 32], [1024, 64, 32, 32], [512, 128, 9, 16]):
+        x = torch.randn(*shp, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        tu = gtime(lambda: upfirdn2d.upsample2d(x, f))
+        xd = torch.randn(shp[0], shp[1], shp[2] * 2, shp[3] * 2, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        td = gtime(lambda: upfirdn2d.downsample2d(xd, f))
+        nb = (x.numel() * 5) * x.element_size()
+        print(f'NHWC {dtype} {shp}: up2 {tu:7.1f} us {nb/tu/1e3:7.1f} GB/s | down2 {td:7.1f} us {nb/td/1e3:7.1f} GB/s')
