@@ -111,10 +111,19 @@ def _taps_1d(f, scale_is_one):
         return (f.contiguous(), f.shape[0])
     return None  # dense 2-D filter: generic path
 
+FORCE_GENERIC = False  # test hook: route every call through upfirdn2d -> act -> upfirdn2d
+
+def _fused_supported(fu, fd, up, down, dtype):
+    """True when `lvg_filtered_lrelu` has a fused kernel for this filter pair / factors / dtype."""
+    tu, td = _taps_1d(fu, up == 1), _taps_1d(fd, down == 1)
+    if tu is None or td is None or dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        return False
+    return bool(_hip.lib().lvg_filtered_lrelu_supported(tu[1], td[1], up, down, _hip.dtype_code(dtype)))
+
 def _fused(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filter, write_signs):
     """Try the fused kernel. Returns (y, so, return_code); return_code < 0 = no kernel."""
     tu, td = _taps_1d(fu, up == 1), _taps_1d(fd, down == 1)
-    if tu is None or td is None or x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+    if FORCE_GENERIC or tu is None or td is None or x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         return None, None, -1
     lib = _hip.lib()
     (fu_t, fu_n), (fd_t, fd_n) = tu, td
