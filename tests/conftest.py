@@ -13,6 +13,13 @@ for p in (PKG, ROOT):
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# MIOpen find-db + compiled-kernel cache recorded on MI355X for the shapes the models use (a cold
+# find on a fresh box costs minutes per network); same wiring as bench.py.
+_MIOPEN_DB = os.path.join(PKG, 'miopen_db')
+if os.path.isdir(_MIOPEN_DB) and os.access(_MIOPEN_DB, os.W_OK):
+    os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(_MIOPEN_DB, 'db'))
+    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(_MIOPEN_DB, 'cache'))
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu through gpurun)')
