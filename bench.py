@@ -57,7 +57,7 @@ class OpTimer:
         self.enabled = False
 
     def install(self):
-        from torch_utils.ops import bias_act, upfirdn2d
+        from torch_utils.ops import bias_act, modconv_epilogue, upfirdn2d
 
         def wrap(mod, name, op, bytes_fn):
             orig = getattr(mod, name)
@@ -76,6 +76,9 @@ class OpTimer:
         wrap(bias_act, '_launch', lambda a: 'bias_act_fwd' if a[5] == 0 else 'bias_act_bwd', ba_bytes)
         # upfirdn2d._launch(x, f, ...): (N_in + N_out) * s
         wrap(upfirdn2d, '_launch', lambda a: 'upfirdn2d', lambda args, out: (args[0].numel() + out.numel()) * out.element_size())
+        # modconv_epilogue: forward y -> out (2 streams), backward dout, y -> dy (3 streams)
+        wrap(modconv_epilogue, '_launch_fwd', lambda a: 'modconv_epilogue_fwd', lambda args, out: 2 * args[0].numel() * args[0].element_size())
+        wrap(modconv_epilogue, '_launch_bwd', lambda a: 'modconv_epilogue_bwd', lambda args, out: 3 * args[0].numel() * args[0].element_size())
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step
@@ -162,6 +165,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from lvg import ddp
+    from lvg.models import lres
     from lvg.models.lres import VideoDiscriminator, VideoGenerator
 
     dtype = dict(bf16=torch.bfloat16, fp32=torch.float32, fp16=torch.float16)[args.dtype]
@@ -183,17 +187,27 @@ def main():
     timer = OpTimer()
     timer.install()
 
+    # The generator pass of a training step tracks the input magnitude of every modulated layer
+    # (magnitude_ema_beta = 0.999, video_gan_lres.py:43,143). Across ranks the 19 per-layer statistics are
+    # exchanged in ONE all-reduce after the pass instead of 19 inside it (lres.MagnitudeEMA).
+    ema_beta = 0.999
+    pending_emas = []
+
     def compute():
         if args.forward_only:
             with torch.no_grad():
                 return G(B, T, dtype=dtype)
         sync.zero()
-        video = G(B, T, dtype=dtype)
+        with lres.deferred_magnitude_sync() as pending:
+            video = G(B, T, magnitude_ema_beta=ema_beta, dtype=dtype)
         logits = D(video, dtype=dtype)
         F.softplus(-logits).mean().backward()
+        pending_emas[:] = [pending, lres.stack_pending(pending) if pending else None]
 
     def update():
         if not args.forward_only:
+            if pending_emas and pending_emas[0]:
+                lres.finish_magnitude_sync(*pending_emas)
             sync.finish()          # all-reduce (mean) over ranks, nan_to_num -- no-op collective at N=1
             opt.step()
 
@@ -284,7 +298,7 @@ def main():
             'value': round(frames / elapsed, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic', 'launch_mode': 'hipgraph' if graph is not None else 'eager',
-            'config': {'workload': f'generator_lres {T}-frame 36x64 {args.dtype} ' + ('forward' if args.forward_only else 'forward+backward through discriminator_lres, Adam step') + f', batch {B}/GPU',
+            'config': {'workload': f'generator_lres {T}-frame 36x64 {args.dtype} ' + ('forward' if args.forward_only else 'forward+backward through discriminator_lres (magnitude EMA tracking on), Adam step') + f', batch {B}/GPU',
                        'global_batch': world * B, 'frames_per_clip': T, 'parallelism': f'dp{world}', 'params_G': 83215939},
             'roofline': roofline,
             'ops': {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1)) for k, v in ops.items()},

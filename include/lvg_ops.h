@@ -9,6 +9,8 @@
  *   lvg_upfirdn2d           <- upfirdn2d()           torch_utils/ops/upfirdn2d.cpp:16
  *   lvg_filtered_lrelu      <- filtered_lrelu()      torch_utils/ops/filtered_lrelu.cpp:16
  *   lvg_filtered_lrelu_act  <- filtered_lrelu_act_() torch_utils/ops/filtered_lrelu.cpp:213
+ *   lvg_modconv_epilogue[_backward]  (no pybind counterpart: fuses the modulated-conv epilogue the
+ *                           reference spells in Python, model/generator_lres.py:101-123,570-574)
  *
  * Contract (differs from the pybind ABI on purpose):
  *   - plain pointers and sizes only; the caller owns every buffer (outputs are
@@ -119,6 +121,34 @@ int lvg_filtered_lrelu_act(void* x, uint8_t* s, const int64_t xshape[4], const i
                            const int64_t sshape[2], int sofs_x, int sofs_y,
                            float gain, float slope, float clamp, int sign_mode,
                            int dtype, void* stream);
+
+/*
+ * Epilogue of a style-modulated convolution fused with the prologue of the next one, one pass:
+ *   out[f,c,p] = clamp(act(y[f,c,p] * pre[f,c] + b[c]) * gain, +-clamp) * post[f,c]
+ *   msq[f]    += sum_{c,p} (value before `post`)^2        (optional input-magnitude statistic)
+ * y/out: dense [frames, channels, pixels] (channels_last = 0) or [frames, pixels, channels]
+ * (channels_last = 1) in `dtype` (f32/f16/bf16); pre/post: float32 [frames, channels] or NULL (= 1);
+ * b: [channels] in `dtype` or NULL; msq: float32 [frames], zero-initialised by the caller, or NULL.
+ * act: LVG_ACT_LINEAR / RELU / LRELU (others: LVG_ERR_UNSUPPORTED). clamp < 0 disables clamping.
+ * Replaces the reference's Python-level sequence  output * demodulation  (model/generator_lres.py:122),
+ * bias_act (:570, torch_utils/ops/bias_act.cpp:32), input * style (:101) and the magnitude
+ * statistic (:574) -- there is no single reference entry point; the binding is this library's own.
+ */
+int lvg_modconv_epilogue(const void* y, const float* pre, const void* b, const float* post, void* out, float* msq,
+                         int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
+                         float alpha, float gain, float clamp, void* stream);
+
+/*
+ * Backward of lvg_modconv_epilogue with the activation recomputed from y:
+ *   du = dout * post * [|g| < clamp] * gain * act'(y*pre + b);   dy = du * pre
+ *   d_pre[f,c] = sum_p du * y;  d_post[f,c] = sum_p dout * g;  d_sum[f,c] = sum_p du  (db = sum_f d_sum)
+ * d_pre / d_post / d_sum: float32 [frames, channels], zero-initialised by the caller (d_pre / d_post
+ * may be NULL when pre / post are).
+ */
+int lvg_modconv_epilogue_backward(const void* dout, const void* y, const float* pre, const void* b, const float* post,
+                                  void* dy, float* d_pre, float* d_post, float* d_sum,
+                                  int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
+                                  float alpha, float gain, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,404 @@
+// modconv_epilogue.hip -- epilogue of a style-modulated convolution fused with the prologue of the
+// next one, as ONE HBM-streaming pass over the activations (gfx950):
+//
+//     out[f,c,p] = clamp( act( y[f,c,p] * pre[f,c] + b[c] ) * gain, +-clamp ) * post[f,c]
+//     msq[f]    += sum_{c,p} clamp(...)^2                   (optional; the input-magnitude statistic)
+//
+// f = frame (sample x time), c = channel, p = pixel. `pre` is the demodulation coefficient of the
+// convolution that produced y, `post` the style modulation of the convolution that consumes out.
+// The reference spells this as three elementwise passes and a reduction (model/generator_lres.py:
+// 122-123 `output * demodulation`, :570 bias_act, :101-103 `input * style`, :574 magnitude EMA) --
+// 7 tensor streams where this kernel moves 2.
+//
+// The backward kernel recomputes the activation from y and returns, next to dy, the three
+// per-(frame, channel) reductions the small tensors need:
+//     d_pre[f,c] = sum_p du*y     d_post[f,c] = sum_p dout*clamped     d_sum[f,c] = sum_p du   (db = sum_f d_sum)
+// with du = dout * post * [|g| < clamp] * gain * act'(u) and dy = du * pre.
+//
+// Two kernel families:
+//   * channels-last ([f][p][c] in memory, c % vector == 0, c/vector a power of two <= 256): 16-byte
+//     lanes; every thread keeps ONE channel-vector for its whole loop, so pre/post/b live in registers
+//     and the (f,c) reductions are a block-level LDS transpose plus one atomic per channel;
+//   * strided planes (any layout, e.g. NCHW or 3-channel RGB): one wavefront per (f,c) plane.
+//
+// Roofline: pure stream. Algorithmic bytes per element: forward 2*s, backward 3*s (s = sizeof(T)).
+
+#include "lvg_common.h"
+
+namespace {
+
+struct EpilogueArgs
+{
+    const void*  y;
+    const float* pre;      // [frames, channels] or NULL (= 1)
+    const void*  b;        // [channels] in T or NULL (= 0)
+    const float* post;     // [frames, channels] or NULL (= 1)
+    void*        out;
+    float*       msq;      // forward: [frames] floats, atomically accumulated (zeroed by the caller); or NULL
+    const void*  dout;     // backward only
+    void*        dy;
+    float*       d_pre;    // [frames, channels], zero-initialised by the caller
+    float*       d_post;
+    float*       d_sum;
+    int64_t      frames;
+    int          channels;
+    int          pixels;
+    int64_t      strideF;  // element strides (plane kernels)
+    int64_t      strideC;
+    int64_t      strideP;
+    int64_t      frameVecs;  // channels-last kernels: 16-byte vectors per frame
+    int          chunkVecs;  //                       vectors per block
+    float        alpha, gain, clamp;
+};
+
+constexpr int kThreads = 256;
+
+template <int ACT> __device__ __forceinline__ float act_fwd(float u, float alpha)
+{
+    if (ACT == LVG_ACT_RELU)  return u > 0.f ? u : 0.f;
+    if (ACT == LVG_ACT_LRELU) return u > 0.f ? u : u * alpha;
+    return u;
+}
+template <int ACT> __device__ __forceinline__ float act_slope(float u, float alpha)
+{
+    if (ACT == LVG_ACT_RELU)  return u > 0.f ? 1.f : 0.f;
+    if (ACT == LVG_ACT_LRELU) return u > 0.f ? 1.f : alpha;
+    return 1.f;
+}
+
+// Forward value before `post`, and whether the clamp was hit.
+template <int ACT> __device__ __forceinline__ float epi_value(float y, float pre, float b, float alpha, float gain, float clamp, bool& inside)
+{
+    float g = act_fwd<ACT>(fmaf(y, pre, b), alpha) * gain;
+    inside = true;
+    if (clamp >= 0.f)
+    {
+        inside = (g > -clamp && g < clamp);
+        if (!inside) g = (g >= 0.f) ? clamp : -clamp;
+    }
+    return g;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channels-last kernels. grid = (chunks per frame, frames).
+
+template <class T> struct ChanVec
+{
+    static constexpr int V = Elem<T>::kVec;
+    float pre[V], post[V], b[V];
+};
+
+template <class T> __device__ __forceinline__ void load_chan(const EpilogueArgs& p, int64_t f, int c0, ChanVec<T>& k)
+{
+    constexpr int V = Elem<T>::kVec;
+    const int64_t fc = f * p.channels + c0;
+    #pragma unroll
+    for (int i = 0; i < V; i++)
+    {
+        k.pre[i]  = p.pre  ? p.pre[fc + i]  : 1.f;
+        k.post[i] = p.post ? p.post[fc + i] : 1.f;
+        k.b[i]    = p.b    ? to_acc(static_cast<const T*>(p.b)[c0 + i]) : 0.f;
+    }
+}
+
+template <class T, int ACT>
+__global__ __launch_bounds__(kThreads) void epilogue_cl_fwd_kernel(EpilogueArgs p)
+{
+    constexpr int V = Elem<T>::kVec;
+    const int     cv = p.channels / V;                       // power of two, divides kThreads
+    const int64_t f  = blockIdx.y;
+    const T* y   = static_cast<const T*>(p.y)   + f * p.frameVecs * V;
+    T*       out = static_cast<T*>(p.out)       + f * p.frameVecs * V;
+    ChanVec<T> k;
+    load_chan<T>(p, f, (threadIdx.x & (cv - 1)) * V, k);
+
+    const int64_t first = (int64_t)blockIdx.x * p.chunkVecs;
+    const int64_t last  = min(first + p.chunkVecs, p.frameVecs);
+    float sq = 0.f;
+    auto one = [&](const Vec16<T>& in, int64_t i)
+    {
+        Vec16<T> o;
+        #pragma unroll
+        for (int e = 0; e < V; e++)
+        {
+            bool inside;
+            float g = epi_value<ACT>(to_acc(in.v[e]), k.pre[e], k.b[e], p.alpha, p.gain, p.clamp, inside);
+            sq = fmaf(g, g, sq);
+            o.v[e] = from_acc<T>(g * k.post[e]);
+        }
+        store_vec16<T>(out + i * V, o);
+    };
+    // U independent 16-byte loads are issued before any of them is consumed (a per-iteration bounds
+    // check would serialise them: one load in flight per lane measured 3.2 TB/s).
+    constexpr int U = 4;
+    int64_t i = first + threadIdx.x;
+    for (; i + (U - 1) * kThreads < last; i += U * kThreads)
+    {
+        Vec16<T> in[U];
+        #pragma unroll
+        for (int u = 0; u < U; u++) in[u] = load_vec16<T>(y + (i + u * kThreads) * V);
+        #pragma unroll
+        for (int u = 0; u < U; u++) one(in[u], i + u * kThreads);
+    }
+    for (; i < last; i += kThreads) one(load_vec16<T>(y + i * V), i);
+    if (p.msq)
+    {
+        __shared__ float part[kThreads / 64];
+        sq = wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.msq + f, part[0] + part[1] + part[2] + part[3]);
+    }
+}
+
+template <class T, int ACT>
+__global__ __launch_bounds__(kThreads) void epilogue_cl_bwd_kernel(EpilogueArgs p)
+{
+    constexpr int V = Elem<T>::kVec;
+    const int     cv = p.channels / V;
+    const int64_t f  = blockIdx.y;
+    const T* y    = static_cast<const T*>(p.y)    + f * p.frameVecs * V;
+    const T* dout = static_cast<const T*>(p.dout) + f * p.frameVecs * V;
+    T*       dy   = static_cast<T*>(p.dy)         + f * p.frameVecs * V;
+    ChanVec<T> k;
+    load_chan<T>(p, f, (threadIdx.x & (cv - 1)) * V, k);
+
+    float aPre[V], aPost[V], aSum[V];
+    #pragma unroll
+    for (int e = 0; e < V; e++) { aPre[e] = 0.f; aPost[e] = 0.f; aSum[e] = 0.f; }
+
+    const int64_t first = (int64_t)blockIdx.x * p.chunkVecs;
+    const int64_t last  = min(first + p.chunkVecs, p.frameVecs);
+    auto one = [&](const Vec16<T>& in, const Vec16<T>& go, int64_t i)
+    {
+        Vec16<T> o;
+        #pragma unroll
+        for (int e = 0; e < V; e++)
+        {
+            const float yv = to_acc(in.v[e]), gv = to_acc(go.v[e]);
+            const float u = fmaf(yv, k.pre[e], k.b[e]);
+            bool inside;
+            const float g = epi_value<ACT>(yv, k.pre[e], k.b[e], p.alpha, p.gain, p.clamp, inside);
+            const float du = inside ? gv * k.post[e] * p.gain * act_slope<ACT>(u, p.alpha) : 0.f;
+            aPost[e] = fmaf(gv, g, aPost[e]);
+            aPre[e]  = fmaf(du, yv, aPre[e]);
+            aSum[e] += du;
+            o.v[e] = from_acc<T>(du * k.pre[e]);
+        }
+        store_vec16<T>(dy + i * V, o);
+    };
+    constexpr int U = 2;                                     // 2 streams x 2 = 4 loads in flight per lane
+    int64_t i = first + threadIdx.x;
+    for (; i + (U - 1) * kThreads < last; i += U * kThreads)
+    {
+        Vec16<T> in[U], go[U];
+        #pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            in[u] = load_vec16<T>(y + (i + u * kThreads) * V);
+            go[u] = load_vec16<T>(dout + (i + u * kThreads) * V);
+        }
+        #pragma unroll
+        for (int u = 0; u < U; u++) one(in[u], go[u], i + u * kThreads);
+    }
+    for (; i < last; i += kThreads) one(load_vec16<T>(y + i * V), load_vec16<T>(dout + i * V), i);
+
+    // Block reduction over the threads that share a channel-vector (t, t + cv, t + 2cv, ...):
+    // red[q][e][t] is written conflict-free (t fastest); reader j owns channel (j % cv) * V + j / cv.
+    __shared__ float red[3][V][kThreads];
+    #pragma unroll
+    for (int e = 0; e < V; e++)
+    {
+        red[0][e][threadIdx.x] = aPre[e];
+        red[1][e][threadIdx.x] = aPost[e];
+        red[2][e][threadIdx.x] = aSum[e];
+    }
+    __syncthreads();
+    const int rows = kThreads / cv;
+    for (int j = threadIdx.x; j < p.channels; j += kThreads)
+    {
+        const int c = j & (cv - 1), e = j / cv;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < rows; r++)
+        {
+            s0 += red[0][e][c + r * cv];
+            s1 += red[1][e][c + r * cv];
+            s2 += red[2][e][c + r * cv];
+        }
+        const int64_t o = f * p.channels + c * V + e;
+        if (p.pre)  atomicAdd(p.d_pre + o, s0);
+        if (p.post) atomicAdd(p.d_post + o, s1);
+        atomicAdd(p.d_sum + o, s2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Strided-plane kernels: one wavefront per (frame, channel) plane, 4 planes per block.
+
+template <class T, int ACT>
+__global__ __launch_bounds__(kThreads) void epilogue_plane_fwd_kernel(EpilogueArgs p)
+{
+    const int64_t plane = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float sq = 0.f;
+    int64_t f = 0;
+    if (plane < p.frames * p.channels)
+    {
+        f = plane / p.channels;
+        const int     c = (int)(plane - f * p.channels);
+        const float pre  = p.pre  ? p.pre[plane]  : 1.f;
+        const float post = p.post ? p.post[plane] : 1.f;
+        const float b    = p.b ? to_acc(static_cast<const T*>(p.b)[c]) : 0.f;
+        const int64_t base = f * p.strideF + c * p.strideC;
+        const T* y   = static_cast<const T*>(p.y) + base;
+        T*       out = static_cast<T*>(p.out) + base;
+        for (int i = lane; i < p.pixels; i += 64)
+        {
+            bool inside;
+            const float g = epi_value<ACT>(to_acc(y[i * p.strideP]), pre, b, p.alpha, p.gain, p.clamp, inside);
+            sq = fmaf(g, g, sq);
+            out[i * p.strideP] = from_acc<T>(g * post);
+        }
+    }
+    if (p.msq)
+    {
+        sq = wave_sum(sq);
+        if (lane == 0 && sq != 0.f) atomicAdd(p.msq + f, sq);
+    }
+}
+
+template <class T, int ACT>
+__global__ __launch_bounds__(kThreads) void epilogue_plane_bwd_kernel(EpilogueArgs p)
+{
+    const int64_t plane = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (plane >= p.frames * p.channels) return;
+    const int64_t f = plane / p.channels;
+    const int     c = (int)(plane - f * p.channels);
+    const float pre  = p.pre  ? p.pre[plane]  : 1.f;
+    const float post = p.post ? p.post[plane] : 1.f;
+    const float b    = p.b ? to_acc(static_cast<const T*>(p.b)[c]) : 0.f;
+    const int64_t base = f * p.strideF + c * p.strideC;
+    const T* y    = static_cast<const T*>(p.y) + base;
+    const T* dout = static_cast<const T*>(p.dout) + base;
+    T*       dy   = static_cast<T*>(p.dy) + base;
+    float aPre = 0.f, aPost = 0.f, aSum = 0.f;
+    for (int i = lane; i < p.pixels; i += 64)
+    {
+        const float yv = to_acc(y[i * p.strideP]), gv = to_acc(dout[i * p.strideP]);
+        const float u = fmaf(yv, pre, b);
+        bool inside;
+        const float g = epi_value<ACT>(yv, pre, b, p.alpha, p.gain, p.clamp, inside);
+        const float du = inside ? gv * post * p.gain * act_slope<ACT>(u, p.alpha) : 0.f;
+        aPost = fmaf(gv, g, aPost);
+        aPre  = fmaf(du, yv, aPre);
+        aSum += du;
+        dy[i * p.strideP] = from_acc<T>(du * pre);
+    }
+    aPre = wave_sum(aPre); aPost = wave_sum(aPost); aSum = wave_sum(aSum);
+    if (lane == 0)
+    {
+        if (p.pre)  p.d_pre[plane]  = aPre;
+        if (p.post) p.d_post[plane] = aPost;
+        p.d_sum[plane] = aSum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+
+template <class T, int ACT>
+int launch(EpilogueArgs& p, bool backward, bool channelsLast, hipStream_t stream)
+{
+    constexpr int V = Elem<T>::kVec;
+    const int cv = p.channels / V;
+    const bool vec = channelsLast && p.channels % V == 0 && cv <= kThreads && (cv & (cv - 1)) == 0 &&
+                     lvg_aligned16(p.y) && lvg_aligned16(backward ? p.dy : p.out) && (!backward || lvg_aligned16(p.dout)) &&
+                     p.frames <= 65535;
+    if (vec)
+    {
+        p.frameVecs = (int64_t)p.pixels * cv;
+        // A block streams up to 32 vectors per thread (few atomics per byte moved); a frame is split
+        // into EQUAL chunks (multiples of the block size, so a thread keeps its channel-vector), and
+        // lres-sized frames (9x16x512 ... 36x64x64) give >= frames blocks to fill 256 CUs.
+        const int64_t chunks = lvg_ceil_div(p.frameVecs, kThreads * 32);
+        p.chunkVecs = (int)(lvg_ceil_div(lvg_ceil_div(p.frameVecs, chunks), kThreads) * kThreads);
+        dim3 grid((unsigned)lvg_ceil_div(p.frameVecs, p.chunkVecs), (unsigned)p.frames);
+        if (backward) hipLaunchKernelGGL((epilogue_cl_bwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);
+        else          hipLaunchKernelGGL((epilogue_cl_fwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);
+        return lvg_check_launch("modconv_epilogue (channels-last)");
+    }
+    const int64_t planes = p.frames * p.channels;
+    const int64_t blocks = lvg_ceil_div(planes, kThreads / 64);
+    if (blocks > 0x7fffffffLL) { lvg_set_error("modconv_epilogue: %lld planes exceed the grid limit", (long long)planes); return LVG_ERR_UNSUPPORTED; }
+    if (backward) hipLaunchKernelGGL((epilogue_plane_bwd_kernel<T, ACT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+    else          hipLaunchKernelGGL((epilogue_plane_fwd_kernel<T, ACT>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p);
+    return lvg_check_launch("modconv_epilogue (planes)");
+}
+
+template <class T>
+int dispatch_act(EpilogueArgs& p, int act, bool backward, bool channelsLast, hipStream_t stream)
+{
+    switch (act)
+    {
+    case LVG_ACT_LINEAR: return launch<T, LVG_ACT_LINEAR>(p, backward, channelsLast, stream);
+    case LVG_ACT_RELU:   return launch<T, LVG_ACT_RELU>(p, backward, channelsLast, stream);
+    case LVG_ACT_LRELU:  return launch<T, LVG_ACT_LRELU>(p, backward, channelsLast, stream);
+    default:
+        lvg_set_error("modconv_epilogue: activation %d has no fused kernel (linear, relu, lrelu only)", act);
+        return LVG_ERR_UNSUPPORTED;
+    }
+}
+
+int run(EpilogueArgs& p, int dtype, int act, bool backward, int channels_last, void* stream)
+{
+    LVG_REQUIRE(p.frames >= 0 && p.channels >= 0 && p.pixels >= 0, "modconv_epilogue: negative extent");
+    if (p.frames == 0 || p.channels == 0 || p.pixels == 0) return LVG_OK;
+    LVG_REQUIRE(p.y && (backward ? (p.dout && p.dy && p.d_sum) : p.out != nullptr), "modconv_epilogue: NULL tensor");
+    LVG_REQUIRE(!backward || ((!p.pre || p.d_pre) && (!p.post || p.d_post)), "modconv_epilogue: d_pre/d_post missing");
+    LVG_REQUIRE((int64_t)p.pixels * p.channels <= 0x7fffffffLL, "modconv_epilogue: frame too large");
+    if (channels_last) { p.strideP = p.channels; p.strideC = 1; }
+    else               { p.strideP = 1;          p.strideC = p.pixels; }
+    p.strideF = (int64_t)p.pixels * p.channels;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype)
+    {
+    case LVG_F32:  return dispatch_act<float>(p, act, backward, channels_last != 0, s);
+    case LVG_F16:  return dispatch_act<f16_t>(p, act, backward, channels_last != 0, s);
+    case LVG_BF16: return dispatch_act<bf16_t>(p, act, backward, channels_last != 0, s);
+    default:
+        lvg_set_error("modconv_epilogue: dtype %d not supported (f32, f16, bf16)", dtype);
+        return LVG_ERR_UNSUPPORTED;
+    }
+}
+
+} // namespace
+
+extern "C" int lvg_modconv_epilogue(const void* y, const float* pre, const void* b, const float* post, void* out, float* msq,
+                                    int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
+                                    float alpha, float gain, float clamp, void* stream)
+{
+    EpilogueArgs p = {};
+    p.y = y; p.pre = pre; p.b = b; p.post = post; p.out = out; p.msq = msq;
+    p.frames = frames; p.channels = channels; p.pixels = pixels;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    return run(p, dtype, act, false, channels_last, stream);
+}
+
+extern "C" int lvg_modconv_epilogue_backward(const void* dout, const void* y, const float* pre, const void* b, const float* post,
+                                             void* dy, float* d_pre, float* d_post, float* d_sum,
+                                             int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
+                                             float alpha, float gain, float clamp, void* stream)
+{
+    EpilogueArgs p = {};
+    p.y = y; p.pre = pre; p.b = b; p.post = post; p.dout = dout; p.dy = dy;
+    p.d_pre = d_pre; p.d_post = d_post; p.d_sum = d_sum;
+    p.frames = frames; p.channels = channels; p.pixels = pixels;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    return run(p, dtype, act, true, channels_last, stream);
+}

@@ -26,7 +26,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import torch_utils.distributed as dist_utils
+import contextlib
+
 from torch_utils.ops import bias_act, upfirdn2d
+from torch_utils.ops.modconv_epilogue import modconv_epilogue
 
 SQRT_HALF = math.sqrt(0.5)
 
@@ -122,22 +125,73 @@ class TemporalKaiserDownsample(_FilterHolder):
 
 
 class MagnitudeEMA(nn.Module):
-    """Tracks E[x^2] of a layer input; returns its reciprocal square root as a scalar gain."""
+    """Tracks E[x^2] of a layer input; returns its reciprocal square root as a scalar gain.
+
+    Across ranks the reference all-reduces the statistic inside every layer's forward
+    (model/generator_lres.py:298-312: 19 one-float collectives per generator pass). Inside a
+    `deferred_magnitude_sync()` scope the layer instead folds in its LOCAL mean and records it; one
+    batched all-reduce afterwards (`finish_magnitude_sync`) corrects every buffer to the global-mean
+    update, so buffers end up identical on all ranks and identical to the reference's. The only
+    difference is that the gain used in THIS forward pass saw the local mean: a relative change of
+    (1 - beta) * (local/global - 1) ~ 1e-5, and nothing at world size 1."""
+
+    pending = None          # list of (module, local mean, beta, previous EMA) while a deferred scope is open
 
     def __init__(self, dist_sync: bool = True):
         super().__init__()
         self.dist_sync = dist_sync
         self.register_buffer('magnitude_ema', torch.ones(()))
 
-    def forward(self, x: torch.Tensor, beta: float = 1.0) -> torch.Tensor:
-        if beta != 1:
-            mag = x.detach().float().square().mean()
-            world = dist_utils.get_world_size()
-            if self.dist_sync and world > 1:
+    def update(self, mean_square: torch.Tensor, beta: float) -> torch.Tensor:
+        """Fold a freshly measured mean square (float32 scalar tensor) into the EMA; returns the gain."""
+        mag = mean_square.detach()
+        world = dist_utils.get_world_size()
+        if self.dist_sync and world > 1:
+            if MagnitudeEMA.pending is not None:
+                MagnitudeEMA.pending.append((self, mag, beta, self.magnitude_ema.clone()))
+            else:
+                mag = mag.clone()
                 torch.distributed.all_reduce(mag)
                 mag = mag / world
-            self.magnitude_ema.lerp_(mag, 1.0 - beta)
+        self.magnitude_ema.lerp_(mag.to(self.magnitude_ema.dtype), 1.0 - beta)
         return self.magnitude_ema.rsqrt()
+
+    def forward(self, x: torch.Tensor, beta: float = 1.0) -> torch.Tensor:
+        if beta != 1:
+            return self.update(x.detach().float().square().mean(), beta)
+        return self.magnitude_ema.rsqrt()
+
+
+@contextlib.contextmanager
+def deferred_magnitude_sync():
+    """Scope in which MagnitudeEMA layers record their local statistic instead of all-reducing it."""
+    assert MagnitudeEMA.pending is None, 'deferred_magnitude_sync scopes do not nest'
+    MagnitudeEMA.pending = []
+    try:
+        yield MagnitudeEMA.pending
+    finally:
+        MagnitudeEMA.pending = None
+
+
+def stack_pending(pending):
+    """(local means, previous EMAs) of a deferred scope as two vectors (cheap to keep in a captured graph)."""
+    return torch.stack([m for _, m, _, _ in pending]), torch.stack([p for _, _, _, p in pending])
+
+
+def finish_magnitude_sync(pending, stacked=None) -> None:
+    """One all-reduce for every statistic recorded in a deferred scope, then each buffer is REDONE as
+    lerp(previous EMA, global mean, 1 - beta): the reference's arithmetic, bit-identical on every rank."""
+    world = dist_utils.get_world_size()
+    if not pending or world <= 1:
+        return
+    local, prev = stack_pending(pending) if stacked is None else stacked
+    glob = local.clone()
+    torch.distributed.all_reduce(glob)
+    glob = glob / world
+    weight = torch.tensor([1.0 - beta for _, _, beta, _ in pending], dtype=glob.dtype, device=glob.device)
+    new = torch.lerp(prev.to(glob.dtype), glob, weight)
+    for (mod, _, _, _), v in zip(pending, new.unbind(0)):
+        mod.magnitude_ema.copy_(v)
 
 
 class FullyConnectedLayer(nn.Module):
@@ -361,6 +415,24 @@ def modulated_conv_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Te
     return y
 
 
+def modulation_terms(weight: torch.Tensor, style: torch.Tensor, demodulate: bool):
+    """Small-tensor side of a modulated convolution in frames layout.
+
+    weight [Co, Ci, kt, kh, kw], style [T, N, Ci] float32 -> (scaled weight, per-frame modulation
+    [(T N), Ci], per-frame demodulation [(T N), Co] or None); same normalisations as
+    `modulated_conv_frames`, so conv(x * modulation, weight) * demodulation is the modulated conv."""
+    t, n, ci = style.shape
+    if demodulate:
+        weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
+        style = style / style.abs().amax(dim=(0, 2), keepdim=True)
+    weight = weight * (1.0 / math.sqrt(weight[0].numel()))
+    demod = None
+    if demodulate:
+        w2 = weight.square().sum(dim=(2, 3, 4))
+        demod = torch.matmul(style.square(), w2.t()).add(1e-8).rsqrt().reshape(t * n, -1)
+    return weight, style.reshape(t * n, ci), demod
+
+
 # --------------------------------------------------------------------------------------------------
 # Generator.
 
@@ -508,18 +580,32 @@ class Synthesis3dResBlock(nn.Module):
         n, c, t = latent.shape
         lat = latent.permute(2, 0, 1).reshape(t * n, c)                         # rows ordered (t n), like the frames
         x = x.to(dtype)
-        style_0 = self.affine_0(lat).reshape(t, n, -1)
-        gain_0 = self.input_magnitude_ema_0(x, magnitude_ema_beta) if self.magnitude_ema else None
-        h = modulated_conv_frames(x, self.weight_0, style_0, gain_0, self.padding, True, dtype)
-        h = bias_act.bias_act(h, self.bias_0.to(dtype), act=self.activation, clamp=self.activation_clamp)
-        style_1 = self.affine_1(lat).reshape(t, n, -1)
-        gain_1 = self.input_magnitude_ema_1(h, magnitude_ema_beta) if self.magnitude_ema else None
-        y1, demod_1 = modulated_conv_frames(h, self.weight_1, style_1, gain_1, self.padding, True, dtype, return_demod=True)
+        track = self.magnitude_ema and magnitude_ema_beta != 1
+        w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True)
+        w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True)
+
+        # conv 0: modulate (one pass, which also measures E[x^2]) -> conv -> fused epilogue
+        xm = modconv_epilogue(x, post=mod_0, want_msq=track)
+        gain_0 = None
+        if self.magnitude_ema:
+            gain_0 = self.input_magnitude_ema_0.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_0(x)
+        xm = xm[0] if track else xm
+        y0 = temporal_conv_frames(xm, w0.to(dtype), n, self.padding[1:])
+        # demodulation * input gain, bias, activation, clamp, AND the modulation of conv 1 in one pass
+        hm = modconv_epilogue(y0, pre=(demod_0 if gain_0 is None else demod_0 * gain_0), b=self.bias_0.to(dtype), post=mod_1,
+                              act=self.activation, clamp=self.activation_clamp, want_msq=track)
+        gain_1 = None
+        if self.magnitude_ema:
+            gain_1 = self.input_magnitude_ema_1.update(hm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_1.magnitude_ema.rsqrt()
+        hm = hm[0] if track else hm
+        y1 = temporal_conv_frames(hm, w1.to(dtype), n, self.padding[1:])
+
         w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
         if gain_0 is not None:
             w_skip = w_skip * gain_0
         skip = F.conv2d(x, _cl(w_skip.to(dtype)))
-        h = torch.addcmul(skip, y1, (demod_1 * SQRT_HALF).to(dtype))
+        scale_1 = demod_1 * SQRT_HALF if gain_1 is None else demod_1 * (gain_1 * SQRT_HALF)
+        h = torch.addcmul(skip, y1, scale_1.to(dtype).reshape(t * n, -1, 1, 1))
         if self.temporal_up:
             h = resample_time_frames(h, self.temporal_upsample.filter, n, up=self.temporal_upsample.scale)
         h = crop_frames(h, n, seq_length=out_seq_length)
@@ -557,8 +643,14 @@ class ToRGB(nn.Module):
         n, c, t = latent.shape
         style = self.affine(latent.permute(2, 0, 1).reshape(t * n, c)).reshape(t, n, -1)
         x = x.to(dtype)
-        gain = self.input_magnitude_ema(x, magnitude_ema_beta) if self.magnitude_ema else None
-        y = modulated_conv_frames(x, self.weight, style, gain, (0, 0, 0), False, dtype)
+        track = self.magnitude_ema and magnitude_ema_beta != 1
+        weight, mod, _ = modulation_terms(self.weight, style, False)
+        xm = modconv_epilogue(x, post=mod, want_msq=track)
+        if self.magnitude_ema:                                                  # scalar gain folded into the 3 x Ci weight
+            gain = self.input_magnitude_ema.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema(x)
+            weight = weight * gain
+        xm = xm[0] if track else xm
+        y = temporal_conv_frames(xm, weight.to(dtype), n, (0, 0))
         return bias_act.bias_act(y, self.bias.to(dtype), act='linear', clamp=self.activation_clamp)
 
 

@@ -1,0 +1,156 @@
+"""Epilogue of a style-modulated convolution fused with the prologue of the next one:
+
+    out[f, c] = clamp(act(y[f, c] * pre[f, c] + b[c]) * gain) * post[f, c]     (+ mean(value^2) before `post`)
+
+`y` is the raw convolution output over frames f (sample x time), `pre` its demodulation
+coefficients, `post` the style modulation of the convolution that consumes `out`, and the mean
+square is the input-magnitude statistic the next layer tracks. The reference spells this as three
+elementwise passes plus a reduction (model/generator_lres.py:122 `output * demodulation`, :570
+bias_act, :101 `input * style`, :574 magnitude EMA); here GPU tensors take ONE pass,
+`lvg_modconv_epilogue` (csrc/modconv_epilogue.hip), whose backward recomputes the activation and
+returns the per-(frame, channel) reductions d_pre / d_post / d_bias from the same pass. CPU tensors
+run the plain-PyTorch composition (also the definition the GPU tests compare against).
+
+Activations: linear, relu, lrelu (what the modulated layers use). First-order gradients only --
+the generator losses of this repo never differentiate twice through a modulated layer (R1 acts on
+the discriminator)."""
+
+import torch
+
+from .. import custom_ops
+from . import _hip
+from .bias_act import activation_funcs
+
+_FUSED_ACTS = ('linear', 'relu', 'lrelu')
+_plugin = None
+
+
+def _init():
+    global _plugin
+    if _plugin is None:
+        custom_ops.get_plugin(module_name='modconv_epilogue_plugin')
+        _plugin = _hip.lib()
+    return True
+
+
+def _resolve(act, alpha, gain, clamp):
+    assert act in _FUSED_ACTS, f'modconv_epilogue supports {_FUSED_ACTS}, got {act!r}'
+    spec = activation_funcs[act]
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    return spec, alpha, gain, clamp
+
+
+def _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq):
+    """Plain-PyTorch definition (float32 arithmetic, one rounding at the end)."""
+    u = y.float()
+    if pre is not None:
+        u = u * pre[:, :, None, None]
+    if b is not None:
+        u = u + b.float()[None, :, None, None]
+    if act == 'relu':
+        u = torch.relu(u)
+    elif act == 'lrelu':
+        u = torch.nn.functional.leaky_relu(u, alpha)
+    if gain != 1:
+        u = u * gain
+    if clamp >= 0:
+        u = u.clamp(-clamp, clamp)
+    msq = u.detach().square().mean() if want_msq else None
+    if post is not None:
+        u = u * post[:, :, None, None]
+    return u.to(y.dtype), msq
+
+
+def _layout(t):
+    """(dense tensor, channels_last flag) as handed to the kernel."""
+    if t.shape[1] > 1 and t.stride(1) == 1 and t.is_contiguous(memory_format=torch.channels_last):
+        return t, 1
+    if t.is_contiguous():
+        return t, 0
+    if t.shape[1] > 1 and t.stride(1) == 1:
+        return t.contiguous(memory_format=torch.channels_last), 1
+    return t.contiguous(), 0
+
+
+def _launch_fwd(y, pre, b, post, cl, act_id, alpha, gain, clamp, want_msq):
+    """One lvg_modconv_epilogue launch on y's device and the current stream -> (out, msq per frame | None)."""
+    f, c, h, w = y.shape
+    out = torch.empty_like(y)
+    assert out.stride() == y.stride()
+    msq = torch.zeros(f, dtype=torch.float32, device=y.device) if want_msq else None
+    with torch.cuda.device(y.device):
+        rc = _hip.lib().lvg_modconv_epilogue(
+            y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), out.data_ptr(), _hip.ptr(msq),
+            f, c, h * w, cl, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
+    _hip.check(rc, 'modconv_epilogue')
+    return out, msq
+
+
+def _launch_bwd(dout, y, pre, b, post, cl, act_id, alpha, gain, clamp):
+    """One lvg_modconv_epilogue_backward launch -> (dy, [d_pre, d_post, d_sum] float32 [3, frames, channels])."""
+    f, c, h, w = y.shape
+    dy = torch.empty_like(y)
+    red = torch.zeros(3, f, c, dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = _hip.lib().lvg_modconv_epilogue_backward(
+            dout.data_ptr(), y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), dy.data_ptr(),
+            red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
+            f, c, h * w, cl, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
+    _hip.check(rc, 'modconv_epilogue_backward')
+    return dy, red
+
+
+class _Epilogue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, pre, b, post, act_id, alpha, gain, clamp, want_msq):
+        y, cl = _layout(y)
+        pre = pre.contiguous() if pre is not None else None
+        post = post.contiguous() if post is not None else None
+        b = b.contiguous() if b is not None else None
+        out, msq = _launch_fwd(y, pre, b, post, cl, act_id, alpha, gain, clamp, want_msq)
+        ctx.save_for_backward(y, pre, b, post)
+        ctx.cfg = (cl, act_id, alpha, gain, clamp)
+        mean_sq = msq.sum() / float(y.numel()) if want_msq else None
+        if want_msq:
+            ctx.mark_non_differentiable(mean_sq)
+        return out, mean_sq
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout, _dmsq):
+        y, pre, b, post = ctx.saved_tensors
+        cl, act_id, alpha, gain, clamp = ctx.cfg
+        dout = dout.contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+        assert dout.stride() == y.stride() and dout.dtype == y.dtype
+        dy, red = _launch_bwd(dout, y, pre, b, post, cl, act_id, alpha, gain, clamp)
+        d_pre = red[0] if (pre is not None and ctx.needs_input_grad[1]) else None
+        d_b = red[2].sum(dim=0).to(b.dtype) if (b is not None and ctx.needs_input_grad[2]) else None
+        d_post = red[1] if (post is not None and ctx.needs_input_grad[3]) else None
+        return dy, d_pre, d_b, d_post, None, None, None, None, None
+
+
+def modconv_epilogue(y, pre=None, b=None, post=None, act='linear', alpha=None, gain=None, clamp=None, want_msq=False, impl='cuda'):
+    r"""out = clamp(act(y * pre + b) * gain) * post, optionally with mean(value before post ** 2).
+
+    Args:
+        y:     [frames, channels, H, W], contiguous or channels-last; float32 / float16 / bfloat16.
+        pre:   float32 [frames, channels] or None.
+        b:     [channels] in y's dtype, or None.
+        post:  float32 [frames, channels] or None.
+        act, alpha, gain, clamp: as `bias_act` ('linear', 'relu', 'lrelu').
+        want_msq: also return the (detached, float32 scalar) mean square of the value before `post`.
+
+    Returns `out`, or `(out, mean_square)` with `want_msq`."""
+    assert y.ndim == 4
+    f, c = y.shape[:2]
+    for name, t in (('pre', pre), ('post', post)):
+        assert t is None or (t.shape == (f, c) and t.dtype == torch.float32 and t.device == y.device), f'{name} must be float32 [frames, channels]'
+    assert b is None or (b.shape == (c,) and b.dtype == y.dtype and b.device == y.device), 'b must be [channels] in y\'s dtype'
+    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+    if impl == 'cuda' and y.device.type == 'cuda' and _init():
+        out, msq = _Epilogue.apply(y, pre, b, post, spec.cuda_idx, alpha, gain, clamp, bool(want_msq))
+    else:
+        out, msq = _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq)
+    return (out, msq) if want_msq else out

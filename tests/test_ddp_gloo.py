@@ -1,7 +1,8 @@
 """Data-parallel gradient exchange on CPU with gloo, world_size 2 (the N>1 path of bench.py):
 `lvg.ddp.sync_grads` == the reference's arithmetic (mean over ranks, gain, nan_to_num clamp,
 shard boundaries at 2**23), `FlatGradSync` (persistent flat buffer, bucketed, backward-overlapped)
-== `sync_grads`, and a 2-rank trainer step keeps parameters bit-identical across ranks."""
+== `sync_grads`, and the deferred input-magnitude synchronisation keeps the generator's EMA buffers
+identical across ranks."""
 
 import os
 import socket
@@ -93,21 +94,44 @@ def _worker_sync(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def _worker_trainer(rank, world, port, out):
+def _worker_magnitude(rank, world, port, out):
+    """Deferred input-magnitude sync (one batched all-reduce after the pass) leaves every EMA buffer
+    identical on all ranks and equal to the reference's per-layer all-reduce."""
+    import copy
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'long-video-gan_amd'))
     _init(rank, world, port)
     try:
-        from lvg.train_lres import LowResTrainer
-        import lvg.models.lres as lres
-        torch.manual_seed(1234 + rank)                    # different init per rank: broadcast must fix it
-        tiny_G = dict(temporal_emb_dim=32, latent_w_dim=32, embedding_kwargs=dict(channels=32, blur_widths=4, min_sampling_rate=20, max_sampling_rate=40),
-                      temporal_padding=1)
-        # shrink channel widths for a CPU-sized run
-        orig = lres.Synthesis3dResBlock.__init__
-        tr = LowResTrainer(seq_length=8, height=36, width=64, device='cpu', G_kwargs=tiny_G, temp_scale_augment=0.5,
-                           G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=True, with_ema=True) if False else None
-        out.put((rank, 'skip'))
+        from lvg.models import lres
+        torch.manual_seed(0)
+        blk = lres.Synthesis3dResBlock(latent_dim=16, in_channels=8, out_channels=8, temporal_ksize=3, spatial_ksize=3)
+        rgb = lres.ToRGB(latent_dim=16, in_channels=8)
+        blk_ref, rgb_ref = copy.deepcopy(blk), copy.deepcopy(rgb)
+        g = torch.Generator().manual_seed(10 + rank)                     # different data per rank
+        x = torch.randn(2, 8, 4, 5, 6, generator=g) * (1 + rank)
+        latent = torch.randn(2, 16, 4, generator=g)
+        for _ in range(2):                                               # two steps: corrections must compose
+            # reference behaviour: all-reduce inside every layer
+            h_ref = blk_ref(x, latent, 0.9)
+            rgb_ref(h_ref, latent, 0.9)
+            # deferred: local statistic now, one all-reduce afterwards
+            with lres.deferred_magnitude_sync() as pending:
+                h = lres.video_from_frames(blk.forward_frames(lres.frames_from_video(x), latent, 0.9), 2)
+                rgb.forward_frames(lres.frames_from_video(h_ref), latent, 0.9)
+            assert len(pending) == 3
+            lres.finish_magnitude_sync(pending)
+        pairs = [(blk.input_magnitude_ema_0, blk_ref.input_magnitude_ema_0), (blk.input_magnitude_ema_1, blk_ref.input_magnitude_ema_1),
+                 (rgb.input_magnitude_ema, rgb_ref.input_magnitude_ema)]
+        mine = torch.stack([a.magnitude_ema for a, _ in pairs])
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.equal(gathered[0], gathered[1]), 'EMA buffers differ across ranks'
+        # conv-0 statistic is measured on identical inputs in both variants -> equal to the reference's;
+        # later layers see inputs that differ by the O((1-beta) * local/global) gain deviation only.
+        torch.testing.assert_close(pairs[0][0].magnitude_ema, pairs[0][1].magnitude_ema, rtol=1e-5, atol=1e-6)
+        for a, b in pairs[1:]:
+            torch.testing.assert_close(a.magnitude_ema, b.magnitude_ema, rtol=2e-2, atol=1e-3)
+        out.put((rank, 'ok'))
     except Exception:
         import traceback
         out.put((rank, traceback.format_exc()))
@@ -131,3 +155,7 @@ def _spawn(fn):
 
 def test_sync_grads_and_flat_sync_world2():
     _spawn(_worker_sync)
+
+
+def test_deferred_magnitude_sync_world2():
+    _spawn(_worker_magnitude)

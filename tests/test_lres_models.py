@@ -132,3 +132,29 @@ def test_crop_frames_backward_keeps_memory_format():
     ref = torch.zeros(6, 8, 5, 7)
     ref[2:4, :, 1:4, 1:5] = 1
     assert torch.equal(g, ref)
+
+
+def test_frames_block_tracks_input_magnitude_like_the_layer_definition():
+    """forward_frames (fused epilogues, statistic measured inside them) vs the literal NCTHW layer:
+    same output and the same EMA buffers when magnitude_ema_beta < 1."""
+    import copy
+    from lvg.models.lres import Synthesis3dResBlock, ToRGB, frames_from_video, video_from_frames
+    torch.manual_seed(0)
+    blk = Synthesis3dResBlock(latent_dim=16, in_channels=8, out_channels=12, temporal_ksize=3, spatial_ksize=3, spatial_up=True)
+    with torch.no_grad():
+        blk.bias_0.normal_(0, 0.2); blk.bias_1.normal_(0, 0.2)
+        blk.input_magnitude_ema_0.magnitude_ema.fill_(0.7); blk.input_magnitude_ema_1.magnitude_ema.fill_(1.6)
+    blk2 = copy.deepcopy(blk)
+    x = torch.randn(2, 8, 6, 5, 7)
+    latent = torch.randn(2, 16, 6)
+    want = blk(x, latent, 0.9)
+    got = video_from_frames(blk2.forward_frames(frames_from_video(x), latent, 0.9), 2)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    for name in ('input_magnitude_ema_0', 'input_magnitude_ema_1'):
+        torch.testing.assert_close(getattr(blk2, name).magnitude_ema, getattr(blk, name).magnitude_ema, rtol=1e-5, atol=1e-6)
+    rgb = ToRGB(latent_dim=16, in_channels=8)
+    rgb2 = copy.deepcopy(rgb)
+    want = rgb(x, latent, 0.9)
+    got = video_from_frames(rgb2.forward_frames(frames_from_video(x), latent, 0.9), 2)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rgb2.input_magnitude_ema.magnitude_ema, rgb.input_magnitude_ema.magnitude_ema, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,112 @@
+"""modconv_epilogue: the fused modulated-conv epilogue (csrc/modconv_epilogue.hip) against its
+definition -- demodulation multiply -> bias_act -> modulation multiply, with bias_act taken from the
+float64 C oracle (oracle/lvg_oracle.c) -- forward, backward (dy, d_pre, d_b, d_post) and the
+mean-square side output; both memory layouts, vector and strided-plane kernels, ragged sizes."""
+
+import numpy as np
+import pytest
+import torch
+
+from torch_utils.ops.modconv_epilogue import modconv_epilogue, _ref
+
+
+def _case(seed, f, c, h, w, dtype, device, channels_last, with_pre=True, with_b=True, with_post=True):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn(f, c, h, w, generator=g) * 2
+    pre = (0.5 + torch.rand(f, c, generator=g)) if with_pre else None
+    post = (torch.randn(f, c, generator=g)) if with_post else None
+    b = (0.3 * torch.randn(c, generator=g)) if with_b else None
+    y = y.to(device=device, dtype=dtype)
+    if channels_last:
+        y = y.contiguous(memory_format=torch.channels_last)
+    mv = lambda t: None if t is None else t.to(device)
+    return y, mv(pre), (None if b is None else b.to(device=device, dtype=dtype)), mv(post)
+
+
+def _oracle_forward(oracle, y, pre, b, post, act, clamp):
+    """numpy float64 definition with the oracle's bias_act in the middle."""
+    u = y.double().cpu().numpy()
+    if pre is not None:
+        u = u * pre.double().cpu().numpy()[:, :, None, None]
+    v = oracle.bias_act(u, None if b is None else b.double().cpu().numpy(), dim=1, act=act, clamp=clamp)
+    out = v if post is None else v * post.double().cpu().numpy()[:, :, None, None]
+    return out, float((v ** 2).mean())
+
+
+def test_ref_definition_matches_oracle_cpu(oracle):
+    y, pre, b, post = _case(0, 3, 5, 4, 6, torch.float32, 'cpu', False)
+    out, msq = modconv_epilogue(y, pre, b, post, act='lrelu', clamp=1.5, want_msq=True)
+    want, want_msq = _oracle_forward(oracle, y, pre, b, post, 'lrelu', 1.5)
+    np.testing.assert_allclose(out.numpy(), want, rtol=1e-5, atol=1e-6)
+    assert abs(float(msq) - want_msq) < 1e-5 * want_msq
+
+
+def test_ref_path_is_differentiable_cpu():
+    y, pre, b, post = _case(1, 2, 4, 3, 5, torch.float64, 'cpu', False)
+    y.requires_grad_(True)
+    pre = pre.float().requires_grad_(True)
+    post = post.float().requires_grad_(True)
+    out = modconv_epilogue(y, pre, b.requires_grad_(True), post, act='lrelu')
+    out.sum().backward()
+    assert y.grad is not None and pre.grad.shape == (2, 4) and post.grad.shape == (2, 4) and b.grad.shape == (4,)
+
+
+CASES = [
+    # f, c, h, w, channels_last
+    (6, 64, 9, 16, True),        # vector kernel, one block per frame
+    (3, 512, 18, 32, True),      # vector kernel, several chunks per frame (atomics across blocks)
+    (5, 8, 7, 5, True),          # cv = 1 (bf16) / 2 (f32)
+    (4, 24, 5, 7, True),         # c/vector not a power of two -> strided planes
+    (4, 3, 9, 16, True),         # RGB
+    (4, 40, 11, 13, False),      # NCHW planes, ragged
+    (2, 16, 36, 64, False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('f,c,h,w,cl', CASES)
+@pytest.mark.parametrize('act,clamp', [('lrelu', 2.0), ('linear', None), ('relu', 1.0)])
+def test_forward_backward_match_definition_gpu(oracle, dtype, f, c, h, w, cl, act, clamp):
+    y, pre, b, post = _case(7, f, c, h, w, dtype, 'cuda', cl)
+    y.requires_grad_(True); pre.requires_grad_(True); post.requires_grad_(True); b.requires_grad_(True)
+    out, msq = modconv_epilogue(y, pre, b, post, act=act, clamp=clamp, want_msq=True)
+    assert out.stride() == y.stride() and out.dtype == dtype
+    want, want_msq = _oracle_forward(oracle, y.detach(), pre.detach(), b.detach(), post.detach(), act, clamp)
+    eps = {torch.float32: 2e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    np.testing.assert_allclose(out.detach().double().cpu().numpy(), want, rtol=eps, atol=eps)
+    assert abs(float(msq) - want_msq) <= 1e-4 * want_msq
+
+    # backward against autograd through the float32 definition on the same (rounded) inputs
+    go = torch.randn(out.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)).to(dtype)
+    if cl:
+        go = go.contiguous(memory_format=torch.channels_last)
+    got = torch.autograd.grad(out, (y, pre, b, post), go)
+    y2, pre2, b2, post2 = (t.detach().clone().requires_grad_(True) for t in (y, pre, b, post))
+    spec_alpha = 0.2
+    gain = 1.0 if act == 'linear' else float(np.sqrt(2))
+    ref_out, _ = _ref(y2.float(), pre2, b2.float(), post2, act, spec_alpha, gain, -1.0 if clamp is None else clamp, False)
+    ref = torch.autograd.grad(ref_out, (y2, pre2, b2, post2), go.float())
+    names = ('dy', 'd_pre', 'd_b', 'd_post')
+    for name, a, r in zip(names, got, ref):
+        a, r = a.double().cpu(), r.double().cpu()
+        scale = float(r.abs().max()) + 1e-12
+        tol = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype]
+        assert float((a - r).abs().max()) <= tol * scale, (name, float((a - r).abs().max()), scale)
+    assert got[0].stride() == y.stride()
+
+
+@pytest.mark.gpu
+def test_optional_operands_and_no_msq_gpu():
+    y, pre, b, post = _case(9, 4, 32, 6, 10, torch.bfloat16, 'cuda', True)
+    for kw in (dict(pre=pre), dict(post=post), dict(b=b), dict()):
+        out = modconv_epilogue(y, act='lrelu', clamp=4.0, **kw)
+        ref, _ = _ref(y, kw.get('pre'), kw.get('b'), kw.get('post'), 'lrelu', 0.2, float(np.sqrt(2)), 4.0, False)
+        torch.testing.assert_close(out.float(), ref.float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_unsupported_activation_raises_gpu():
+    y = torch.randn(2, 8, 4, 4, device='cuda')
+    with pytest.raises(AssertionError):
+        modconv_epilogue(y, act='tanh')
