@@ -30,12 +30,12 @@ template <> __device__ __forceinline__ double from_acc<double>(double v) { retur
 template <> __device__ __forceinline__ f16_t  from_acc<f16_t>(float v)   { _Float16 h = (_Float16)v; f16_t r; __builtin_memcpy(&r.bits, &h, 2); return r; }
 template <> __device__ __forceinline__ bf16_t from_acc<bf16_t>(float v)
 {
-    // round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16)
-    uint32_t u = __float_as_uint(v);
+    // gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN -- the same
+    // rounding as torch's float -> bfloat16); the integer emulation cost ~6 VALU ops per element, which
+    // showed up in the bf16 streaming kernels.
+    __bf16 h = (__bf16)v;
     bf16_t r;
-    if ((u & 0x7fffffffu) > 0x7f800000u) { r.bits = (uint16_t)((u >> 16) | 0x40u); return r; }
-    u += 0x7fffu + ((u >> 16) & 1u);
-    r.bits = (uint16_t)(u >> 16);
+    __builtin_memcpy(&r.bits, &h, 2);
     return r;
 }
 

@@ -24,6 +24,7 @@
 // Roofline: pure stream. Algorithmic bytes per element: forward 2*s, backward 3*s (s = sizeof(T)).
 
 #include "lvg_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -326,7 +327,9 @@ int launch(EpilogueArgs& p, bool backward, bool channelsLast, hipStream_t stream
         // A block streams up to 32 vectors per thread (few atomics per byte moved); a frame is split
         // into EQUAL chunks (multiples of the block size, so a thread keeps its channel-vector), and
         // lres-sized frames (9x16x512 ... 36x64x64) give >= frames blocks to fill 256 CUs.
-        const int64_t chunks = lvg_ceil_div(p.frameVecs, kThreads * 32);
+        int64_t chunks = lvg_ceil_div(p.frameVecs, kThreads * 32);
+        if (p.frames * chunks < 2048)                        // few small frames: split further to fill the chip
+            chunks = std::max<int64_t>(chunks, std::min<int64_t>(lvg_ceil_div(2048, p.frames), lvg_ceil_div(p.frameVecs, kThreads)));
         p.chunkVecs = (int)(lvg_ceil_div(lvg_ceil_div(p.frameVecs, chunks), kThreads) * kThreads);
         dim3 grid((unsigned)lvg_ceil_div(p.frameVecs, p.chunkVecs), (unsigned)p.frames);
         if (backward) hipLaunchKernelGGL((epilogue_cl_bwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);

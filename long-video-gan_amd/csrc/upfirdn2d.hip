@@ -1227,7 +1227,9 @@ int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
     if (up2 || down2)
     {
         // streaming form: enough lanes even for short frames thanks to row chunks of 16 output rows
-        p.chunkRows = 16;
+        // (equal chunks: 18 output rows are 2 x 10/8, not 16 + 2 -- the short tail chunk measured 37 % slower)
+        p.rowChunks = (p.oh + 15) / 16;
+        p.chunkRows = (((p.oh + p.rowChunks - 1) / p.rowChunks) + 1) & ~1;
         p.rowChunks = (p.oh + p.chunkRows - 1) / p.chunkRows;
         const int64_t threads = (int64_t)p.n * p.rowChunks * p.ow * (p.c / V);
         const int64_t nb = (threads + 255) / 256;

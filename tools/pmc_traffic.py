@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {'bias_act': 'bias_act', 'upfirdn2d': 'upfirdn2d', 'filtered_lrelu': 'filtered_lrelu'}
+FAMILIES = {'bias_act': 'bias_act', 'upfirdn2d': 'upfirdn2d', 'filtered_lrelu': 'filtered_lrelu', 'modconv_epilogue': 'epilogue_'}
 
 
 def per_family(path, counter):
