@@ -1,0 +1,180 @@
+"""Training-step body of the super-resolution GAN on synthetic data (reference
+model/video_gan_sres.py:126-294 + train_sres.py:236-264): the generator maps a low-resolution
+clip with +-`temporal_context` extra frames to high-resolution frames; the discriminator sees the
+(bilinearly upsampled) low-resolution clip stacked with the high-resolution one, both pushed
+through the SAME ADA transform; R1 on the high-resolution input; the ADA probability follows the
+sign of the real logits. One process per GPU; gradients are exchanged with `lvg.ddp` over RCCL.
+The reference's dataset / W&B / checkpoint plumbing is out of scope."""
+
+import copy
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from torch_utils.ops import conv2d_gradfix, grid_sample_gradfix
+
+from . import ddp
+from .ada_augment import AugmentPipe
+from .models import sres
+
+
+class SuperResTrainer:
+    def __init__(self, seq_length: int = 8, temporal_context: int = 4, lr_height: int = 36, lr_width: int = 64,
+                 hr_height: int = 144, hr_width: int = 256, channels: int = 3, device='cuda',
+                 compute_dtype: torch.dtype = torch.float16,
+                 G_lrate: float = 0.003, G_beta2: float = 0.99, G_ema_beta: float = 0.99985, G_ema_warmup_steps: int = 25000,
+                 G_magnitude_ema_beta: float = 0.999, G_grad_accum: int = 1,
+                 D_lrate: float = 0.002, D_beta2: float = 0.99, D_grad_accum: int = 1,
+                 r1_gamma: float = 1.0, lr_cond_prob: float = 0.1,
+                 augment_p_init: float = 0.0, augment_p_max: float = 0.5, augment_p_update_rate: float = 0.000125,
+                 augment_real_sign_target: Optional[float] = 0.6, augment_kwargs: Optional[dict] = None,
+                 in_augment_p: float = 0.5, in_augment_strength: float = 8.0, overlap_grad_sync: bool = True,
+                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True):
+        conv2d_gradfix.enabled = True            # as train_sres.py:81-82: R1 differentiates twice through
+        grid_sample_gradfix.enabled = True       # the resampling convs and ADA's grid_sample
+        self.seq_length, self.temporal_context, self.channels = seq_length, temporal_context, channels
+        self.context_seq_length = seq_length + 2 * temporal_context
+        self.lr_size, self.hr_size = (lr_height, lr_width), (hr_height, hr_width)
+        self.device = torch.device(device)
+        self.G_magnitude_ema_beta, self.G_ema_beta, self.G_ema_warmup_steps = G_magnitude_ema_beta, G_ema_beta, G_ema_warmup_steps
+        self.G_grad_accum, self.D_grad_accum = G_grad_accum, D_grad_accum
+        self.r1_gamma, self.lr_cond_prob = r1_gamma, lr_cond_prob
+        self.augment_p_max, self.augment_p_update_rate, self.augment_real_sign_target = augment_p_max, augment_p_update_rate, augment_real_sign_target
+
+        sizes = dict(hr_height=hr_height, hr_width=hr_width, lr_height=lr_height, lr_width=lr_width)
+        self.G = sres.VideoGenerator(temporal_context=temporal_context, compute_dtype=compute_dtype, **sizes, **(G_kwargs or {}))
+        self.D = sres.VideoDiscriminator(channels=channels, seq_length=seq_length, compute_dtype=compute_dtype, **sizes, **(D_kwargs or {}))
+        for net in (self.G, self.D):
+            net.to(self.device).requires_grad_(False).train()
+            ddp.broadcast_module(net, src=0)
+        self.G_ema = copy.deepcopy(self.G).eval() if with_ema else None
+        self.G_opt = torch.optim.Adam(self.G.parameters(), lr=G_lrate, betas=(0.0, G_beta2))
+        self.D_opt = torch.optim.Adam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
+        self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
+        self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
+
+        # discriminator-side ADA (probability adapted from the sign of the real logits)
+        self.augment = None
+        if augment_p_init > 0 or augment_real_sign_target is not None:
+            self.augment = AugmentPipe(**(augment_kwargs or {})).to(self.device).requires_grad_(False).train()
+            self.augment.p.fill_(augment_p_init)
+        self._real_sign_sum = torch.zeros(2, device=self.device)          # [sum of signs, count] since the last update_ada
+        # conditioning-side augmentation: mild geometric jitter + noise on the low-resolution input
+        self.in_augment = None
+        if in_augment_strength > 0 and in_augment_p > 0:
+            k = in_augment_strength
+            self.in_augment = AugmentPipe(scale=1, scale_std=0.01 * k, rotate=1, rotate_max=0.002 * k, aniso=1, aniso_std=0.01 * k,
+                                          xfrac=1, xfrac_std=0.002 * k, noise=1, noise_std=0.01 * k)
+            self.in_augment.to(self.device).requires_grad_(False).train()
+            self.in_augment.p.fill_(in_augment_p)
+
+    # ------------------------------------------------------------------------------------------
+    def crop_to_seq_length(self, video: torch.Tensor) -> torch.Tensor:
+        t0 = (video.size(2) - self.seq_length) // 2
+        return video[:, :, t0:t0 + self.seq_length]
+
+    def _jitter(self, lr_video: torch.Tensor) -> torch.Tensor:
+        return lr_video if self.in_augment is None else self.in_augment(lr_video)
+
+    def run_D(self, lr_video: torch.Tensor, hr_video: torch.Tensor) -> torch.Tensor:
+        """lr [N, C, T, h, w] and hr [N, C, T, H, W] -> logits [N, 1]. Both clips go through ONE augmentation
+        call (stacked along time) so they receive the same geometric / colour transform."""
+        assert lr_video.shape[2:] == (self.seq_length, *self.lr_size) and hr_video.shape[2:] == (self.seq_length, *self.hr_size)
+        pair = torch.cat((self.D.upsample(lr_video), hr_video), dim=2)
+        if self.augment is not None:
+            pair = self.augment(pair)
+        lr_up, hr_video = pair.chunk(2, dim=2)
+        if self.lr_cond_prob < 1:                                           # conditioning dropout, per sample
+            keep = torch.rand(lr_up.size(0), 1, 1, 1, 1, device=lr_up.device) < self.lr_cond_prob
+            lr_up = lr_up * keep.to(lr_up.dtype)
+        return self.D(lr_up, hr_video)
+
+    # ------------------------------------------------------------------------------------------
+    def update_G(self, lr_video: torch.Tensor) -> None:
+        assert lr_video.shape[1:] == (self.channels, self.context_seq_length, *self.lr_size)
+        assert lr_video.size(0) % self.G_grad_accum == 0
+        lr_video = self._jitter(lr_video)
+        self.G.requires_grad_(True)
+        self.G_sync.zero()
+        chunks = lr_video.chunk(self.G_grad_accum)
+        for k, lr in enumerate(chunks):
+            if k == len(chunks) - 1 and self.G_sync.overlap:
+                self.G_sync.arm()
+            logits = self.run_D(self.crop_to_seq_length(lr), self.G(lr))
+            F.softplus(-logits).mean().backward()
+        self.G.requires_grad_(False)
+        self.G_sync.finish(gain=1 / self.G_grad_accum)
+        self.G_opt.step()
+
+    def update_D(self, fake_lr_video: torch.Tensor, real_lr_video: torch.Tensor, real_hr_video: torch.Tensor) -> None:
+        assert fake_lr_video.size(0) == real_lr_video.size(0) == real_hr_video.size(0)
+        assert fake_lr_video.size(0) % self.D_grad_accum == 0
+        fake_lr_video, real_lr_video = self._jitter(fake_lr_video), self._jitter(real_lr_video)
+        fake_hr_video = self.G(fake_lr_video, magnitude_ema_beta=self.G_magnitude_ema_beta)    # G frozen: no graph is built
+        fake_lr_video, real_lr_video = self.crop_to_seq_length(fake_lr_video), self.crop_to_seq_length(real_lr_video)
+        self.D.requires_grad_(True)
+        self.D_sync.zero()
+        parts = [t.chunk(self.D_grad_accum) for t in (fake_lr_video, fake_hr_video, real_lr_video, real_hr_video)]
+        for k, (f_lr, f_hr, r_lr, r_hr) in enumerate(zip(*parts)):
+            F.softplus(self.run_D(f_lr, f_hr)).mean().backward()
+            real_logits = self.run_D(r_lr, r_hr)
+            if k == self.D_grad_accum - 1 and self.D_sync.overlap:
+                self.D_sync.arm()
+            F.softplus(-real_logits).mean().backward()
+            with torch.no_grad():
+                self._real_sign_sum += torch.stack((real_logits.sign().sum(), real_logits.new_tensor(float(real_logits.numel()))))
+        self.D.requires_grad_(False)
+        self.D_sync.finish(gain=1 / self.D_grad_accum)
+        self.D_opt.step()
+
+    def update_r1(self, lr_video: torch.Tensor, hr_video: torch.Tensor, gain: float = 1.0) -> None:
+        assert lr_video.size(0) == hr_video.size(0) and lr_video.size(0) % self.D_grad_accum == 0
+        lr_video = self._jitter(lr_video)
+        self.D.requires_grad_(True)
+        self.D_sync.zero()
+        pairs = list(zip(lr_video.chunk(self.D_grad_accum), hr_video.chunk(self.D_grad_accum)))
+        for k, (lr, hr) in enumerate(pairs):
+            hr = hr.detach().requires_grad_(True)
+            logits = self.run_D(lr, hr)
+            (grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[hr], create_graph=True)
+            penalty = grad.square().sum(dim=(1, 2, 3, 4))
+            if k == len(pairs) - 1 and self.D_sync.overlap:
+                self.D_sync.arm()
+            (penalty * (self.r1_gamma / 2)).mean().backward()
+        self.D.requires_grad_(False)
+        self.D_sync.finish(gain=gain / self.D_grad_accum)
+        self.D_opt.step()
+
+    @torch.no_grad()
+    def update_ada(self, gain: float = 1.0) -> None:
+        """p += rate * gain * sign(mean sign of the real logits since the last call - target), clamped to [0, p_max]."""
+        if self.augment is None or self.augment_real_sign_target is None:
+            return
+        stats = ddp.sharded_all_mean(self._real_sign_sum.clone()) if torch.distributed.is_initialized() else self._real_sign_sum
+        if float(stats[1]) > 0:
+            mean_sign = float(stats[0] / stats[1])
+            step = math.copysign(self.augment_p_update_rate, mean_sign - self.augment_real_sign_target) * gain
+            self.augment.p.add_(step).clamp_(0, self.augment_p_max)
+        self._real_sign_sum.zero_()
+
+    @torch.no_grad()
+    def update_G_ema(self, step: int) -> None:
+        if self.G_ema is None:
+            return
+        halflife = math.log(self.G_ema_beta, 0.5) * (self.G_ema_warmup_steps + 1) / (step + 1)
+        beta = min(0.5 ** halflife, self.G_ema_beta)
+        src = list(self.G.parameters()) + list(self.G.buffers())
+        dst = list(self.G_ema.parameters()) + list(self.G_ema.buffers())
+        torch._foreach_lerp_(dst, src, 1.0 - beta)
+
+    def train_step(self, step: int, lr_video: torch.Tensor, hr_video: torch.Tensor, r1_interval: int = 16, ada_interval: int = 4) -> None:
+        """One iteration of the reference loop (train_sres.py:241-264) on one (lr with context, hr) batch."""
+        self.update_G(lr_video)
+        self.update_D(lr_video, lr_video, hr_video)
+        if r1_interval > 0 and step % r1_interval == 0:
+            self.update_r1(self.crop_to_seq_length(lr_video), hr_video, gain=r1_interval)
+        if ada_interval > 0 and step % ada_interval == 0:
+            self.update_ada(gain=ada_interval)
+        self.update_G_ema(step)

@@ -86,6 +86,8 @@ def test_fixed_quantile_transforms_match_reference_gpu():
 def test_r1_style_double_backward_through_augment_gpu():
     """R1 differentiates the discriminator input gradient again: second-order through the HIP
     upfirdn2d up/down pair and grid_sample must exist and be finite."""
+    from torch_utils.ops import grid_sample_gradfix
+    grid_sample_gradfix.enabled = True                                       # as the train scripts do
     pipe = AugmentPipe(**TRAIN_SRES_KW).cuda()
     v = sample_video().cuda().requires_grad_(True)
     w = torch.randn(1, 3, 1, 1, 1, device='cuda', requires_grad=True)

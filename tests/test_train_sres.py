@@ -1,0 +1,76 @@
+"""Super-resolution training step (lvg.train_sres.SuperResTrainer): generator update through the
+ADA-augmented discriminator, discriminator update, R1 (double backward through ADA's upfirdn2d /
+grid_sample and the discriminator's resampling convs), ADA probability control and the generator
+EMA, on synthetic clips. CPU run = plain-PyTorch ops at reduced width; GPU run = HIP kernels."""
+
+import pytest
+import torch
+
+from helpers.ada_cfg import TRAIN_SRES_KW
+
+from lvg.train_sres import SuperResTrainer
+
+SMALL = dict(seq_length=2, temporal_context=1, lr_height=9, lr_width=16, hr_height=36, hr_width=64,
+             G_kwargs=dict(latent_z_dim=32, latent_w_dim=48, channel_base=1024, channel_max=24, num_fp16_res=2),
+             D_kwargs=dict(channels_base=1024, channels_max=32, num_fp16_res=0),
+             augment_kwargs=TRAIN_SRES_KW, augment_p_init=0.3, overlap_grad_sync=False)
+
+
+def _step(device, dtype):
+    torch.manual_seed(0)
+    tr = SuperResTrainer(device=device, compute_dtype=dtype, **SMALL)
+    g0 = [p.detach().clone() for p in tr.G.parameters()]
+    d0 = [p.detach().clone() for p in tr.D.parameters()]
+    lr = torch.rand(2, 3, 4, 9, 16, device=device) * 2 - 1
+    hr = torch.rand(2, 3, 2, 36, 64, device=device) * 2 - 1
+    p0 = float(tr.augment.p)
+    tr.train_step(step=0, lr_video=lr, hr_video=hr, r1_interval=16, ada_interval=4)
+    for p in list(tr.G.parameters()) + list(tr.D.parameters()):
+        assert torch.isfinite(p).all()
+    assert sum(int(not torch.equal(a, b)) for a, b in zip(g0, tr.G.parameters())) > len(g0) // 2
+    assert sum(int(not torch.equal(a, b)) for a, b in zip(d0, tr.D.parameters())) > len(d0) // 2
+    assert abs(abs(float(tr.augment.p) - p0) - 4 * tr.augment_p_update_rate) < 1e-7      # moved by rate * ada_interval
+    mags = [float(l.magnitude_ema) for l in tr.G.SG3.synthesis.layers()]
+    assert any(m != 1.0 for m in mags)                                                  # update_D tracked the magnitudes
+    ema = dict(tr.G_ema.named_parameters())
+    name, p = next(iter(tr.G.named_parameters()))
+    assert not torch.equal(ema[name], p)                                                # EMA lags the updated weights
+    return tr
+
+
+def test_train_step_cpu():
+    torch.set_num_threads(8)
+    tr = _step('cpu', torch.float32)
+    # ADA control law: real logits mostly positive -> p rises, mostly negative -> p falls, clamped to [0, p_max]
+    tr.augment.p.fill_(0.4999)
+    tr._real_sign_sum.copy_(torch.tensor([8.0, 8.0]))
+    tr.update_ada(gain=4)
+    assert float(tr.augment.p) == pytest.approx(0.5)
+    tr._real_sign_sum.copy_(torch.tensor([-8.0, 8.0]))
+    tr.update_ada(gain=4)
+    assert float(tr.augment.p) == pytest.approx(0.5 - 4 * 0.000125)
+    p = float(tr.augment.p)
+    tr.update_ada(gain=4)                                                               # nothing collected: unchanged
+    assert float(tr.augment.p) == p
+
+
+def test_run_D_applies_one_transform_to_both_clips_cpu():
+    torch.manual_seed(1)
+    tr = SuperResTrainer(device='cpu', compute_dtype=torch.float32, **dict(SMALL, lr_cond_prob=1.0, in_augment_strength=0.0))
+    tr.augment.p.fill_(1.0)
+    seen = {}
+    orig = tr.D.forward
+    tr.D.forward = lambda lr_up, hr: seen.update(lr=lr_up, hr=hr) or orig(lr_up, hr)
+    hr = torch.rand(1, 3, 2, 36, 64) * 2 - 1
+    lr = torch.nn.functional.avg_pool3d(hr, (1, 4, 4))
+    tr.run_D(lr, tr.D.upsample(lr) * 0 + hr)                       # hr clip == a clip at hr size; lr its 4x box average
+    # both halves came out of one AugmentPipe call: same geometry => the augmented lr stays the blur of the augmented hr
+    a, b = seen['lr'], seen['hr']
+    assert a.shape == b.shape == (1, 3, 2, 36, 64)
+    corr = torch.corrcoef(torch.stack((a.flatten(), torch.nn.functional.avg_pool3d(b, (1, 5, 5), stride=1, padding=(0, 2, 2)).flatten())))[0, 1]
+    assert float(corr) > 0.5
+
+
+@pytest.mark.gpu
+def test_train_step_gpu_fp16():
+    _step('cuda', torch.float16)
