@@ -1,102 +1,100 @@
-"""2-D convolution with optional FIR up/downsampling (`torch_utils.ops.conv2d_resample`,
-reference torch_utils/ops/conv2d_resample.py:46-141). The dense contraction goes to
-`conv2d_gradfix` (MIOpen); the resampling filters go to the HIP `upfirdn2d`. The order of
-filter and convolution is chosen per case so that the convolution runs at the lower resolution."""
+"""`torch_utils.ops.conv2d_resample`: 2-D convolution combined with FIR up / down-sampling
+(reference torch_utils/ops/conv2d_resample.py:46-141). The dense contraction goes to
+`conv2d_gradfix` (MIOpen, MFMA), every resampling filter to the HIP `upfirdn2d`. Filter and
+convolution are ordered per case so that the contraction always runs at the LOWER resolution:
+
+    1x1 weight, down     decimate (filter)        -> convolve
+    1x1 weight, up       convolve                 -> interpolate (filter)
+    k x k,     down      blur at full resolution  -> strided convolution
+    any,       up        transposed strided conv  -> blur (-> decimate)
+    no resampling        plain convolution (symmetric padding) or explicit pad -> convolve"""
 
 import torch
 
 from .. import misc
 from . import conv2d_gradfix
 from . import upfirdn2d
-from .upfirdn2d import _parse_padding
-from .upfirdn2d import _get_filter_size
+from .upfirdn2d import _get_filter_size, _parse_padding
 
-#----------------------------------------------------------------------------
 
 def _get_weight_shape(w):
-    with misc.suppress_tracer_warnings(): # constant under tracing
+    with misc.suppress_tracer_warnings():  # constant under tracing
         shape = [int(sz) for sz in w.shape]
     misc.assert_shape(w, shape)
     return shape
 
-def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
-    """conv2d / conv_transpose2d; `flip_weight=True` is correlation (what conv2d does natively),
-    False flips the spatial taps first to get true convolution."""
-    _oc, _icpg, kh, kw = _get_weight_shape(w)
-    if not flip_weight and (kw > 1 or kh > 1):
-        w = w.flip([2, 3])
-    op = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
-    return op(x, w, stride=stride, padding=padding, groups=groups)
 
-#----------------------------------------------------------------------------
+def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+    """conv2d / conv_transpose2d. `flip_weight=True` means correlation (what the library computes),
+    False mirrors the taps first, i.e. a true convolution."""
+    kh, kw = _get_weight_shape(w)[2:]
+    if (kh > 1 or kw > 1) and not flip_weight:
+        w = w.flip([2, 3])
+    run = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
+    return run(x, w, stride=stride, padding=padding, groups=groups)
+
+
+def _delay_compensated_padding(padding, fw, fh, up, down):
+    """User padding plus the group delay of the resampling filter (same rule as upsample2d / downsample2d)."""
+    pad = list(_parse_padding(padding))                     # x0, x1, y0, y1
+    for axis, taps in ((0, fw), (2, fh)):
+        if up > 1:
+            pad[axis] += (taps + up - 1) // 2
+            pad[axis + 1] += (taps - up) // 2
+        if down > 1:
+            pad[axis] += (taps - down + 1) // 2
+            pad[axis + 1] += (taps - down) // 2
+    return pad
+
+
+def _swap_in_out_channels(w, groups):
+    """Weight layout conv_transpose2d expects: [Cin, Cout/groups, kh, kw]."""
+    if groups == 1:
+        return w.transpose(0, 1)
+    cout, cin_g, kh, kw = _get_weight_shape(w)
+    w = w.reshape(groups, cout // groups, cin_g, kh, kw).transpose(1, 2)
+    return w.reshape(groups * cin_g, cout // groups, kh, kw)
+
 
 @misc.profiled_function
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
-    r"""x: [N, Cin, H, W]; w: [Cout, Cin//groups, kh, kw] (x's dtype); f: filter from
-    `upfirdn2d.setup_filter()` or None; up/down: integer factors; padding (int, [x, y] or
-    [x0, x1, y0, y1]) is relative to the up-sampled image and applied once, up front."""
-    assert isinstance(x, torch.Tensor) and (x.ndim == 4)
-    assert isinstance(w, torch.Tensor) and (w.ndim == 4) and (w.dtype == x.dtype)
-    assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
-    assert isinstance(up, int) and (up >= 1)
-    assert isinstance(down, int) and (down >= 1)
-    assert isinstance(groups, int) and (groups >= 1)
-    out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
+    r"""x: [N, Cin, H, W]; w: [Cout, Cin//groups, kh, kw] in x's dtype; f: filter from
+    `upfirdn2d.setup_filter()` or None; up / down: integer factors; padding (int, [x, y] or
+    [x0, x1, y0, y1]) is measured on the up-sampled image."""
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    assert f is None or (isinstance(f, torch.Tensor) and f.ndim in (1, 2) and f.dtype == torch.float32)
+    for name, value in (('up', up), ('down', down), ('groups', groups)):
+        assert isinstance(value, int) and value >= 1, name
+    kh, kw = _get_weight_shape(w)[2:]
     fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
+    px0, px1, py0, py1 = _delay_compensated_padding(padding, fw, fh, up, down)
+    fir = dict(f=f, flip_filter=flip_filter)
+    conv = dict(w=w, groups=groups, flip_weight=flip_weight)
+    pointwise = kh == 1 and kw == 1
 
-    # Filter delay compensation, same rule as upsample2d / downsample2d.
-    if up > 1:
-        px0 += (fw + up - 1) // 2; px1 += (fw - up) // 2
-        py0 += (fh + up - 1) // 2; py1 += (fh - up) // 2
-    if down > 1:
-        px0 += (fw - down + 1) // 2; px1 += (fw - down) // 2
-        py0 += (fh - down + 1) // 2; py1 += (fh - down) // 2
-
-    pointwise = (kw == 1 and kh == 1)
-
-    if pointwise and down > 1 and up == 1:
-        # 1x1 commutes with the filter: decimate first, contract on the small image.
-        x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-
-    if pointwise and up > 1 and down == 1:
-        # contract on the small image, then upsample.
-        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-        return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=[px0, px1, py0, py1], gain=up**2, flip_filter=flip_filter)
-
-    if down > 1 and up == 1:
-        # blur at full resolution, then a strided convolution does the decimation.
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
+    if up == 1 and down > 1:
+        if pointwise:       # a 1x1 contraction commutes with the filter: decimate first
+            x = upfirdn2d.upfirdn2d(x=x, down=down, padding=[px0, px1, py0, py1], **fir)
+            return _conv2d_wrapper(x=x, **conv)
+        x = upfirdn2d.upfirdn2d(x=x, padding=[px0, px1, py0, py1], **fir)
+        return _conv2d_wrapper(x=x, stride=down, **conv)
 
     if up > 1:
-        # transposed strided convolution does the zero insertion, then blur (and decimate).
-        if groups == 1:
-            w = w.transpose(0, 1)
-        else:
-            w = w.reshape(groups, out_channels // groups, in_channels_per_group, kh, kw)
-            w = w.transpose(1, 2)
-            w = w.reshape(groups * in_channels_per_group, out_channels // groups, kh, kw)
-        px0 -= kw - 1; px1 -= kw - up
-        py0 -= kh - 1; py1 -= kh - up
-        pxt = max(min(-px0, -px1), 0)
-        pyt = max(min(-py0, -py1), 0)
-        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up**2, flip_filter=flip_filter)
-        if down > 1:
-            x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
-        return x
+        if pointwise and down == 1:
+            x = _conv2d_wrapper(x=x, **conv)
+            return upfirdn2d.upfirdn2d(x=x, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, **fir)
+        # the transposed strided convolution inserts the zeros; what it cannot pad away is left to the filter
+        px0, px1 = px0 - (kw - 1), px1 - (kw - up)
+        py0, py1 = py0 - (kh - 1), py1 - (kh - up)
+        crop_x, crop_y = max(min(-px0, -px1), 0), max(min(-py0, -py1), 0)
+        x = _conv2d_wrapper(x=x, w=_swap_in_out_channels(w, groups), stride=up, padding=[crop_y, crop_x], groups=groups,
+                            transpose=True, flip_weight=not flip_weight)
+        x = upfirdn2d.upfirdn2d(x=x, padding=[px0 + crop_x, px1 + crop_x, py0 + crop_y, py1 + crop_y], gain=up ** 2, **fir)
+        return upfirdn2d.upfirdn2d(x=x, down=down, **fir) if down > 1 else x
 
-    if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-        # no resampling and symmetric non-negative padding: plain convolution.
-        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
-
-    # anything else: explicit pad/crop, convolve, decimate.
-    x = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=[px0, px1, py0, py1], gain=up**2, flip_filter=flip_filter)
-    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-    if down > 1:
-        x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
-    return x
-
-#----------------------------------------------------------------------------
+    # up == down == 1
+    if px0 == px1 >= 0 and py0 == py1 >= 0:
+        return _conv2d_wrapper(x=x, padding=[py0, px0], **conv)
+    x = upfirdn2d.upfirdn2d(x=x, f=None, padding=[px0, px1, py0, py1], flip_filter=flip_filter)    # pad / crop only
+    return _conv2d_wrapper(x=x, **conv)
