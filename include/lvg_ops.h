@@ -9,6 +9,7 @@
  *   lvg_upfirdn2d           <- upfirdn2d()           torch_utils/ops/upfirdn2d.cpp:16
  *   lvg_filtered_lrelu      <- filtered_lrelu()      torch_utils/ops/filtered_lrelu.cpp:16
  *   lvg_filtered_lrelu_act  <- filtered_lrelu_act_() torch_utils/ops/filtered_lrelu.cpp:213
+ *   lvg_tapconv_epilogue[_backward]  (same, with the temporal-tap sum of a tap-stacked convolution)
  *   lvg_modconv_epilogue[_backward]  (no pybind counterpart: fuses the modulated-conv epilogue the
  *                           reference spells in Python, model/generator_lres.py:101-123,570-574)
  *
@@ -149,6 +150,32 @@ int lvg_modconv_epilogue_backward(const void* dout, const void* y, const float* 
                                   void* dy, float* d_pre, float* d_post, float* d_sum,
                                   int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
                                   float alpha, float gain, float clamp, void* stream);
+
+/*
+ * Temporal-tap gather fused with the epilogue above (channels-last only). A kt x kh x kw convolution over
+ * time-major frames is run as ONE 2-D convolution whose output channels stack the kt taps,
+ * z [frames, pixels, taps*channels] (tap-major); this entry point performs the temporal sum while applying
+ * the epilogue:
+ *   ysum[f,p,c] = sum_k z[f + (k - taps/2) * tap_shift, p, k*channels + c]     (frames outside -> 0)
+ *   out[f,p,c]  = clamp(act(ysum * pre[f,c] + b[c] + res[f,p,c]) * gain, +-clamp) * post[f,c];  msq[f] as above
+ * res (layout of out) and ysum (saved for the backward pass) may be NULL. tap_shift = frames per time step.
+ * Replaces, next to the sequence cited for lvg_modconv_epilogue, the accumulation of the per-tap
+ * convolution outputs (the reference's conv3d does it inside cuDNN: model/generator_lres.py:119).
+ */
+int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const void* res, const float* post,
+                         void* out, void* ysum, float* msq,
+                         int64_t frames, int channels, int pixels, int taps, int64_t tap_shift,
+                         int dtype, int act, float alpha, float gain, float clamp, void* stream);
+
+/*
+ * Backward of lvg_tapconv_epilogue from dout and the saved ysum; the gradient is written already scattered
+ * into the tap-stacked layout, dz[f + (k - taps/2) * tap_shift, p, k*channels + c] = dy[f,p,c] (zeros where
+ * the source frame lies outside), every element of dz exactly once. d_pre / d_post / d_sum as above.
+ */
+int lvg_tapconv_epilogue_backward(const void* dout, const void* ysum, const float* pre, const void* b, const void* res,
+                                  const float* post, void* dz, float* d_pre, float* d_post, float* d_sum,
+                                  int64_t frames, int channels, int pixels, int taps, int64_t tap_shift,
+                                  int dtype, int act, float alpha, float gain, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

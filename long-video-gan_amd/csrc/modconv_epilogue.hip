@@ -23,90 +23,12 @@
 //
 // Roofline: pure stream. Algorithmic bytes per element: forward 2*s, backward 3*s (s = sizeof(T)).
 
-#include "lvg_common.h"
-#include <algorithm>
+#include "epilogue_common.h"
 
 namespace {
 
-struct EpilogueArgs
-{
-    const void*  y;
-    const float* pre;      // [frames, channels] or NULL (= 1)
-    const void*  b;        // [channels] in T or NULL (= 0)
-    const float* post;     // [frames, channels] or NULL (= 1)
-    void*        out;
-    float*       msq;      // forward: [frames] floats, atomically accumulated (zeroed by the caller); or NULL
-    const void*  dout;     // backward only
-    void*        dy;
-    float*       d_pre;    // [frames, channels], zero-initialised by the caller
-    float*       d_post;
-    float*       d_sum;
-    int64_t      frames;
-    int          channels;
-    int          pixels;
-    int64_t      strideF;  // element strides (plane kernels)
-    int64_t      strideC;
-    int64_t      strideP;
-    int64_t      frameVecs;  // channels-last kernels: 16-byte vectors per frame
-    int          chunkVecs;  //                       vectors per block
-    float        alpha, gain, clamp;
-};
-
-constexpr int kThreads = 256;
-
-template <int ACT> __device__ __forceinline__ float act_fwd(float u, float alpha)
-{
-    if (ACT == LVG_ACT_RELU)  return u > 0.f ? u : 0.f;
-    if (ACT == LVG_ACT_LRELU) return u > 0.f ? u : u * alpha;
-    return u;
-}
-template <int ACT> __device__ __forceinline__ float act_slope(float u, float alpha)
-{
-    if (ACT == LVG_ACT_RELU)  return u > 0.f ? 1.f : 0.f;
-    if (ACT == LVG_ACT_LRELU) return u > 0.f ? 1.f : alpha;
-    return 1.f;
-}
-
-// Forward value before `post`, and whether the clamp was hit.
-template <int ACT> __device__ __forceinline__ float epi_value(float y, float pre, float b, float alpha, float gain, float clamp, bool& inside)
-{
-    float g = act_fwd<ACT>(fmaf(y, pre, b), alpha) * gain;
-    inside = true;
-    if (clamp >= 0.f)
-    {
-        inside = (g > -clamp && g < clamp);
-        if (!inside) g = (g >= 0.f) ? clamp : -clamp;
-    }
-    return g;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Channels-last kernels. grid = (chunks per frame, frames).
-
-template <class T> struct ChanVec
-{
-    static constexpr int V = Elem<T>::kVec;
-    float pre[V], post[V], b[V];
-};
-
-template <class T> __device__ __forceinline__ void load_chan(const EpilogueArgs& p, int64_t f, int c0, ChanVec<T>& k)
-{
-    constexpr int V = Elem<T>::kVec;
-    const int64_t fc = f * p.channels + c0;
-    #pragma unroll
-    for (int i = 0; i < V; i++)
-    {
-        k.pre[i]  = p.pre  ? p.pre[fc + i]  : 1.f;
-        k.post[i] = p.post ? p.post[fc + i] : 1.f;
-        k.b[i]    = p.b    ? to_acc(static_cast<const T*>(p.b)[c0 + i]) : 0.f;
-    }
-}
 
 template <class T, int ACT>
 __global__ __launch_bounds__(kThreads) void epilogue_cl_fwd_kernel(EpilogueArgs p)
@@ -324,13 +246,7 @@ int launch(EpilogueArgs& p, bool backward, bool channelsLast, hipStream_t stream
     if (vec)
     {
         p.frameVecs = (int64_t)p.pixels * cv;
-        // A block streams up to 32 vectors per thread (few atomics per byte moved); a frame is split
-        // into EQUAL chunks (multiples of the block size, so a thread keeps its channel-vector), and
-        // lres-sized frames (9x16x512 ... 36x64x64) give >= frames blocks to fill 256 CUs.
-        int64_t chunks = lvg_ceil_div(p.frameVecs, kThreads * 32);
-        if (p.frames * chunks < 2048)                        // few small frames: split further to fill the chip
-            chunks = std::max<int64_t>(chunks, std::min<int64_t>(lvg_ceil_div(2048, p.frames), lvg_ceil_div(p.frameVecs, kThreads)));
-        p.chunkVecs = (int)(lvg_ceil_div(lvg_ceil_div(p.frameVecs, chunks), kThreads) * kThreads);
+        p.chunkVecs = epilogue_chunk_vecs(p.frameVecs, p.frames);
         dim3 grid((unsigned)lvg_ceil_div(p.frameVecs, p.chunkVecs), (unsigned)p.frames);
         if (backward) hipLaunchKernelGGL((epilogue_cl_bwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);
         else          hipLaunchKernelGGL((epilogue_cl_fwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);

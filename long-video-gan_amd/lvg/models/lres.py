@@ -29,7 +29,7 @@ import torch_utils.distributed as dist_utils
 import contextlib
 
 from torch_utils.ops import bias_act, upfirdn2d
-from torch_utils.ops.modconv_epilogue import modconv_epilogue
+from torch_utils.ops.modconv_epilogue import modconv_epilogue, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
 
@@ -343,6 +343,70 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
     return _TemporalConvFrames.apply(x, weight, n, tuple(padding_hw))
 
 
+# Tap-stacked form of the temporal convolution (default off until its MIOpen find-db entries are recorded
+# and measured on MI355X): ONE 2-D convolution with kt*Co output channels, the temporal sum folded into the
+# epilogue kernel (csrc/tapconv_epilogue.hip) instead of kt - 1 accumulate passes.
+TAP_STACK = os.environ.get('LVG_TAP_STACK', '0') == '1'
+
+
+def stack_taps(weight: torch.Tensor) -> torch.Tensor:
+    """[Co, Ci, kt, kh, kw] -> [kt*Co, Ci, kh, kw], tap-major along the output channels."""
+    co, ci, kt, kh, kw = weight.shape
+    return weight.permute(2, 0, 1, 3, 4).reshape(kt * co, ci, kh, kw)
+
+
+class _TapConvEpilogue(torch.autograd.Function):
+    """conv3d ('same' in time) + modulated-conv epilogue on time-major frames:
+    out = clamp(act(conv(x, w) * pre + b + res) * gain) * post. First-order gradients only (generator path)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pre, b, res, post, n, padding_hw, act, clamp, want_msq):
+        kt = weight.shape[2]
+        wst = _cl(stack_taps(weight))
+        z = _cl(F.conv2d(_cl(x), wst, padding=padding_hw))
+        out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq)
+        ctx.save_for_backward(x, weight, ysum, pre, b, res, post)
+        ctx.cfg = (n, list(padding_hw), act, clamp)
+        if want_msq:
+            ctx.mark_non_differentiable(msq)
+        return out, msq
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout, _dmsq):
+        x, weight, ysum, pre, b, res, post = ctx.saved_tensors
+        n, pad, act, clamp = ctx.cfg
+        co, ci, kt, kh, kw = weight.shape
+        need = ctx.needs_input_grad
+        dz, d_pre, d_post, d_sum = tap_gather_backward(dout, ysum, pre, b, res, post, kt, n, act=act, clamp=clamp)
+        gx, gwst, _ = torch.ops.aten.convolution_backward(
+            _cl(dz), _cl(x), _cl(stack_taps(weight)), None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need[0], need[1], False])
+        gw = gwst.reshape(kt, co, ci, kh, kw).permute(1, 2, 0, 3, 4) if need[1] else None
+        d_b = d_sum.sum(dim=0).to(b.dtype) if (b is not None and need[3]) else None
+        d_res = None
+        if res is not None and need[4]:
+            assert act == 'linear' and clamp is None and post is None, 'residual gradient: linear epilogue only'
+            d_res = dout
+        return gx, gw, (d_pre if need[2] else None), d_b, d_res, (d_post if need[5] else None), None, None, None, None, None
+
+
+def temporal_conv_epilogue(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw, pre: Optional[torch.Tensor] = None,
+                           b: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, post: Optional[torch.Tensor] = None,
+                           act: str = 'linear', clamp: Optional[float] = None, want_msq: bool = False):
+    """conv3d with 'same' zero padding in time followed by the fused epilogue
+    `clamp(act(y * pre + b + res) * gain) * post` (pre / post float32 [(T N), C], res like the output).
+    Returns `out` or `(out, mean_square)`. With TAP_STACK the kt taps are one convolution and their sum is
+    taken inside the epilogue kernel; otherwise kt convolutions are accumulated and the epilogue runs on the sum."""
+    if TAP_STACK and weight.shape[2] > 1 and (res is None or (act == 'linear' and clamp is None and post is None)):
+        out, msq = _TapConvEpilogue.apply(x, weight, pre, b, res, post, n, tuple(padding_hw), act, clamp, bool(want_msq))
+        return (out, msq) if want_msq else out
+    y = temporal_conv_frames(x, weight, n, padding_hw)
+    if res is not None:
+        assert b is None and post is None and act == 'linear' and clamp is None and not want_msq
+        return torch.addcmul(res, y, pre.to(y.dtype).reshape(y.shape[0], -1, 1, 1))
+    return modconv_epilogue(y, pre=pre, b=b, post=post, act=act, clamp=clamp, want_msq=want_msq)
+
+
 class _CropFrames(torch.autograd.Function):
     """Centre crop of frames / rows / columns whose backward writes the gradient into a zero tensor of the
     INPUT's memory format (autograd's slice backward always produces NCHW-contiguous zeros)."""
@@ -590,22 +654,21 @@ class Synthesis3dResBlock(nn.Module):
         if self.magnitude_ema:
             gain_0 = self.input_magnitude_ema_0.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_0(x)
         xm = xm[0] if track else xm
-        y0 = temporal_conv_frames(xm, w0.to(dtype), n, self.padding[1:])
-        # demodulation * input gain, bias, activation, clamp, AND the modulation of conv 1 in one pass
-        hm = modconv_epilogue(y0, pre=(demod_0 if gain_0 is None else demod_0 * gain_0), b=self.bias_0.to(dtype), post=mod_1,
-                              act=self.activation, clamp=self.activation_clamp, want_msq=track)
+        # conv 0 and its epilogue: demodulation * input gain, bias, activation, clamp AND the modulation of conv 1
+        hm = temporal_conv_epilogue(xm, w0.to(dtype), n, self.padding[1:], pre=(demod_0 if gain_0 is None else demod_0 * gain_0),
+                                    b=self.bias_0.to(dtype), post=mod_1, act=self.activation, clamp=self.activation_clamp, want_msq=track)
         gain_1 = None
         if self.magnitude_ema:
             gain_1 = self.input_magnitude_ema_1.update(hm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_1.magnitude_ema.rsqrt()
         hm = hm[0] if track else hm
-        y1 = temporal_conv_frames(hm, w1.to(dtype), n, self.padding[1:])
 
         w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
         if gain_0 is not None:
             w_skip = w_skip * gain_0
         skip = F.conv2d(x, _cl(w_skip.to(dtype)))
+        # conv 1: h = skip + conv * (demodulation * gain * sqrt(1/2)), one pass
         scale_1 = demod_1 * SQRT_HALF if gain_1 is None else demod_1 * (gain_1 * SQRT_HALF)
-        h = torch.addcmul(skip, y1, scale_1.to(dtype).reshape(t * n, -1, 1, 1))
+        h = temporal_conv_epilogue(hm, w1.to(dtype), n, self.padding[1:], pre=scale_1, res=skip)
         if self.temporal_up:
             h = resample_time_frames(h, self.temporal_upsample.filter, n, up=self.temporal_upsample.scale)
         h = crop_frames(h, n, seq_length=out_seq_length)

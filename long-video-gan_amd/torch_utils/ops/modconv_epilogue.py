@@ -42,13 +42,15 @@ def _resolve(act, alpha, gain, clamp):
     return spec, alpha, gain, clamp
 
 
-def _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq):
+def _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq, res=None):
     """Plain-PyTorch definition (float32 arithmetic, one rounding at the end)."""
     u = y.float()
     if pre is not None:
         u = u * pre[:, :, None, None]
     if b is not None:
         u = u + b.float()[None, :, None, None]
+    if res is not None:
+        u = u + res.float()
     if act == 'relu':
         u = torch.relu(u)
     elif act == 'lrelu':
@@ -154,3 +156,97 @@ def modconv_epilogue(y, pre=None, b=None, post=None, act='linear', alpha=None, g
     else:
         out, msq = _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq)
     return (out, msq) if want_msq else out
+
+
+# ----------------------------------------------------------------------------------------------------
+# Temporal-tap gather + epilogue (csrc/tapconv_epilogue.hip). z [(T N), taps*C, H, W] channels-last holds the
+# output of ONE 2-D convolution whose output channels stack the temporal taps (tap-major); frame f of the
+# result sums tap k from frame f + (k - taps//2) * shift. These two functions are the launch-level interface
+# (used by lvg.models.lres._TapConvEpilogue); CPU tensors take the explicit PyTorch formulas below, which
+# are also what the GPU tests compare against.
+
+def _tap_ranges(k, taps, shift, total):
+    """(source frames of z, destination frames of the sum) for tap k, or None if they never overlap."""
+    d = (k - taps // 2) * shift
+    if abs(d) >= total:
+        return None
+    if d == 0:
+        return slice(None), slice(None)
+    return (slice(d, None), slice(None, -d)) if d > 0 else (slice(None, d), slice(-d, None))
+
+
+def tap_gather_forward(z, pre, b, res, post, taps, shift, act='linear', alpha=None, gain=None, clamp=None, want_msq=False, keep_sum=True):
+    """-> (out, ysum | None, mean_square | None). out/ysum: [(T N), C, H, W] in z's dtype and memory format."""
+    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+    f, kc, h, w = z.shape
+    c = kc // taps
+    assert c * taps == kc
+    if z.device.type == 'cuda' and _init():
+        assert z.is_contiguous(memory_format=torch.channels_last), 'tap gather needs channels-last z'
+        out = torch.empty((f, c, h, w), dtype=z.dtype, device=z.device, memory_format=torch.channels_last)
+        ysum = torch.empty_like(out) if keep_sum else None
+        msq = torch.zeros(f, dtype=torch.float32, device=z.device) if want_msq else None
+        if res is not None:
+            res = res.contiguous(memory_format=torch.channels_last)
+        with torch.cuda.device(z.device):
+            rc = _hip.lib().lvg_tapconv_epilogue(
+                z.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(res), _hip.ptr(post), out.data_ptr(), _hip.ptr(ysum), _hip.ptr(msq),
+                f, c, h * w, taps, shift, _hip.dtype_code(z.dtype), spec.cuda_idx, alpha, gain, clamp, _hip.stream(z.device))
+        _hip.check(rc, 'tapconv_epilogue')
+        return out, ysum, (msq.sum() / float(out.numel()) if want_msq else None)
+    ysum = torch.zeros((f, c, h, w), dtype=torch.float32, device=z.device)
+    for k in range(taps):
+        r = _tap_ranges(k, taps, shift, f)
+        if r is not None:
+            ysum[r[1]] += z[r[0], k * c:(k + 1) * c].float()
+    ysum = ysum.to(z.dtype)                                   # what the kernel saves (rounded); `out` uses the exact sum
+    out, msq = _ref(ysum, pre, b, post, act, alpha, gain, clamp, want_msq, res=res)
+    return out, (ysum if keep_sum else None), msq
+
+
+def tap_gather_backward(dout, ysum, pre, b, res, post, taps, shift, act='linear', alpha=None, gain=None, clamp=None):
+    """-> (dz [(T N), taps*C, H, W], d_pre | None, d_post | None, d_sum [(T N), C]); float32 reductions."""
+    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+    f, c, h, w = ysum.shape
+    if ysum.device.type == 'cuda' and _init():
+        dout = dout.contiguous(memory_format=torch.channels_last)
+        assert ysum.is_contiguous(memory_format=torch.channels_last) and dout.dtype == ysum.dtype
+        dz = torch.empty((f, taps * c, h, w), dtype=ysum.dtype, device=ysum.device, memory_format=torch.channels_last)
+        red = torch.zeros(3, f, c, dtype=torch.float32, device=ysum.device)
+        if res is not None:
+            res = res.contiguous(memory_format=torch.channels_last)
+        with torch.cuda.device(ysum.device):
+            rc = _hip.lib().lvg_tapconv_epilogue_backward(
+                dout.data_ptr(), ysum.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(res), _hip.ptr(post), dz.data_ptr(),
+                red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
+                f, c, h * w, taps, shift, _hip.dtype_code(ysum.dtype), spec.cuda_idx, alpha, gain, clamp, _hip.stream(ysum.device))
+        _hip.check(rc, 'tapconv_epilogue_backward')
+        return dz, (red[0] if pre is not None else None), (red[1] if post is not None else None), red[2]
+    y = ysum.float()
+    u = y if pre is None else y * pre[:, :, None, None]
+    if b is not None:
+        u = u + b.float()[None, :, None, None]
+    if res is not None:
+        u = u + res.float()
+    if act == 'relu':
+        a, slope = torch.relu(u), (u > 0).float()
+    elif act == 'lrelu':
+        a, slope = torch.nn.functional.leaky_relu(u, alpha), torch.where(u > 0, torch.ones_like(u), torch.full_like(u, alpha))
+    else:
+        a, slope = u, torch.ones_like(u)
+    g = a * gain
+    inside = torch.ones_like(g) if clamp < 0 else ((g > -clamp) & (g < clamp)).float()
+    gc = g if clamp < 0 else g.clamp(-clamp, clamp)
+    go = dout.float()
+    du = go * inside * gain * slope
+    if post is not None:
+        du = du * post[:, :, None, None]
+    dy = du if pre is None else du * pre[:, :, None, None]
+    dz = torch.zeros((f, taps * c, h, w), dtype=torch.float32, device=ysum.device)
+    for k in range(taps):
+        r = _tap_ranges(k, taps, shift, f)
+        if r is not None:
+            dz[r[0], k * c:(k + 1) * c] = dy[r[1]]
+    d_pre = (du * y).sum(dim=(2, 3)) if pre is not None else None
+    d_post = (go * gc).sum(dim=(2, 3)) if post is not None else None
+    return dz.to(ysum.dtype), d_pre, d_post, du.sum(dim=(2, 3))
