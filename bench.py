@@ -79,6 +79,22 @@ class OpTimer:
         # modconv_epilogue: forward y -> out (2 streams), backward dout, y -> dy (3 streams)
         wrap(modconv_epilogue, '_launch_fwd', lambda a: 'modconv_epilogue_fwd', lambda args, out: 2 * args[0].numel() * args[0].element_size())
         wrap(modconv_epilogue, '_launch_bwd', lambda a: 'modconv_epilogue_bwd', lambda args, out: 3 * args[0].numel() * args[0].element_size())
+        # tapconv_epilogue (tap-stacked temporal conv, sum fused into the epilogue; lres binds the launch functions
+        # by name, so they are wrapped there). forward: z (taps*N) -> out (+ saved sum) (+ residual); backward:
+        # dout, saved sum (+ residual) -> dz (taps*N)
+        from lvg.models import lres
+
+        def tap_fwd_bytes(args, out):
+            z, res = args[0], args[3]
+            streams = z.numel() + out[0].numel() + (out[1].numel() if out[1] is not None else 0) + (res.numel() if res is not None else 0)
+            return streams * z.element_size()
+
+        def tap_bwd_bytes(args, out):
+            dout, ysum, res = args[0], args[1], args[4]
+            streams = dout.numel() + ysum.numel() + (res.numel() if res is not None else 0) + out[0].numel()
+            return streams * ysum.element_size()
+        wrap(lres, 'tap_gather_forward', lambda a: 'tapconv_epilogue_fwd', tap_fwd_bytes)
+        wrap(lres, 'tap_gather_backward', lambda a: 'tapconv_epilogue_bwd', tap_bwd_bytes)
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step
