@@ -351,6 +351,21 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
 TAP_STACK = os.environ.get('LVG_TAP_STACK', '0') == '1'
 
 
+SECOND_ORDER = False      # True inside `second_order()`: layers must build a graph that can be differentiated twice
+
+
+@contextlib.contextmanager
+def second_order():
+    """Scope for passes whose gradient is differentiated again (R1): the tap-stacked convolution implements
+    first-order gradients only, so layers fall back to the kt-convolution form inside this scope."""
+    global SECOND_ORDER
+    prev, SECOND_ORDER = SECOND_ORDER, True
+    try:
+        yield
+    finally:
+        SECOND_ORDER = prev
+
+
 def stack_taps(weight: torch.Tensor) -> torch.Tensor:
     """[Co, Ci, kt, kh, kw] -> [kt*Co, Ci, kh, kw], tap-major along the output channels."""
     co, ci, kt, kh, kw = weight.shape
@@ -366,8 +381,10 @@ class _TapConvEpilogue(torch.autograd.Function):
         kt = weight.shape[2]
         wst = _cl(stack_taps(weight))
         z = _cl(F.conv2d(_cl(x), wst, padding=padding_hw))
-        out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq)
-        ctx.save_for_backward(x, weight, ysum, pre, b, res, post)
+        # a bare temporal sum (no scale / bias / activation) IS its own saved sum: nothing extra is written
+        plain = pre is None and b is None and res is None and post is None and act == 'linear' and clamp is None
+        out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq, keep_sum=not plain)
+        ctx.save_for_backward(x, weight, out if plain else ysum, pre, b, res, post)
         ctx.cfg = (n, list(padding_hw), act, clamp)
         if want_msq:
             ctx.mark_non_differentiable(msq)
@@ -399,13 +416,17 @@ def temporal_conv_epilogue(x: torch.Tensor, weight: torch.Tensor, n: int, paddin
     `clamp(act(y * pre + b + res) * gain) * post` (pre / post float32 [(T N), C], res like the output).
     Returns `out` or `(out, mean_square)`. With TAP_STACK the kt taps are one convolution and their sum is
     taken inside the epilogue kernel; otherwise kt convolutions are accumulated and the epilogue runs on the sum."""
-    if TAP_STACK and weight.shape[2] > 1 and (res is None or (act == 'linear' and clamp is None and post is None)):
+    if TAP_STACK and not SECOND_ORDER and weight.shape[2] > 1 and (res is None or (act == 'linear' and clamp is None and post is None)):
         out, msq = _TapConvEpilogue.apply(x, weight, pre, b, res, post, n, tuple(padding_hw), act, clamp, bool(want_msq))
         return (out, msq) if want_msq else out
     y = temporal_conv_frames(x, weight, n, padding_hw)
     if res is not None:
         assert b is None and post is None and act == 'linear' and clamp is None and not want_msq
         return torch.addcmul(res, y, pre.to(y.dtype).reshape(y.shape[0], -1, 1, 1))
+    if pre is None and post is None and not want_msq:
+        if b is None and act == 'linear' and clamp is None:
+            return y
+        return bias_act.bias_act(y, b, act=act, clamp=clamp)          # differentiable to second order (discriminator, R1)
     return modconv_epilogue(y, pre=pre, b=b, post=post, act=act, clamp=clamp, want_msq=want_msq)
 
 
@@ -891,13 +912,15 @@ class Conv3dLayer(nn.Module):
 
     def forward_frames(self, x: torch.Tensor, n: int) -> torch.Tensor:
         """Time-major frames layout: x [(T N), C, H, W]."""
-        y = temporal_conv_frames(x, (self.weight * self.weight_gain).to(x.dtype), n, self.padding[1:])
-        if self.has_down:
-            if self.downsample.spatial_down:
-                y = upfirdn2d.downsample2d(y, self.downsample._downsample_filter, down=2)
-            if self.downsample.temporal_down:
-                y = resample_time_frames(y, self.downsample._downsample_filter, n, down=2)
+        w = (self.weight * self.weight_gain).to(x.dtype)
         b = self._bias.to(x.dtype) if self._bias is not None else None
+        if not self.has_down:                   # conv -> bias / activation / clamp in one epilogue pass
+            return temporal_conv_epilogue(x, w, n, self.padding[1:], b=b, act=self.activation, clamp=self.conv_clamp)
+        y = temporal_conv_epilogue(x, w, n, self.padding[1:])          # the resamplers need the plain sum
+        if self.downsample.spatial_down:
+            y = upfirdn2d.downsample2d(y, self.downsample._downsample_filter, down=2)
+        if self.downsample.temporal_down:
+            y = resample_time_frames(y, self.downsample._downsample_filter, n, down=2)
         return bias_act.bias_act(y, b, act=self.activation, clamp=self.conv_clamp)
 
 

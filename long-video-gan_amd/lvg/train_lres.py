@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import ddp
 from .augment import diff_augment, temporal_scale_augment
+from .models import lres as lres_models
 from .models.lres import VideoDiscriminator, VideoGenerator
 
 
@@ -89,7 +90,8 @@ class LowResTrainer:
         chunks = video.chunk(self.D_grad_accum)
         for k, chunk in enumerate(chunks):
             chunk = chunk.detach().requires_grad_(True)
-            logits = self.run_D(chunk)
+            with lres_models.second_order():                  # the gradient below is differentiated again
+                logits = self.run_D(chunk)
             (grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[chunk], create_graph=True)
             penalty = grad.square().sum(dim=(1, 2, 3, 4))
             if k == len(chunks) - 1 and self.D_sync.overlap:

@@ -116,6 +116,43 @@ def test_generator_matches_reference_golden_with_stacked_taps_cpu(monkeypatch):
     np.testing.assert_allclose(video.numpy(), g['video'], rtol=0, atol=1e-3)
 
 
+def _disc_run(D, video, flag, monkeypatch):
+    monkeypatch.setattr(lres, 'TAP_STACK', flag)
+    v = video.clone().requires_grad_(True)
+    logits = D(v)
+    (g,) = torch.autograd.grad(torch.nn.functional.softplus(-logits).mean(), v)
+    return logits.detach(), g
+
+
+def test_discriminator_with_stacked_taps_equals_accumulated_taps_cpu(monkeypatch):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    D = lres.VideoDiscriminator(seq_length=16, max_edge=64).requires_grad_(False)
+    video = torch.rand(1, 3, 16, 36, 64) * 2 - 1
+    a = _disc_run(D, video, False, monkeypatch)
+    b = _disc_run(D, video, True, monkeypatch)
+    torch.testing.assert_close(b[0], a[0], rtol=1e-4, atol=1e-5)
+    scale = float(a[1].abs().max())
+    assert float((b[1] - a[1]).abs().max()) <= 1e-3 * scale
+
+
+def test_second_order_scope_falls_back_to_differentiable_form_cpu(monkeypatch):
+    """R1: inside lres.second_order() the stacked form is not used, so grad-of-grad exists."""
+    monkeypatch.setattr(lres, 'TAP_STACK', True)
+    torch.manual_seed(0)
+    layer = lres.Conv3dLayer(4, 8, spatial_ksize=3, temporal_ksize=3, activation='lrelu', conv_clamp=256)
+    x = torch.randn(6, 4, 5, 7, requires_grad=True)
+    with lres.second_order():
+        y = layer.forward_frames(x, 2)
+    (g,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    g.square().sum().backward()
+    assert layer.weight.grad is not None and torch.isfinite(layer.weight.grad).all()
+    y = layer.forward_frames(x, 2)                                  # outside the scope: first-order only, and it says so
+    (g,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        g.square().sum().backward()
+
+
 CASES = [(8, 2, 64, 9, 16, 3), (6, 1, 8, 5, 7, 3), (12, 2, 32, 4, 6, 5), (4, 3, 256, 3, 4, 3)]
 
 
