@@ -205,8 +205,8 @@ def main():
 
     # The generator pass tracks the input magnitude of every modulated layer (magnitude_ema_beta = 0.999; the
     # reference does this in the generator pass of update_D, video_gan_lres.py:140-144 -- timing it here makes
-    # the measured pass a superset of update_G's). Across ranks the 19 per-layer statistics are exchanged in ONE
-    # all-reduce after the pass instead of 19 inside it (lres.MagnitudeEMA).
+    # the measured pass a superset of update_G's). Across ranks the 21 per-convolution statistics are exchanged in ONE
+    # all-reduce after the pass instead of 21 inside it (lres.MagnitudeEMA).
     ema_beta = 0.999
     pending_emas = []
 

@@ -128,7 +128,7 @@ class MagnitudeEMA(nn.Module):
     """Tracks E[x^2] of a layer input; returns its reciprocal square root as a scalar gain.
 
     Across ranks the reference all-reduces the statistic inside every layer's forward
-    (model/generator_lres.py:298-312: 19 one-float collectives per generator pass). Inside a
+    (model/generator_lres.py:298-312: 21 one-float collectives per generator pass). Inside a
     `deferred_magnitude_sync()` scope the layer instead folds in its LOCAL mean and records it; one
     batched all-reduce afterwards (`finish_magnitude_sync`) corrects every buffer to the global-mean
     update, so buffers end up identical on all ranks and identical to the reference's. The only

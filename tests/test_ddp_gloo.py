@@ -139,6 +139,50 @@ def _worker_magnitude(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_generator_update(rank, world, port, out):
+    """The N>1 body of bench.py on CPU: full generator, per-rank noise, deferred magnitude sync, flat
+    gradient all-reduce, Adam. Afterwards every parameter and buffer must be bit-identical on both ranks."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'long-video-gan_amd'))
+    _init(rank, world, port)
+    torch.set_num_threads(4)
+    try:
+        import torch.nn.functional as F
+        from lvg import ddp
+        from lvg.models import lres
+        torch.manual_seed(100 + rank)                                   # different init per rank: the broadcast must fix it
+        G = lres.VideoGenerator().requires_grad_(True).train()
+        D = lres.VideoDiscriminator(seq_length=16, max_edge=64).requires_grad_(False).train()
+        ddp.broadcast_module(G)
+        ddp.broadcast_module(D)
+        opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0.0, 0.99))
+        sync = ddp.FlatGradSync(G.parameters(), overlap=False)
+        torch.manual_seed(1 + rank)                                     # per-rank noise stream
+        sync.zero()
+        with lres.deferred_magnitude_sync() as pending:
+            video = G(1, 16, magnitude_ema_beta=0.999)
+        F.softplus(-D(video)).mean().backward()
+        assert len(pending) == 21
+        local_grad = sync.flat.clone()
+        lres.finish_magnitude_sync(pending, lres.stack_pending(pending))
+        sync.finish()
+        assert not torch.equal(local_grad, sync.flat), 'gradients were not exchanged'
+        opt.step()
+        state = torch.cat([t.detach().flatten().double() for t in list(G.parameters()) + list(G.buffers())])
+        digest = torch.stack([state.sum(), state.abs().sum(), (state * torch.arange(state.numel(), dtype=torch.float64) % 7).sum()])
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        assert torch.equal(gathered[0], gathered[1]), f'rank states differ: {gathered}'
+        emas = [float(b) for n, b in G.named_buffers() if n.endswith('magnitude_ema')]
+        assert len(emas) == 21 and all(e != 1.0 for e in emas)
+        out.put((rank, 'ok'))
+    except Exception:
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _spawn(fn):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -159,3 +203,7 @@ def test_sync_grads_and_flat_sync_world2():
 
 def test_deferred_magnitude_sync_world2():
     _spawn(_worker_magnitude)
+
+
+def test_generator_update_world2_keeps_ranks_identical():
+    _spawn(_worker_generator_update)
