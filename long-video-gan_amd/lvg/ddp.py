@@ -87,7 +87,14 @@ class FlatGradSync:
         self._hooks = []
         if overlap:
             for i, p in enumerate(self.params):
+                # hooks can only be registered on tensors that require grad; the trainers keep their networks
+                # frozen (requires_grad False) outside the update that trains them, so flip it for the call
+                frozen = not p.requires_grad
+                if frozen:
+                    p.requires_grad_(True)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                if frozen:
+                    p.requires_grad_(False)
         self.zero()
 
     def _make_hook(self, index: int):

@@ -183,6 +183,44 @@ def _worker_generator_update(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_sres_step(rank, world, port, out):
+    """SuperResTrainer on two ranks with different data: one full step (G, D, R1, ADA, EMA) leaves the
+    networks, the ADA probability and the EMA copy identical on both ranks."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'long-video-gan_amd'))
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    _init(rank, world, port)
+    torch.set_num_threads(4)
+    try:
+        from helpers.ada_cfg import TRAIN_SRES_KW
+        from lvg.train_sres import SuperResTrainer
+        torch.manual_seed(50 + rank)                                    # different init per rank: broadcast fixes it
+        tr = SuperResTrainer(device='cpu', compute_dtype=torch.float32, seq_length=2, temporal_context=1, lr_height=9, lr_width=16,
+                             hr_height=36, hr_width=64,
+                             G_kwargs=dict(latent_z_dim=32, latent_w_dim=48, channel_base=1024, channel_max=24, num_fp16_res=2),
+                             D_kwargs=dict(channels_base=1024, channels_max=32, num_fp16_res=0),
+                             augment_kwargs=TRAIN_SRES_KW, augment_p_init=0.3, overlap_grad_sync=True)
+        g = torch.Generator().manual_seed(7 + rank)                     # different data per rank
+        lr = torch.rand(2, 3, 4, 9, 16, generator=g) * 2 - 1
+        hr = torch.rand(2, 3, 2, 36, 64, generator=g) * 2 - 1
+        tr.train_step(step=0, lr_video=lr, hr_video=hr, r1_interval=16, ada_interval=4)
+        tensors = []
+        for net in (tr.G, tr.D, tr.G_ema, tr.augment):
+            tensors += [t.detach().flatten().double() for t in list(net.parameters()) + list(net.buffers())]
+        state = torch.cat(tensors)
+        digest = torch.stack([state.sum(), state.abs().sum(), state.square().sum()])
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        assert torch.equal(gathered[0], gathered[1]), f'rank states differ: {gathered}'
+        out.put((rank, 'ok'))
+    except Exception:
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _spawn(fn):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -207,3 +245,7 @@ def test_deferred_magnitude_sync_world2():
 
 def test_generator_update_world2_keeps_ranks_identical():
     _spawn(_worker_generator_update)
+
+
+def test_sres_train_step_world2_keeps_ranks_identical():
+    _spawn(_worker_sres_step)
