@@ -366,6 +366,20 @@ def second_order():
         SECOND_ORDER = prev
 
 
+# 1x1 convolutions as plain GEMMs on the channels-last pixel matrix [(frames H W), Ci] (hipBLASLt) instead of MIOpen's
+# implicit-GEMM + its split-K zero-fill / cast helpers. Opt-in (LVG_POINTWISE_GEMM=1) until measured on MI355X.
+POINTWISE_GEMM = os.environ.get('LVG_POINTWISE_GEMM', '0') == '1'
+
+
+def pointwise_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """conv2d with a [Co, Ci] / [Co, Ci, 1, 1] weight on frames [(T N), Ci, H, W]; result in x's memory format."""
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    cl = x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+    if POINTWISE_GEMM and cl:
+        return torch.matmul(x.permute(0, 2, 3, 1), w2.t()).permute(0, 3, 1, 2)      # views: [F, H, W, C] is the memory order
+    return F.conv2d(x, _cl(w2[:, :, None, None]))
+
+
 def stack_taps(weight: torch.Tensor) -> torch.Tensor:
     """[Co, Ci, kt, kh, kw] -> [kt*Co, Ci, kh, kw], tap-major along the output channels."""
     co, ci, kt, kh, kw = weight.shape
@@ -688,7 +702,7 @@ class Synthesis3dResBlock(nn.Module):
         w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
         if gain_0 is not None:
             w_skip = w_skip * gain_0
-        skip = F.conv2d(x, _cl(w_skip.to(dtype)))
+        skip = pointwise_conv(x, w_skip.to(dtype))
         # conv 1: h = skip + conv * (demodulation * gain * sqrt(1/2)), one pass
         scale_1 = demod_1 * SQRT_HALF if gain_1 is None else demod_1 * (gain_1 * SQRT_HALF)
         h = temporal_conv_epilogue(hm, w1.to(dtype), n, self.padding[1:], pre=scale_1, res=skip)
