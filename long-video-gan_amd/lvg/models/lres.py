@@ -340,6 +340,8 @@ class _TemporalConvFrames(torch.autograd.Function):
 def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw) -> torch.Tensor:
     """conv3d with 'same' zero padding in time, as kt 2-D convolutions. x [(T N), Ci, H, W] and
     weight [Co, Ci, kt, kh, kw] in the compute dtype."""
+    if POINTWISE_GEMM and tuple(weight.shape[2:]) == (1, 1, 1):
+        return pointwise_conv(x, weight[:, :, 0, 0, 0])
     return _TemporalConvFrames.apply(x, weight, n, tuple(padding_hw))
 
 
