@@ -195,3 +195,25 @@ def fma(a, b, c):
     rc = lib().orc_fma(_dp(a), _dp(b), _dp(c), _dp(y), ctypes.c_int64(a.size))
     assert rc == 0
     return y
+
+
+def modconv_epilogue(z, pre=None, b=None, res=None, post=None, taps=1, shift=1, act='linear', alpha=None, gain=None, clamp=None):
+    """Modulated-conv epilogue (orc_modconv_epilogue). z [frames, taps*C, H, W] (tap-major channels);
+    pre / post [frames, C]; b [C]; res [frames, C, H, W]. Returns (out, ysum, mean_square)."""
+    z = _f64(z)
+    f, kc, h, w = z.shape
+    c = kc // taps
+    assert c * taps == kc
+    def_alpha, def_gain = ACT_DEFAULTS[act]
+    alpha = float(def_alpha if alpha is None else alpha)
+    gain = float(def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    pre64, b64, res64, post64 = _f64(pre), _f64(b), _f64(res), _f64(post)
+    out = np.empty((f, c, h, w), dtype=np.float64)
+    ysum = np.empty_like(out)
+    msq = ctypes.c_double(0.0)
+    rc = lib().orc_modconv_epilogue(_dp(z), _dp(pre64), _dp(b64), _dp(res64), _dp(post64), _dp(out), _dp(ysum), ctypes.byref(msq),
+                                    ctypes.c_int64(f), ctypes.c_int(c), ctypes.c_int(h * w), ctypes.c_int(taps), ctypes.c_int64(shift),
+                                    ctypes.c_int(ACT_IDS[act]), ctypes.c_double(alpha), ctypes.c_double(gain), ctypes.c_double(clamp))
+    assert rc == 0, rc
+    return out, ysum, float(msq.value)

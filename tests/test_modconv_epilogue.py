@@ -24,13 +24,21 @@ def _case(seed, f, c, h, w, dtype, device, channels_last, with_pre=True, with_b=
 
 
 def _oracle_forward(oracle, y, pre, b, post, act, clamp):
-    """numpy float64 definition with the oracle's bias_act in the middle."""
-    u = y.double().cpu().numpy()
-    if pre is not None:
-        u = u * pre.double().cpu().numpy()[:, :, None, None]
-    v = oracle.bias_act(u, None if b is None else b.double().cpu().numpy(), dim=1, act=act, clamp=clamp)
-    out = v if post is None else v * post.double().cpu().numpy()[:, :, None, None]
-    return out, float((v ** 2).mean())
+    """float64 C oracle (oracle/lvg_oracle.c: orc_modconv_epilogue)."""
+    cpu = lambda t: None if t is None else t.double().cpu().numpy()
+    out, _, msq = oracle.modconv_epilogue(cpu(y), cpu(pre), cpu(b), None, cpu(post), act=act, clamp=clamp)
+    return out, msq
+
+
+def test_oracle_epilogue_is_the_composition_of_the_reference_passes(oracle):
+    """orc_modconv_epilogue == demodulation multiply -> ORACLE bias_act -> modulation multiply (the three
+    reference passes, each pinned to the reference by tests/test_oracle_golden.py)."""
+    y, pre, b, post = _case(4, 3, 5, 4, 6, torch.float64, 'cpu', False)
+    out, ysum, msq = oracle.modconv_epilogue(y.numpy(), pre.numpy(), b.numpy(), None, post.numpy(), act='lrelu', clamp=1.5)
+    v = oracle.bias_act(y.numpy() * pre.double().numpy()[:, :, None, None], b.numpy(), dim=1, act='lrelu', clamp=1.5)
+    np.testing.assert_allclose(out, v * post.double().numpy()[:, :, None, None], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ysum, y.numpy(), rtol=0, atol=0)
+    assert abs(msq - float((v ** 2).mean())) < 1e-12
 
 
 def test_ref_definition_matches_oracle_cpu(oracle):

@@ -51,10 +51,15 @@ def _compose(z, pre, b, res, post, taps, shift, act, clamp):
 
 
 @pytest.mark.parametrize('taps,with_res', [(3, False), (5, False), (3, True)])
-def test_launch_level_reference_formulas_cpu(taps, with_res):
+def test_launch_level_reference_formulas_cpu(oracle, taps, with_res):
     z, pre, b, res, post = _gather_case(0, 6, 2, 8, 3, 5, taps, torch.float32, 'cpu', with_res)
     act, clamp = ('linear', None) if with_res else ('lrelu', 1.5)
     out, ysum, msq = me.tap_gather_forward(z, pre, b, res, post, taps, 2, act=act, clamp=clamp, want_msq=True)
+    np_ = lambda t: None if t is None else t.double().numpy()
+    o_out, o_sum, o_msq = oracle.modconv_epilogue(np_(z), np_(pre), np_(b), np_(res), np_(post), taps=taps, shift=2, act=act, clamp=clamp)
+    np.testing.assert_allclose(out.numpy(), o_out, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ysum.numpy(), o_sum, rtol=1e-5, atol=1e-5)
+    assert abs(float(msq) - o_msq) < 1e-5 * o_msq
     zz = z.clone().requires_grad_(True)
     prer = pre.clone().requires_grad_(True)
     postr = post.clone().requires_grad_(True) if post is not None else None
@@ -160,10 +165,15 @@ CASES = [(8, 2, 64, 9, 16, 3), (6, 1, 8, 5, 7, 3), (12, 2, 32, 4, 6, 5), (4, 3, 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('t,n,c,h,w,taps', CASES)
 @pytest.mark.parametrize('with_res', [False, True])
-def test_kernels_match_formulas_gpu(dtype, t, n, c, h, w, taps, with_res):
+def test_kernels_match_formulas_gpu(oracle, dtype, t, n, c, h, w, taps, with_res):
     z, pre, b, res, post = _gather_case(3, t, n, c, h, w, taps, dtype, 'cuda', with_res)
     act, clamp = ('linear', None) if with_res else ('lrelu', 2.0)
     out, ysum, msq = me.tap_gather_forward(z, pre, b, res, post, taps, n, act=act, clamp=clamp, want_msq=True)
+    np_ = lambda v: None if v is None else v.double().cpu().numpy()
+    o_out, o_sum, _ = oracle.modconv_epilogue(np_(z), np_(pre), np_(b), np_(res), np_(post), taps=taps, shift=n, act=act, clamp=clamp)
+    o_eps = 2e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(out.double().cpu().numpy(), o_out, rtol=o_eps, atol=o_eps)
+    np.testing.assert_allclose(ysum.double().cpu().numpy(), o_sum, rtol=o_eps, atol=o_eps)
     cpu = lambda v: None if v is None else v.cpu()
     out_r, ysum_r, msq_r = me.tap_gather_forward(cpu(z).float(), cpu(pre), cpu(b.float()) if b is not None else None,
                                                  cpu(res.float()) if res is not None else None, cpu(post), taps, n, act=act, clamp=clamp, want_msq=True)
