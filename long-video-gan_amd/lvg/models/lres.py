@@ -878,6 +878,12 @@ class VideoGenerator(nn.Module):
         emb = self.sample_temporal_emb(batch_size, seq_length, generator_emb)
         return self.forward_from_emb(emb, seq_length, magnitude_ema_beta, dtype)
 
+    def sample_temporal_input(self, batch_size: int, seq_length: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Gaussian stand-in for the learned temporal input, [N, C0, T_in] (reference generator_lres.py:832)."""
+        device = next(self.parameters()).device
+        t_in = self.compute_seq_lengths(seq_length)[0]
+        return torch.randn(batch_size, self.temporal_layers[0].in_channels, t_in, generator=generator, device=device)
+
     def sample_video_segments(self, batch_size: int, seq_length: int, segment_length: int = 8,
                               generator_emb: Optional[torch.Generator] = None, dtype: Optional[torch.dtype] = None):
         video = self.forward(batch_size, seq_length, generator_emb=generator_emb, dtype=dtype)
