@@ -145,3 +145,72 @@ def check_ddp_consistency(module, ignore_regex=None):
         theirs = mine.clone()
         torch.distributed.broadcast(tensor=theirs, src=0)
         assert (mine == theirs).all(), fullname
+
+
+def print_module_summary(module, inputs, max_nesting=3, skip_redundant=True, **input_kwargs):
+    """Run `module(*inputs, **input_kwargs)` once and print one table row per sub-module (down to
+    `max_nesting` levels): parameters and buffers it owns that no earlier row owned, output shape /
+    dtype and output statistics. Returns the module's outputs (reference misc.py:196)."""
+    assert isinstance(module, torch.nn.Module) and not isinstance(module, torch.jit.ScriptModule)
+    assert isinstance(inputs, (tuple, list))
+
+    depth = 0
+    visited = []                                  # (module, [output tensors]) in completion order
+
+    def enter(_mod, _args):
+        nonlocal depth
+        depth += 1
+
+    def leave(mod, _args, result):
+        nonlocal depth
+        depth -= 1
+        if depth <= max_nesting:
+            seq = result if isinstance(result, (tuple, list)) else [result]
+            visited.append((mod, [t for t in seq if isinstance(t, torch.Tensor)]))
+
+    handles = []
+    for sub in module.modules():
+        handles.append(sub.register_forward_pre_hook(enter))
+        handles.append(sub.register_forward_hook(leave))
+    try:
+        outputs = module(*inputs, **input_kwargs)
+    finally:
+        for h in handles:
+            h.remove()
+
+    names = {sub: name for name, sub in module.named_modules()}
+    columns = ['Mean', 'Std', 'Min (abs)', 'Max (abs)']
+    measure = [torch.mean, torch.std, lambda t: t.abs().min(), lambda t: t.abs().max()]
+    table = [[type(module).__name__, 'Parameters', 'Buffers', 'Output shape', 'Datatype'] + [f'{c:<10}' for c in columns]]
+    table.append(['---'] * len(table[0]))
+    owned = set()
+    totals = [0, 0]
+    for sub, outs in visited:
+        params = [t for t in sub.parameters() if id(t) not in owned]
+        buffers = [t for t in sub.buffers() if id(t) not in owned]
+        fresh_outs = [t for t in outs if id(t) not in owned]
+        owned.update(id(t) for t in params + buffers + fresh_outs)
+        if skip_redundant and not (params or buffers or fresh_outs):
+            continue
+        n_param, n_buf = sum(t.numel() for t in params), sum(t.numel() for t in buffers)
+        totals[0] += n_param
+        totals[1] += n_buf
+        label = '<top-level>' if sub is module else names[sub]
+        for idx in range(max(len(outs), 1)):
+            if idx < len(outs):
+                t = outs[idx]
+                cells = [str(list(t.shape)), str(t.dtype).split('.')[-1]] + [f'{float(f(t.detach().float())):>10.3e}' for f in measure]
+            else:
+                cells = ['-'] * (2 + len(columns))
+            head = label + (f':{idx}' if len(outs) >= 2 else '')
+            counts = [str(n_param) if n_param else '-', str(n_buf) if n_buf else '-'] if idx == 0 else ['-', '-']
+            table.append([head] + counts + cells)
+    table.append(['---'] * len(table[0]))
+    table.append(['Total', str(totals[0]), str(totals[1])] + ['-'] * (len(table[0]) - 3))
+
+    widths = [max(len(row[i]) for row in table) for i in range(len(table[0]))]
+    print()
+    for row in table:
+        print('  '.join(cell.ljust(w) for cell, w in zip(row, widths)))
+    print()
+    return outputs
