@@ -215,6 +215,8 @@ class SynthesisLayer(nn.Module):
         dtype = self.compute_dtype if low_precision else torch.float32
         x = modulated_conv2d(x.to(dtype), self.weight, style, demodulate=not self.is_torgb,
                              padding=self.conv_kernel - 1, input_gain=input_gain)
+        if not x.is_contiguous():          # a 1x1 conv may hand back channels-last strides; the fused kernel tiles NCHW planes
+            x = x.contiguous()
         x = filtered_lrelu.filtered_lrelu(
             x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(dtype), up=self.up_factor, down=self.down_factor,
             padding=self.padding, gain=(1 if self.is_torgb else math.sqrt(2)), slope=(1 if self.is_torgb else 0.2),
