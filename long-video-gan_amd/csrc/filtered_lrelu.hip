@@ -27,6 +27,7 @@
 // ceiling that actually binds at 16-bit I/O.
 
 #include "lvg_common.h"
+#include <atomic>
 
 namespace {
 
@@ -572,11 +573,13 @@ int launch_fused(FlreluArgs& p, int mode, hipStream_t stream)
     const size_t lds = G::LDS_BYTES;
     // Opt in to > 64 KiB of dynamic LDS once per specialisation.
     #define LVG_FLRELU_LAUNCH(M) do { \
-        static bool attr_done = false; \
-        if (!attr_done) { \
+        int dev_ = 0; (void)hipGetDevice(&dev_); \
+        static std::atomic<uint64_t> attr_done{0};          /* one bit per device (the attribute is per device) */ \
+        const uint64_t bit_ = 1ull << (dev_ & 63); \
+        if (!(attr_done.load(std::memory_order_acquire) & bit_)) { \
             hipError_t e = hipFuncSetAttribute((const void*)filtered_lrelu_fused_kernel<T, UP, DOWN, FU, FD, TW, TH, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { lvg_set_error("filtered_lrelu: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return LVG_ERR_LAUNCH; } \
-            attr_done = true; } \
+            attr_done.fetch_or(bit_, std::memory_order_release); } \
         hipLaunchKernelGGL((filtered_lrelu_fused_kernel<T, UP, DOWN, FU, FD, TW, TH, M>), dim3((unsigned)blocks), dim3(kNT), lds, stream, p); } while (0)
     if (mode == LVG_SIGNS_WRITE)     LVG_FLRELU_LAUNCH(LVG_SIGNS_WRITE);
     else if (mode == LVG_SIGNS_READ) LVG_FLRELU_LAUNCH(LVG_SIGNS_READ);

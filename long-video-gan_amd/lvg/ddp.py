@@ -83,22 +83,27 @@ class FlatGradSync:
         self.overlap = overlap
         self._armed = False
         self._pending = [0] * len(self.buckets)
+        self._launched = set()
         self._work = []
         self._hooks = []
-        if overlap:
-            for i, p in enumerate(self.params):
-                # hooks can only be registered on tensors that require grad; the trainers keep their networks
-                # frozen (requires_grad False) outside the update that trains them, so flip it for the call
-                frozen = not p.requires_grad
-                if frozen:
-                    p.requires_grad_(True)
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
-                if frozen:
-                    p.requires_grad_(False)
+        # Which parameters received a gradient since zero(): the reference starts every update from
+        # zero_grad(set_to_none=True) and sync_grads / Adam skip parameters whose grad is None (utils.py:106);
+        # finish() restores exactly that for parameters autograd never touched.
+        self._fired = [False] * len(self.params)
+        for i, p in enumerate(self.params):
+            # hooks can only be registered on tensors that require grad; the trainers keep their networks
+            # frozen (requires_grad False) outside the update that trains them, so flip it for the call
+            frozen = not p.requires_grad
+            if frozen:
+                p.requires_grad_(True)
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            if frozen:
+                p.requires_grad_(False)
         self.zero()
 
     def _make_hook(self, index: int):
         def hook(_param):
+            self._fired[index] = True
             if not self._armed:
                 return
             b = self.bucket_of[index]
@@ -108,6 +113,7 @@ class FlatGradSync:
         return hook
 
     def _launch(self, b: int) -> None:
+        self._launched.add(b)
         if dist.is_available() and dist.is_initialized():
             s, e, _ = self.buckets[b]
             self._work.append(dist.all_reduce(self.flat[s:e], async_op=True))
@@ -117,6 +123,7 @@ class FlatGradSync:
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self._fired = [False] * len(self.params)
 
     def arm(self) -> None:
         """Call before the last backward of the step: buckets reduce as they fill."""
@@ -125,9 +132,29 @@ class FlatGradSync:
         for b, (_, _, mem) in enumerate(self.buckets):
             self._pending[b] = sum(1 for i in mem if self.params[i].requires_grad)
         self._launched = set()
+        self._work = []
 
-    def finish(self, gain: Optional[float] = None) -> None:
-        """Complete the exchange: mean over ranks, * gain, nan_to_num. In place on the flat buffer."""
+    def _adopt_replaced_grads(self) -> None:
+        """Autograd accumulates OUT of place when the backward itself is recorded (create_graph=True) or the
+        view was otherwise not usable: `p.grad` is then a new tensor holding the full sum and the flat buffer
+        is stale. Copy it in before anything is reduced; if that bucket has already been sent (overlap), the
+        exchanged values are wrong and there is no way to repair them, so fail loudly."""
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            g = p.grad
+            if g is None or g is v or (g.data_ptr() == v.data_ptr() and g.shape == v.shape):
+                continue
+            if self._armed and self.bucket_of[i] in self._launched:
+                raise RuntimeError('FlatGradSync: autograd replaced the .grad view of a parameter whose bucket was already '
+                                   'all-reduced (backward with create_graph=True under overlap=True); arm() only before a plain backward')
+            v.copy_(g.detach())
+            self._fired[i] = True
+            p.grad = v
+
+    def finish(self, gain: Optional[float] = None, drop_unused: bool = True) -> None:
+        """Complete the exchange: mean over ranks, * gain, nan_to_num. In place on the flat buffer.
+        With `drop_unused`, parameters that received no gradient since zero() end with grad None (so the
+        optimizer leaves their state alone, like the reference's zero_grad(set_to_none=True))."""
+        self._adopt_replaced_grads()
         if self._armed:
             # buckets whose hooks never fired (unused parameters) still have to be reduced
             for b in range(len(self.buckets)):
@@ -145,9 +172,10 @@ class FlatGradSync:
         if scale != 1.0:
             self.flat.mul_(scale)
         torch.nan_to_num(self.flat, nan=0, posinf=1e5, neginf=-1e5, out=self.flat)
-        for p, v in zip(self.params, self.views):
-            if p.grad is not v:      # autograd replaced the view (grad was None during backward)
-                p.grad = v
+        if drop_unused and any(self._fired):
+            for p, fired in zip(self.params, self._fired):
+                if not fired:
+                    p.grad = None
 
     def close(self) -> None:
         for h in self._hooks:

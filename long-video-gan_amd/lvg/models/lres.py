@@ -348,9 +348,8 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
 # Tap-stacked form of the temporal convolution: ONE 2-D convolution with kt*Co output channels, the temporal
 # sum folded into the epilogue kernel (csrc/tapconv_epilogue.hip) instead of kt - 1 accumulate passes.
 # Measured on MI355X (bench.py, batch 8): 78.0 -> 75.3 ms/step (13.2k -> 13.6k frames/s); parity-green on CPU
-# and GPU. Opt-in (LVG_TAP_STACK=1) for this round only because the committed rocprof / PMC evidence in
-# profiles/ was recorded with the kt-convolution form and the round's GPU budget ended before re-profiling.
-TAP_STACK = os.environ.get('LVG_TAP_STACK', '0') == '1'
+# and GPU. On by default since round 2 (LVG_TAP_STACK=0 restores the kt-convolution form).
+TAP_STACK = os.environ.get('LVG_TAP_STACK', '1') == '1'
 
 
 SECOND_ORDER = False      # True inside `second_order()`: layers must build a graph that can be differentiated twice

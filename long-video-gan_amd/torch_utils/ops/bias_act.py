@@ -118,7 +118,9 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     for other in (xref, yref, dy):
         if other is not None and other.numel():
             assert other.shape == x.shape and other.dtype == x.dtype and other.device == x.device
-            assert other.stride() == x.stride(), 'xref/yref/dy must share the layout of x'
+            # same dense layout; strides of size-1 dims are arbitrary (a channels-last tensor with N == 1 or
+            # C == 1 is also "contiguous" and .contiguous(memory_format=...) returns it unchanged)
+            assert all(so == sx for so, sx, n_ in zip(other.stride(), x.stride(), x.shape) if n_ > 1), 'xref/yref/dy must share the layout of x'
     has_b = b is not None and b.numel() > 0
     if has_b:
         assert b.ndim == 1 and b.dtype == x.dtype and b.device == x.device and b.is_contiguous()

@@ -249,3 +249,50 @@ def test_generator_update_world2_keeps_ranks_identical():
 
 def test_sres_train_step_world2_keeps_ranks_identical():
     _spawn(_worker_sres_step)
+
+
+def test_flat_sync_adopts_replaced_grads_and_drops_unused():
+    """Single process. (1) backward(create_graph=True) makes autograd REPLACE the .grad views: finish() must
+    carry those values into the flat buffer (round-1 advisor finding: they were silently zeroed). (2) A
+    parameter that received no gradient ends with grad None, so Adam leaves its state alone like the
+    reference's zero_grad(set_to_none=True) (utils.py:106). (3) With overlap armed, a replaced view whose
+    bucket was already sent raises instead of exchanging stale numbers."""
+    from lvg import ddp
+    net = _make_net(3)
+    unused = torch.nn.Parameter(torch.ones(4))
+    params = list(net.parameters()) + [unused]
+    x = torch.randn(6, 37, generator=torch.Generator().manual_seed(1))
+
+    ref = _make_net(3)
+    ref(x).square().sum().backward()
+    want = [p.grad.clone() for p in ref.parameters()]
+
+    sync = ddp.FlatGradSync(params, overlap=False)
+    sync.zero()
+    net(x).square().sum().backward(create_graph=True)
+    assert any(p.grad is not v for p, v in zip(sync.params, sync.views))     # autograd did replace them
+    sync.finish(gain=0.5)
+    for p, w in zip(net.parameters(), want):
+        assert p.grad is not None and p.grad.data_ptr() >= sync.flat.data_ptr()
+        torch.testing.assert_close(p.grad, w * 0.5)
+    assert unused.grad is None
+    opt = torch.optim.Adam(params, lr=0.1)
+    opt.step()
+    assert torch.equal(unused.detach(), torch.ones(4)) and unused not in opt.state
+    sync.zero()
+    assert unused.grad is not None and float(unused.grad.abs().sum()) == 0.0
+
+    # (3) overlap: plain backward works and matches, create_graph under arm() fails loudly
+    net2 = _make_net(3)
+    sync2 = ddp.FlatGradSync(list(net2.parameters()), bucket_numel=64, overlap=True)
+    sync2.zero()
+    sync2.arm()
+    net2(x).square().sum().backward()
+    sync2.finish()
+    for p, w in zip(net2.parameters(), want):
+        torch.testing.assert_close(p.grad, w)
+    sync2.zero()
+    sync2.arm()
+    net2(x).square().sum().backward(create_graph=True)
+    with pytest.raises(RuntimeError, match='create_graph'):
+        sync2.finish()

@@ -107,10 +107,78 @@ def test_sres_layer_shapes_vs_oracle(case, dtype, oracle):
         ref = oracle.filtered_lrelu(host(x), fu, fd, host(b), up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=256)
         assert tuple(y.shape) == ref.shape and y.dtype == dtype
         np.testing.assert_allclose(host(y), ref, err_msg=name, **TOL[dtype])
-        if dtype == torch.float32:
-            dy = torch.randn_like(y)
-            dx, db = torch.autograd.grad(y, [x, b], dy)
-            assert dx.shape == x.shape and db.shape == b.shape and torch.isfinite(dx).all()
+        _check_backward(oracle, x, b, y, fu, fd, up, down, pad, np.sqrt(2), 0.2, dtype, name)
+
+
+def _mask_pixels(s, sw_active):
+    """[n, c, sh, sw_active] array of 2-bit codes from a packed mask."""
+    cols = np.arange(sw_active)
+    return (s[..., cols >> 2] >> ((cols & 3) * 2)) & 3
+
+
+def _check_backward(oracle, x, b, y, fu, fd, up, down, pad, gain, slope, dtype, name, mask_ref=None):
+    """dx and db of the HIP op (the fused kernel in sign-READ mode with the filter roles swapped,
+    reference filtered_lrelu.py:239-268) vs the oracle run in READ mode on the mask the GPU wrote, and
+    the GPU's mask vs the oracle's own (computed in float64 from the same inputs)."""
+    px0, px1, py0, py1 = pad
+    nu, nd = len(fu), len(fd)
+    rs = np.random.RandomState(3)
+    dy = dev(rs.randn(*y.shape), dtype)
+    s_gpu = y.grad_fn.saved_tensors[0].cpu().numpy()
+    dx, db = torch.autograd.grad(y, [x, b], dy)
+    xh, xw = x.shape[2:]
+    yh, yw = y.shape[2:]
+    pp = [(nu - 1) + (nd - 1) - px0, xw * up - yw * down + px0 - (up - 1),
+          (nu - 1) + (nd - 1) - py0, xh * up - yh * down + py0 - (up - 1)]
+    dxo = oracle.filtered_lrelu(host(dy), fd, fu, None, up=down, down=up, padding=pp, gain=gain * up ** 2 / down ** 2,
+                                slope=slope, clamp=None, flip_filter=True, signs=s_gpu,
+                                sign_ofs=(-(nu - 1) + px0, -(nu - 1) + py0))
+    assert dxo.shape == tuple(x.shape)
+    tol = TOL[dtype]
+    np.testing.assert_allclose(host(dx), dxo, err_msg=name + ' dx', **tol)
+    dbo = dxo.sum(axis=(0, 2, 3))
+    # db is a torch reduction of the (rounded) dx
+    np.testing.assert_allclose(host(db), dbo, rtol=max(tol['rtol'], 1e-4) * 4, atol=tol['atol'] * np.sqrt(dxo[0, 0].size) * 4, err_msg=name + ' db')
+    if mask_ref is not None:
+        sh, swb, sw_active = oracle.sign_shape(yh, yw, down, nd, nd)
+        assert s_gpu.shape == mask_ref.shape == (x.shape[0], x.shape[1], sh, swb)
+        diff = _mask_pixels(s_gpu, sw_active) != _mask_pixels(mask_ref, sw_active)
+        # a pre-activation within float32 rounding of 0 may land on the other side in float64
+        assert diff.mean() <= 2e-4, (name, float(diff.mean()))
+        assert not s_gpu[..., (sw_active + 3) >> 2:].any(), 'padding bytes of the mask must be 0'
+
+
+# True layer geometry of the 144x256 super-resolution generator (SURVEY App. A.3): several tiles of the
+# fused kernels in x AND y (tile seams, mask-byte ownership, the READ-mode column re-alignment), few planes.
+FULL = [
+    ('L8_u2d2', [1, 4, 94, 150], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('L10_u4d2', [1, 3, 94, 150], 4, 2, 24, 12, [-6, -9, -6, -9]),
+    ('L13_final_crop', [1, 3, 166, 278], 2, 2, 12, 12, [-11, -12, -11, -12]),
+    ('L4_u2d2_small', [2, 3, 40, 54], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('L5_u4d2_small', [2, 3, 40, 54], 4, 2, 24, 12, [-6, -9, -6, -9]),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('case', FULL, ids=[s[0] for s in FULL])
+def test_full_size_layers_forward_backward_vs_oracle(case, dtype, oracle):
+    import scipy.signal
+    name, shape, up, down, nu, nd, pad = case
+    fu = scipy.signal.firwin(numtaps=nu, cutoff=0.9 / up, width=0.6 / up, fs=2.0).astype(np.float32)
+    fd = scipy.signal.firwin(numtaps=nd, cutoff=0.9 / down, width=0.6 / down, fs=2.0).astype(np.float32)
+    rs = np.random.RandomState(16)
+    x = dev(rs.randn(*shape), dtype, True)
+    b = dev(rs.randn(shape[1]) * 0.3, dtype, True)
+    clamp = 2.5      # low enough that the "clamped" bit of the mask is exercised
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        y = filtered_lrelu.filtered_lrelu(x, torch.tensor(fu, device=DEV), torch.tensor(fd, device=DEV), b,
+                                          up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=clamp)
+        ref, so = oracle.filtered_lrelu(host(x), fu, fd, host(b), up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2,
+                                        clamp=clamp, write_signs=True)
+        assert tuple(y.shape) == ref.shape and y.dtype == dtype
+        np.testing.assert_allclose(host(y), ref, err_msg=name, **TOL[dtype])
+        _check_backward(oracle, x, b, y, fu, fd, up, down, pad, np.sqrt(2), 0.2, dtype, name, mask_ref=so)
 
 
 def test_no_grad_writes_no_mask_and_torgb_1x1(oracle):

@@ -97,6 +97,95 @@ def test_bf16_forward_close_to_fp32_gpu():
     assert err.max() < 6e-2 and err.mean() < 6e-3, (float(err.max()), float(err.mean()))
 
 
+def _run_t128(device, dtype=None):
+    """BASELINE.json configs[1] shape: 128-frame generator forward + discriminator logits vs the reference
+    (tests/golden/make_golden_models_full.py; the stored video is float16: +-2.5e-4 of storage error)."""
+    g = load_golden('lres_models_full')
+    T128 = 128
+    G = VideoGenerator()
+    D = VideoDiscriminator(seq_length=T128, max_edge=64)
+    fill_named(G)
+    fill_named(D)
+    G, D = G.to(device), D.to(device)
+    noise = torch.randn(*[int(v) for v in g['t128_noise_shape']], generator=torch.Generator().manual_seed(int(g['t128_noise_seed'])))
+    assert abs(float(noise.double().sum()) - float(g['t128_noise_sum'])) < 1e-6      # same CPU random stream as the reference run
+    with torch.no_grad():
+        ws = G.compute_latent_ws(G.temporal_emb.blur(noise.to(device)), T128)
+        kw = {} if dtype is None else dict(dtype=dtype)
+        video = G.synthesize_video(G._temporal_input(ws), ws, T128, **kw)
+        logits = D(video.float(), **kw)
+    want = g['t128_video'].astype(np.float32)
+    assert tuple(video.shape) == want.shape == (1, 3, 128, 36, 64)
+    return np.abs(video.float().cpu().numpy() - want), logits.float().cpu().numpy(), g
+
+
+def test_t128_generator_matches_reference_cpu():
+    torch.set_num_threads(8)
+    err, logits, g = _run_t128('cpu')
+    assert err.max() <= 1e-3 + 2.5e-4, float(err.max())
+    np.testing.assert_allclose(logits, g['t128_logits'], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_t128_generator_matches_reference_gpu():
+    err, logits, g = _run_t128('cuda')
+    assert err.max() <= 1e-3 + 2.5e-4, float(err.max())
+    np.testing.assert_allclose(logits, g['t128_logits'], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_t128_bf16_generator_gate_gpu():
+    """configs[1] runs bf16 activations: gate the 128-frame bf16 video against the float32 reference video
+    (range +-0.84) at 8e-2 max / 8e-3 mean absolute error, and the logit at 0.1."""
+    err, logits, g = _run_t128('cuda', dtype=torch.bfloat16)
+    assert err.max() < 8e-2 and err.mean() < 8e-3, (float(err.max()), float(err.mean()))
+    assert abs(float(logits.reshape(-1)[0]) - float(g['t128_logits'].reshape(-1)[0])) < 0.1
+
+
+def _run_r1(device):
+    """R1 penalty (video_gan_lres.py:184-194): logits, d logits / d video, penalty and the parameter gradients
+    of the penalty (double backward through every op of the discriminator) vs the reference."""
+    import lvg.models.lres as lres
+    g = load_golden('lres_models_full')
+    D = VideoDiscriminator(seq_length=T, max_edge=64)
+    fill_named(D)
+    D = D.to(device).requires_grad_(True)
+    real = (torch.rand(2, 3, T, 36, 64, generator=torch.Generator().manual_seed(int(g['r1_real_seed']))) * 2 - 1).to(device).requires_grad_(True)
+    with lres.second_order():
+        logits = D(real)
+    (r1_grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[real], create_graph=True)
+    penalty = r1_grad.square().sum(dim=(1, 2, 3, 4))
+    (penalty * 0.5).mean().backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['r1_logits'], rtol=1e-3, atol=1e-4)
+    want = g['r1_input_grad']
+    np.testing.assert_allclose(r1_grad.detach().cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))
+    np.testing.assert_allclose(penalty.detach().cpu().numpy(), g['r1_penalty'], rtol=5e-3)
+    named = dict(D.named_parameters())
+    without = sorted(k for k, p in named.items() if p.grad is None)
+    assert ','.join(without) == str(g['r1_params_without_grad'])
+    for key in [k for k in g if k.startswith('r1_g_') and k.endswith('_sample')]:
+        stem = key[len('r1_g_'):-len('_sample')]
+        name = [n for n in named if n.replace('.', '_') == stem]
+        assert len(name) == 1, stem
+        flat = named[name[0]].grad.detach().cpu().numpy().reshape(-1)
+        norm = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        want_norm = float(g['r1_g_' + stem + '_norm'])
+        assert abs(norm - want_norm) <= 5e-3 * want_norm, (stem, norm, want_norm)
+        sample = flat[:: max(1, flat.size // 4096)][:4096]
+        want_s = g[key]
+        assert np.abs(sample - want_s).max() <= 5e-3 * (np.abs(want_s).max() + 1e-30), (stem, float(np.abs(sample - want_s).max()), float(np.abs(want_s).max()))
+
+
+def test_r1_penalty_gradients_match_reference_cpu():
+    torch.set_num_threads(8)
+    _run_r1('cpu')
+
+
+@pytest.mark.gpu
+def test_r1_penalty_gradients_match_reference_gpu():
+    _run_r1('cuda')
+
+
 def test_temporal_conv_frames_matches_conv3d_to_second_order():
     """The time-major decomposition (kt 2-D convs + hand-written backward) equals conv3d with zero
     padding, including the double backward that the R1 penalty needs."""
