@@ -25,3 +25,34 @@ def test_train_step_runs_and_updates_parameters():
     assert any(float(b) != 1.0 for b in ema_mag)                  # update_D ran G with beta = 0.999
     # gradients live in the persistent flat buffers
     assert tr.G_sync.flat.numel() == sum(p.numel() for p in tr.G.parameters())
+
+
+def test_update_r1_gradients_match_reference_golden():
+    """LowResTrainer.update_r1 with the augmentations off is deterministic: the gradients it leaves in the flat
+    exchange buffer must be the reference's R1 gradients (tests/golden/make_golden_models_full.py, gamma = 1)."""
+    import numpy as np
+    from conftest import load_golden
+    from helpers.named_fill import fill_named
+    from lvg.train_lres import LowResTrainer
+    g = load_golden('lres_models_full')
+    tr = LowResTrainer(seq_length=16, height=36, width=64, device='cuda', compute_dtype=torch.float32, r1_gamma=1.0,
+                       D_grad_accum=1, overlap_grad_sync=False, with_ema=False, temp_scale_augment=0.0, diffaug_policy='')
+    fill_named(tr.D)
+    real = (torch.rand(2, 3, 16, 36, 64, generator=torch.Generator().manual_seed(int(g['r1_real_seed']))) * 2 - 1).cuda()
+    before = {n: p.detach().clone() for n, p in tr.D.named_parameters()}
+    tr.update_r1(real, gain=1.0)
+    torch.cuda.synchronize()
+    named = dict(tr.D.named_parameters())
+    views = {n: v for (n, _), v in zip(tr.D.named_parameters(), tr.D_sync.views)}
+    for key in [k for k in g if k.startswith('r1_g_') and k.endswith('_sample')]:
+        stem = key[len('r1_g_'):-len('_sample')]
+        (name,) = [n for n in named if n.replace('.', '_') == stem]
+        flat = views[name].detach().cpu().numpy().reshape(-1)
+        want = g[key]
+        got = flat[:: max(1, flat.size // 4096)][:4096]
+        assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max(), (stem, float(np.abs(got - want).max()), float(np.abs(want).max()))
+    # the parameter autograd never reached keeps grad None -> Adam must not have touched it (reference: zero_grad(set_to_none=True))
+    unused = str(g['r1_params_without_grad']).split(',')
+    for n in unused:
+        assert named[n].grad is None and torch.equal(named[n].detach(), before[n]), n
+    assert any(not torch.equal(before[n], p.detach()) for n, p in named.items() if n not in unused)
