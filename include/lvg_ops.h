@@ -109,6 +109,14 @@ int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t* s,
                        float gain, float slope, float clamp, int flip, int sign_mode,
                        int dtype, void* stream);
 
+/*
+ * Which fused kernel serves float16 / bfloat16 tensors: 0 = default (the MFMA kernel, csrc/filtered_lrelu_mfma.hip,
+ * unless the environment says LVG_FLRELU_MFMA=0), 1 = the fp32-VALU kernel (csrc/filtered_lrelu.hip, the only one
+ * for float32), 2 = the MFMA kernel. Process-wide; returns the previous setting. No reference counterpart:
+ * a measurement / bisecting hook for tests and bench.py.
+ */
+int lvg_filtered_lrelu_set_impl(int impl);
+
 /* 1 if lvg_filtered_lrelu has a fused kernel for these parameters, else 0 (no launch). */
 int lvg_filtered_lrelu_supported(int fu_n, int fd_n, int up, int down, int dtype);
 

@@ -27,7 +27,9 @@
 // ceiling that actually binds at 16-bit I/O.
 
 #include "lvg_common.h"
+#include "filtered_lrelu_args.h"
 #include <atomic>
+#include <stdlib.h>
 
 namespace {
 
@@ -111,25 +113,6 @@ int launch_act(ActArgs& p, hipStream_t stream)
 // ---------------------------------------------------------------------------------------------
 // Fused kernel.
 
-struct FlreluArgs
-{
-    const void*  x;
-    void*        y;
-    const void*  b;
-    uint8_t*     s;
-    const float* fu;
-    const float* fd;
-    int64_t      xs[4], ys[4];
-    int          n, c, xh, xw, yh, yw;
-    int          fuN, fdN;       // actual tap counts (<= template FU / FD)
-    int          px0, py0;
-    int          sWBytes, sH;    // mask plane: bytes per row, rows
-    int          sOfsX, sOfsY;
-    int          swLimit;        // bytes per row that carry pixels
-    float        gain, slope, clamp;
-    int          flip;
-    int          tilesX, tilesY;
-};
 
 constexpr int kNT = 512; // threads per workgroup
 
@@ -551,7 +534,8 @@ __global__ __launch_bounds__(256) void filtered_lrelu_pointwise_kernel(FlreluArg
 // ---------------------------------------------------------------------------------------------
 // Host side: specialisation table.
 
-enum { CFG_NONE = 0, CFG_POINTWISE, CFG_U2D2, CFG_U4D2, CFG_U2D4 };
+enum { CFG_NONE = LVG_FLRELU_CFG_NONE, CFG_POINTWISE = LVG_FLRELU_CFG_POINTWISE, CFG_U2D2 = LVG_FLRELU_CFG_U2D2,
+       CFG_U4D2 = LVG_FLRELU_CFG_U4D2, CFG_U2D4 = LVG_FLRELU_CFG_U2D4 };
 
 int pick_config(int fuN, int fdN, int up, int down)
 {
@@ -649,6 +633,14 @@ extern "C" int lvg_filtered_lrelu_act(void* x, uint8_t* s, const int64_t xshape[
     }
 }
 
+static std::atomic<int> g_flrelu_impl{0};
+
+extern "C" int lvg_filtered_lrelu_set_impl(int impl)
+{
+    if (impl < 0 || impl > 2) return LVG_ERR_INVALID;
+    return g_flrelu_impl.exchange(impl);
+}
+
 extern "C" int lvg_filtered_lrelu_supported(int fu_n, int fd_n, int up, int down, int dtype)
 {
     if (dtype != LVG_F32 && dtype != LVG_F16 && dtype != LVG_BF16) return 0;
@@ -704,6 +696,13 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     p.tilesX = p.tilesY = 0;
 
     hipStream_t st = (hipStream_t)stream;
+    // 16-bit I/O: the MFMA kernel (filtered_lrelu_mfma.hip). LVG_FLRELU_MFMA=0 keeps the fp32-VALU kernel
+    // for every dtype (A/B measurements, bisecting); float32 I/O always uses it (exact f32 intermediates).
+    static const bool env_mfma = []() { const char* e = getenv("LVG_FLRELU_MFMA"); return !(e && e[0] == '0'); }();
+    const int impl = g_flrelu_impl.load(std::memory_order_relaxed);
+    const bool use_mfma = impl == 0 ? env_mfma : impl == 2;
+    if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
+        return lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);
     switch (dtype)
     {
         case LVG_F32:  return run_fused<float>(p, cfg, sign_mode, st);

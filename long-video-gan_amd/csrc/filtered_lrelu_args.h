@@ -1,0 +1,30 @@
+// filtered_lrelu_args.h -- launch arguments shared by the two fused filtered_lrelu kernels of liblvg_hip.so:
+// the fp32-VALU kernel (filtered_lrelu.hip: float32 I/O, exact float32 intermediates) and the MFMA kernel
+// (filtered_lrelu_mfma.hip: float16 / bfloat16 I/O, the four FIR stages as banded matrix products).
+#pragma once
+#include "lvg_common.h"
+
+struct FlreluArgs
+{
+    const void*  x;
+    void*        y;
+    const void*  b;
+    uint8_t*     s;
+    const float* fu;
+    const float* fd;
+    int64_t      xs[4], ys[4];
+    int          n, c, xh, xw, yh, yw;
+    int          fuN, fdN;       // actual tap counts (<= template FU / FD)
+    int          px0, py0;
+    int          sWBytes, sH;    // mask plane: bytes per row, rows
+    int          sOfsX, sOfsY;
+    int          swLimit;        // bytes per row that carry pixels
+    float        gain, slope, clamp;
+    int          flip;
+    int          tilesX, tilesY;
+};
+
+enum { LVG_FLRELU_CFG_NONE = 0, LVG_FLRELU_CFG_POINTWISE, LVG_FLRELU_CFG_U2D2, LVG_FLRELU_CFG_U4D2, LVG_FLRELU_CFG_U2D4 };
+
+// filtered_lrelu_mfma.hip. dtype is LVG_F16 or LVG_BF16; cfg one of U2D2 / U4D2 / U2D4.
+int lvg_flrelu_mfma_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);

@@ -1,0 +1,508 @@
+// filtered_lrelu_mfma.hip -- fused bias -> up-FIR -> gain -> leaky ReLU -> clamp -> down-FIR for float16 /
+// bfloat16 tensors on gfx950, with the four separable FIR stages run on the matrix cores.
+//
+// Semantics: exactly those of filtered_lrelu.hip (reference torch_utils/ops/filtered_lrelu.cu:139-1099,
+// filtered_lrelu.cpp:16-210), including the 2-bit sign / clamp mask (write and read with offsets).
+//
+// Why MFMA: at 16-bit I/O the op moves ~5 bytes per output pixel but needs >= 72 FMAs per output pixel
+// (12 + 24 + 24 + 12 for an up-2 / down-2 layer with 12-tap filters); the fp32 vector pipe caps that at about a
+// third of the HBM roofline. A zero-insertion FIR is a banded (block-Toeplitz) matrix; as dense 32x32x16 f16
+// MFMAs the band wastes ~7x the multiplies but the matrix pipe is 16x faster than the vector pipe.
+//
+// One workgroup = 4 waves = one 128 x 128 tile of the UP-SAMPLED plane (u = columns, v = rows). With
+// X the input tile, A_y / A_x the zero-insertion up-sampling matrices and D_x / D_y the decimating ones:
+//
+//   stage A  T'[ic][v] = sum_ir X[ir][ic] * A_y[v][ir]     X^T is the A operand (LDS transpose read), A_y^T constant
+//   stage B  U^T[u][v] = sum_ic A_x[u][ic] * T'[ic][v]     A_x constant, T' = stage A's accumulators (registers)
+//   act      Z^T = clamp(lrelu(U^T)), sign / clamp mask    4 consecutive u per lane = one mask byte
+//   stage C  W[ox][v]  = sum_u  D_x[ox][u] * Z^T[u][v]     D_x constant, Z^T from registers
+//            W -> LDS as [v][ox]                            (the only intermediate that leaves the registers)
+//   stage D  Y[oy][ox] = sum_v  D_y[oy][v] * W[v][ox]      W via LDS transpose read; lanes = ox: row-contiguous stores
+//
+// Every stage is a LEFT multiplication of the running matrix, whose 32x32 MFMA result layout (lane = column,
+// registers = rows) is already the B-operand layout of the next MFMA up to a fixed permutation of k inside each
+// 16-row chunk -- the constant operand is stored with the same permutation, so stages A -> B -> C chain through
+// registers. Wave w owns rows v in [32w, 32w + 32) of the up-sampled tile through stages A - C; stage D splits the
+// output blocks over the waves. Two barriers per tile. The constant operands ("fragments": 32 x 16 slices of
+// the banded matrices, one per distinct band offset) are built once per workgroup in LDS; workgroups are
+// persistent and walk over tiles.
+//
+// Arithmetic: f16 operands (bfloat16 tensors are converted: their 8-bit mantissa is exact in f16), f32
+// accumulation; T', Z and W are rounded to f16 between stages (one rounding each, like the reference's
+// non-fused path which rounds after every op); filter taps are rounded to f16.
+// Algorithmic HBM bytes: (N_in + N_out) * 2 + mask bytes; see DESIGN.md.
+
+#include "lvg_common.h"
+#include "filtered_lrelu_args.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;   // 4 waves
+constexpr int kUpT = 128;       // edge of the up-sampled tile (4 blocks of 32)
+
+constexpr int mdiv_up(int a, int b) { return (a + b - 1) / b; }
+
+template <int UP, int DOWN, int FU, int FD, int TW, int TH>
+struct MG
+{
+    static constexpr int KU     = FU / UP;                                  // taps per output of an up stage
+    static constexpr int IN_N   = (UP - 1 + kUpT - 1) / UP + KU;            // input rows / columns a tile touches
+    static constexpr int IN_BLK = mdiv_up(IN_N, 32);                        // 32-blocks of input columns (stage A's M)
+    static constexpr int IN_CH  = ((((kUpT - 1 + UP - 1) / UP) + KU - 1) >> 4) + 1;   // 16-chunks of input rows / columns
+    static constexpr int X_ROWS = IN_CH * 16;
+    static constexpr int SX     = 96;                                       // X row stride (halves); SX/2 = 48 mod 64 spreads the transpose reads
+    static constexpr int OBX    = mdiv_up(TW, 32);
+    static constexpr int OBY    = mdiv_up(TH, 32);
+    static constexpr int SW     = OBX * 32 + 4;                             // W row stride (halves): 8-byte column writes of 16 rows hit 32 distinct banks
+    static constexpr int NUC    = (UP == 2) ? 2 : (UP == 4 ? 3 : 1);        // distinct band offsets of an up stage
+    static constexpr int NDC    = ((31 * DOWN + FD - 1 + 3) >> 4) + 1;      // ... of a down stage (+3: READ-mode column shift)
+    static constexpr int IMG_FY = 0;                                        // fragment images: A_y natural k order (stage A)
+    static constexpr int IMG_FX = NUC;                                      //                  A_x permuted k order, scaled (stage B)
+    static constexpr int IMG_DX = 2 * NUC;                                  //                  D_x permuted (stage C)
+    static constexpr int IMG_DY = 2 * NUC + NDC;                            //                  D_y natural (stage D)
+    static constexpr int NIMG   = 2 * NUC + 2 * NDC;
+    static constexpr int TAPS   = (FU + FD + 3) / 4 * 4;
+    // LDS map (bytes)
+    static constexpr int OFF_TAPS = 0;
+    static constexpr int OFF_TAB  = TAPS * 4;
+    static constexpr int OFF_X    = OFF_TAB + NIMG * 1024;
+    static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2;
+    static constexpr int OFF_M    = OFF_W + kUpT * SW * 2;
+    static constexpr int LDS_BYTES = OFF_M + kUpT * 32;
+    static_assert(FU % UP == 0 && FD % DOWN == 0, "filter sizes must be multiples of the rates");
+    static_assert(IN_N % 2 == 0 && IN_BLK * 32 <= SX, "input tile geometry");
+    static_assert((TW * DOWN) % 4 == 0 && (TW * DOWN) % UP == 0 && (TH * DOWN) % UP == 0, "tile origin must keep the mask byte and the up-sampling phase fixed");
+    static_assert((TW - 1) * DOWN + FD - 1 + 3 < kUpT && (TH - 1) * DOWN + FD - 1 < kUpT, "tile does not fit the 128 x 128 up-sampled block");
+    static_assert(OBX * OBY <= 4, "stage D: one output block per wave");
+    static_assert(LDS_BYTES <= 64 * 1024, "LDS budget");
+    static_assert(OFF_TAB % 16 == 0 && OFF_X % 16 == 0 && OFF_W % 16 == 0 && OFF_M % 16 == 0, "alignment");
+};
+
+// Offset (in input samples, relative to the first input sample of a 32-output block) of up-stage class `cls`.
+template <int UP> __host__ __device__ constexpr int up_class_offset(int cls) { return UP == 2 ? 16 * cls : (UP == 4 ? 8 * cls - 8 : 0); }
+
+// 16-chunks of the input that output block b of an up stage needs: first chunk, count, class of the first, class step.
+template <int UP> struct UpChunks
+{
+    __host__ __device__ static constexpr int first(int b)  { return UP == 2 ? b : (UP == 4 ? ((b & 1) ? (b - 1) / 2 : b / 2) : 2 * b); }
+    __host__ __device__ static constexpr int count(int b)  { return UP == 2 ? 2 : (UP == 4 ? ((b & 1) ? 2 : 1) : 2); }
+    __host__ __device__ static constexpr int cls0(int b)   { return UP == 2 ? 0 : (UP == 4 ? ((b & 1) ? 0 : 1) : 0); }
+    __host__ __device__ static constexpr int step()        { return UP == 4 ? 2 : 1; }
+};
+
+__device__ __forceinline__ half8 lds_frag(const _Float16* tab, int img, int lane)
+{
+    return *reinterpret_cast<const half8*>(tab + img * 512 + lane * 8);
+}
+
+// MFMA operand (lane: index = lane & 31 along the COLUMNS of a row-major LDS matrix, k = 8 * (lane >> 5) + j along
+// its ROWS) through the gfx950 transpose read: 16 lanes fetch a 4 (rows) x 16 (columns) block, lane s supplying
+// the address of row (s >> 2), columns 4 * (s & 3) .. + 3, and lane l receiving column l of the 4 rows
+// (measured: tools/probe_mfma_layout.hip).
+__device__ __forceinline__ half8 lds_tr_operand(const _Float16* base, int stride, int row0, int col0, int lane)
+{
+    const int g = lane >> 5, hgrp = (lane >> 4) & 1, s = lane & 15;
+    const _Float16* p = base + (row0 + 8 * g + (s >> 2)) * stride + col0 + 16 * hgrp + 4 * (s & 3);
+    typedef __attribute__((address_space(3))) short4v* lds_ptr;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * stride));
+    half8 r;
+    __builtin_memcpy(&r, &lo, 8);
+    __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &hi, 8);
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// Rows 16 * h .. 16 * h + 15 of a 32x32 result as the B operand of the next MFMA (k order: see the header).
+__device__ __forceinline__ half8 pack_chunk(const f32x16& c, int h)
+{
+    half8 r;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = (_Float16)c[8 * h + j];
+    return r;
+}
+
+template <class T> __device__ __forceinline__ float load_in(const T* p);
+template <> __device__ __forceinline__ float load_in<f16_t>(const f16_t* p) { return to_acc(*p); }
+template <> __device__ __forceinline__ float load_in<bf16_t>(const bf16_t* p) { return to_acc(*p); }
+
+template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH, int MODE>
+__global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(FlreluArgs p, int totalTiles)
+{
+    typedef MG<UP, DOWN, FU, FD, TW, TH> G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float*     taps = reinterpret_cast<float*>(smem + G::OFF_TAPS);        // [0, FU): up taps, [FU, FU + FD): down taps (flipped)
+    _Float16*  tab  = reinterpret_cast<_Float16*>(smem + G::OFF_TAB);      // fragment images, 512 halves each, lane-major
+    _Float16*  XL   = reinterpret_cast<_Float16*>(smem + G::OFF_X);        // input tile + bias [X_ROWS][SX]
+    _Float16*  WL   = reinterpret_cast<_Float16*>(smem + G::OFF_W);        // W [128 v][SW]
+    uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][32 bytes]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 31, g = lane >> 5;
+
+    // ---- once per workgroup: taps, fragment images, zero the padding of the input tile -------------------
+    if (tid < FU)
+    {
+        float v = 0.0f;
+        if (tid < p.fuN) v = p.fu ? p.fu[p.flip ? tid : p.fuN - 1 - tid] : 1.0f;
+        taps[tid] = v;
+    }
+    else if (tid < FU + FD)
+    {
+        const int t = tid - FU;
+        float v = 0.0f;
+        if (t < p.fdN) v = p.fd ? p.fd[p.flip ? t : p.fdN - 1 - t] : 1.0f;
+        taps[FU + t] = v;
+    }
+    for (int i = tid; i < G::X_ROWS * G::SX / 2; i += kThreads) reinterpret_cast<uint32_t*>(XL)[i] = 0u;
+    __syncthreads();
+
+    // Launch-constant geometry: the column shift that aligns the tile with the mask bytes in READ mode and the
+    // zero-insertion phases (tile origins are multiples of 4 and of UP in the up-sampled plane).
+    const int rOff = (MODE == LVG_SIGNS_READ) ? (p.sOfsX & 3) : 0;
+    const int phX = ((UP - 1 - p.px0 - rOff) % UP + UP) % UP;
+    const int phY = ((UP - 1 - p.py0) % UP + UP) % UP;
+    {
+        const float scale = (float)(UP * UP) * p.gain;
+        for (int e = tid; e < G::NIMG * 512; e += kThreads)
+        {
+            const int img = e >> 9, idx = e & 511, L = idx >> 3, j = idx & 7, row = L & 31, gg = L >> 5;
+            const bool perm = img >= G::IMG_FX && img < G::IMG_DY;
+            const int k = perm ? ((j & 3) + 8 * (j >> 2) + 4 * gg) : (8 * gg + j);
+            float v = 0.0f;
+            if (img < G::IMG_DX)
+            {
+                // up stage: output row (local u' or v'), input sample kk relative to the block's first input sample
+                const bool isX = img >= G::IMG_FX;
+                const int ph = isX ? phX : phY;
+                const int kk = up_class_offset<UP>(isX ? img - G::IMG_FX : img) + k;
+                const int m = row + ph, i0 = m / UP, t = kk - i0;
+                if (t >= 0 && t < G::KU) v = taps[(UP - 1 - m % UP) + t * UP] * (isX ? scale : 1.0f);
+            }
+            else
+            {
+                const bool isX = img < G::IMG_DY;
+                const int cls = isX ? img - G::IMG_DX : img - G::IMG_DY;
+                const int t = 16 * cls + k - (isX ? rOff : 0) - row * DOWN;
+                if (t >= 0 && t < FD) v = taps[FU + t];
+            }
+            tab[e] = (_Float16)v;
+        }
+    }
+    // (the first barrier inside the tile loop publishes the table)
+
+    for (int tile = blockIdx.x; tile < totalTiles; tile += gridDim.x)
+    {
+        int bid = tile;
+        const int tileX = bid % p.tilesX; bid /= p.tilesX;
+        const int tileY = bid % p.tilesY; bid /= p.tilesY;
+        const int ch = bid % p.c;
+        const int nb = bid / p.c;
+        const int64_t plane = (int64_t)nb * p.c + ch;
+
+        const int outX0 = tileX * TW, outY0 = tileY * TH;
+        const int uStart = outX0 * DOWN - rOff, upY0 = outY0 * DOWN;        // up-sampled pixel (0, 0) of the tile
+        const int inX0 = lvg_floor_div(uStart + UP - 1 - p.px0, UP);
+        const int inY0 = lvg_floor_div(upY0 + UP - 1 - p.py0, UP);
+        const int signByte0 = (uStart + p.sOfsX) >> 2;                       // exact: a multiple of 4
+        const int signY0 = upY0 + p.sOfsY;
+        const int64_t signPlane = plane * (int64_t)p.sH * p.sWBytes;
+
+        // ---- input tile (+ bias on real pixels, zero outside the image) -> XL, two columns per thread ----
+        {
+            const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1];
+            const float bias = (float)to_acc(((const T*)p.b)[ch]);
+            constexpr int PAIRS = G::IN_N / 2;
+            constexpr int TOTAL = G::IN_N * PAIRS;
+            constexpr int PER = mdiv_up(TOTAL, kThreads);
+            float v0[PER], v1[PER];
+            #pragma unroll
+            for (int i = 0; i < PER; i++)
+            {
+                const int idx = tid + i * kThreads;
+                const int r = idx / PAIRS, q = (idx - r * PAIRS) * 2;
+                const int iy = inY0 + r, ix = inX0 + q;
+                v0[i] = 0.0f; v1[i] = 0.0f;
+                if (idx < TOTAL && iy >= 0 && iy < p.xh)
+                {
+                    const T* row = xp + (int64_t)iy * p.xs[2];
+                    if (ix >= 0 && ix < p.xw)         v0[i] = load_in<T>(row + (int64_t)ix * p.xs[3]) + bias;
+                    if (ix + 1 >= 0 && ix + 1 < p.xw) v1[i] = load_in<T>(row + (int64_t)(ix + 1) * p.xs[3]) + bias;
+                }
+            }
+            #pragma unroll
+            for (int i = 0; i < PER; i++)
+            {
+                const int idx = tid + i * kThreads;
+                const int r = idx / PAIRS, q = (idx - r * PAIRS) * 2;
+                if (idx < TOTAL)
+                {
+                    // bfloat16 inputs beyond the f16 range saturate instead of turning into inf (inf * 0 taps = NaN)
+                    half2v h;
+                    h[0] = (_Float16)__builtin_fminf(__builtin_fmaxf(v0[i], -65504.0f), 65504.0f);
+                    h[1] = (_Float16)__builtin_fminf(__builtin_fmaxf(v1[i], -65504.0f), 65504.0f);
+                    *reinterpret_cast<half2v*>(XL + r * G::SX + q) = h;
+                }
+            }
+        }
+        // ---- READ mode: mask tile -> ML (zero = "positive, not clamped" outside the stored plane) --------
+        if (MODE == LVG_SIGNS_READ)
+        {
+            const int row = tid >> 1, half = tid & 1;
+            const int sy = signY0 + row;
+            const bool rowOk = sy >= 0 && sy < p.sH;
+            const uint8_t* srow = p.s + signPlane + (int64_t)sy * p.sWBytes;
+            uint32_t wds[4];
+            #pragma unroll
+            for (int d = 0; d < 4; d++)
+            {
+                const int bx0 = signByte0 + 16 * half + 4 * d;
+                uint32_t v = 0;
+                if (rowOk)
+                {
+                    if ((signByte0 & 3) == 0 && bx0 >= 0 && bx0 + 4 <= p.swLimit) v = *reinterpret_cast<const uint32_t*>(srow + bx0);
+                    else
+                    {
+                        #pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (bx0 + k >= 0 && bx0 + k < p.swLimit) v |= (uint32_t)srow[bx0 + k] << (8 * k);
+                    }
+                }
+                wds[d] = v;
+            }
+            *reinterpret_cast<uint4*>(ML + row * 32 + 16 * half) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+        __syncthreads();                                                    // barrier 1: XL (ML, table) visible; previous tile's stage D done
+
+        // ---- stage A: T'[ic][v] for this wave's 32 rows v ------------------------------------------------
+        half8 tpk[G::IN_BLK][2];
+        {
+            f32x16 accA[G::IN_BLK];
+            #pragma unroll
+            for (int m = 0; m < G::IN_BLK; m++)
+                #pragma unroll
+                for (int r = 0; r < 16; r++) accA[m][r] = 0.0f;
+            const int c0 = UpChunks<UP>::first(w), cnt = UpChunks<UP>::count(w), cls0 = UpChunks<UP>::cls0(w);
+            #pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+                if (t < cnt)
+                {
+                    const half8 fy = lds_frag(tab, G::IMG_FY + cls0 + t * UpChunks<UP>::step(), lane);
+                    #pragma unroll
+                    for (int m = 0; m < G::IN_BLK; m++)
+                    {
+                        const half8 xt = lds_tr_operand(XL, G::SX, 16 * (c0 + t), 32 * m, lane);
+                        accA[m] = mfma(xt, fy, accA[m]);
+                    }
+                }
+            }
+            #pragma unroll
+            for (int m = 0; m < G::IN_BLK; m++) { tpk[m][0] = pack_chunk(accA[m], 0); tpk[m][1] = pack_chunk(accA[m], 1); }
+        }
+
+        // ---- stages B, activation, C, interleaved over the four 32-column blocks of u ---------------------
+        f32x16 accW[G::OBX];
+        #pragma unroll
+        for (int bo = 0; bo < G::OBX; bo++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) accW[bo][r] = 0.0f;
+        const float slope = p.slope, clampv = p.clamp;
+        uint8_t* mrow = ML + (32 * w + n) * 32;
+        #pragma unroll
+        for (int b = 0; b < 4; b++)
+        {
+            f32x16 accU;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) accU[r] = 0.0f;
+            #pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+                if (t < UpChunks<UP>::count(b))
+                {
+                    const int c = UpChunks<UP>::first(b) + t;
+                    const half8 fx = lds_frag(tab, G::IMG_FX + UpChunks<UP>::cls0(b) + t * UpChunks<UP>::step(), lane);
+                    accU = mfma(fx, tpk[c >> 1][c & 1], accU);
+                }
+            }
+            // activation: register r holds u = 32 b + (r & 3) + 8 (r >> 2) + 4 g of row v = 32 w + n;
+            // registers 4q .. 4q + 3 are the four pixels of mask byte 8 b + 2 q + g.
+            #pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                uint32_t bits = 0;
+                if (MODE == LVG_SIGNS_READ) bits = mrow[8 * b + 2 * q + g];
+                #pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    float a = accU[4 * q + e];
+                    if (MODE == LVG_SIGNS_READ)
+                    {
+                        const uint32_t sb = bits >> (2 * e);
+                        if (sb & 1) a *= slope;
+                        if (sb & 2) a = 0.0f;
+                    }
+                    else
+                    {
+                        uint32_t sb = __float_as_uint(a) >> 31;                  // IEEE sign bit (-0.0 counts)
+                        if (sb) a *= slope;
+                        if (fabsf(a) > clampv) { sb = 2; a = (a < 0.0f) ? -clampv : clampv; }
+                        bits |= sb << (2 * e);
+                    }
+                    accU[4 * q + e] = a;
+                }
+                if (MODE == LVG_SIGNS_WRITE) mrow[8 * b + 2 * q + g] = (uint8_t)bits;
+            }
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+            {
+                const half8 z = pack_chunk(accU, h);
+                const int c = 2 * b + h;
+                #pragma unroll
+                for (int bo = 0; bo < G::OBX; bo++)
+                {
+                    const int cls = c - 2 * bo * DOWN;
+                    if (cls >= 0 && cls < G::NDC)
+                        accW[bo] = mfma(lds_frag(tab, G::IMG_DX + cls, lane), z, accW[bo]);
+                }
+            }
+        }
+        // W[ox][v] -> WL[v][ox]: registers 4q .. 4q + 3 are four consecutive ox
+        #pragma unroll
+        for (int bo = 0; bo < G::OBX; bo++)
+            #pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                half4 h;
+                #pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = (_Float16)accW[bo][4 * q + e];
+                *reinterpret_cast<half4*>(WL + (32 * w + n) * G::SW + 32 * bo + 8 * q + 4 * g) = h;
+            }
+        __syncthreads();                                                    // barrier 2: WL (and ML in WRITE mode) complete
+
+        // ---- WRITE mode: mask tile -> global, only the part this tile owns --------------------------------
+        if (MODE == LVG_SIGNS_WRITE)
+        {
+            const int ownBytes = (tileX == p.tilesX - 1) ? 32 : (TW * DOWN) / 4;
+            const int ownRows  = (tileY == p.tilesY - 1) ? kUpT : TH * DOWN;
+            const int row = tid >> 1, half = tid & 1;
+            const int sy = signY0 + row;
+            if (row < ownRows && sy >= 0 && sy < p.sH)
+            {
+                uint8_t* srow = p.s + signPlane + (int64_t)sy * p.sWBytes;
+                const uint4 v = *reinterpret_cast<const uint4*>(ML + row * 32 + 16 * half);
+                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+                #pragma unroll
+                for (int d = 0; d < 4; d++)
+                {
+                    const int k0 = 16 * half + 4 * d, bx0 = signByte0 + k0;
+                    if (k0 + 4 <= ownBytes && bx0 >= 0 && bx0 + 4 <= p.swLimit) *reinterpret_cast<uint32_t*>(srow + bx0) = wds[d];
+                    else
+                    {
+                        #pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (k0 + k < ownBytes && bx0 + k >= 0 && bx0 + k < p.swLimit) srow[bx0 + k] = (uint8_t)(wds[d] >> (8 * k));
+                    }
+                }
+            }
+            // bytes of the 16-pixel row padding carry no pixels: define them as 0
+            if (tileX == p.tilesX - 1 && p.sWBytes > p.swLimit)
+            {
+                const int padBytes = p.sWBytes - p.swLimit;
+                for (int idx = tid; idx < ownRows * padBytes; idx += kThreads)
+                {
+                    const int v = idx / padBytes, k = idx - v * padBytes;
+                    const int sy2 = signY0 + v;
+                    if (sy2 >= 0 && sy2 < p.sH) p.s[signPlane + (int64_t)sy2 * p.sWBytes + p.swLimit + k] = 0;
+                }
+            }
+        }
+
+        // ---- stage D: one 32 x 32 output block per wave ---------------------------------------------------
+        if (w < G::OBX * G::OBY)
+        {
+            const int by = w / G::OBX, bx = w - by * G::OBX;
+            f32x16 accY;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) accY[r] = 0.0f;
+            #pragma unroll
+            for (int cls = 0; cls < G::NDC; cls++)
+            {
+                const int c = 2 * by * DOWN + cls;
+                if (c < 8)
+                {
+                    const half8 fd = lds_frag(tab, G::IMG_DY + cls, lane);
+                    const half8 wt = lds_tr_operand(WL, G::SW, 16 * c, 32 * bx, lane);
+                    accY = mfma(fd, wt, accY);
+                }
+            }
+            T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1];
+            const int oxl = 32 * bx + n, ox = outX0 + oxl;
+            if (oxl < TW && ox < p.yw)
+            {
+                #pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const int oyl = 32 * by + (r & 3) + 8 * (r >> 2) + 4 * g, oy = outY0 + oyl;
+                    if (oyl < TH && oy < p.yh) yp[(int64_t)oy * p.ys[2] + (int64_t)ox * p.ys[3]] = from_acc<T>(accY[r]);
+                }
+            }
+        }
+    }
+}
+
+template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH>
+int launch_mfma(FlreluArgs& p, int mode, hipStream_t stream)
+{
+    typedef MG<UP, DOWN, FU, FD, TW, TH> G;
+    p.tilesX = (p.yw + TW - 1) / TW;
+    p.tilesY = (p.yh + TH - 1) / TH;
+    const int64_t tiles = (int64_t)p.tilesX * p.tilesY * p.n * p.c;
+    LVG_REQUIRE(tiles <= 0x7fffffffLL, "filtered_lrelu: too many tiles for one launch");
+    // Persistent workgroups: 3 per CU fit (LDS), each walks over tiles with stride gridDim.
+    static int cus[64] = {0};
+    int dev = 0; (void)hipGetDevice(&dev);
+    int ncu = cus[dev & 63];
+    if (ncu == 0)
+    {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        cus[dev & 63] = ncu;
+    }
+    const int64_t maxGrid = (int64_t)ncu * 3;
+    const unsigned grid = (unsigned)(tiles < maxGrid ? tiles : maxGrid);
+    const size_t lds = G::LDS_BYTES;
+    if (mode == LVG_SIGNS_WRITE)     hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_WRITE>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles);
+    else if (mode == LVG_SIGNS_READ) hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_READ>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles);
+    else                             hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_NONE>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles);
+    return lvg_check_launch("filtered_lrelu_mfma_kernel");
+}
+
+template <class T>
+int run_mfma(FlreluArgs& p, int cfg, int mode, hipStream_t stream)
+{
+    switch (cfg)
+    {
+        case LVG_FLRELU_CFG_U2D2: return launch_mfma<T, 2, 2, 12, 12, 56, 58>(p, mode, stream);
+        case LVG_FLRELU_CFG_U4D2: return launch_mfma<T, 4, 2, 24, 12, 56, 58>(p, mode, stream);
+        case LVG_FLRELU_CFG_U2D4: return launch_mfma<T, 2, 4, 12, 24, 26, 27>(p, mode, stream);
+    }
+    return LVG_ERR_UNSUPPORTED;
+}
+
+} // namespace
+
+int lvg_flrelu_mfma_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream)
+{
+    if (dtype == LVG_F16)  return run_mfma<f16_t>(p, cfg, mode, stream);
+    if (dtype == LVG_BF16) return run_mfma<bf16_t>(p, cfg, mode, stream);
+    return LVG_ERR_UNSUPPORTED;
+}

@@ -25,6 +25,7 @@ _SIGNATURES = {
     'lvg_upfirdn2d': [_vp] * 5 + [_i64x4] * 4 + [_i32, _i32, _i64, _i64] + [_i32] * 4 + [_i32, _i32, _i32, _f32, _i32, _vp],
     'lvg_filtered_lrelu': [_vp] * 6 + [_i64x4] * 4 + [_i32] * 6 + [_i64x2, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _vp],
     'lvg_filtered_lrelu_supported': [_i32] * 5,
+    'lvg_filtered_lrelu_set_impl': [_i32],
     'lvg_filtered_lrelu_act': [_vp, _vp, _i64x4, _i64x4, _i64x2, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _vp],
     'lvg_modconv_epilogue': [_vp] * 6 + [_i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_modconv_epilogue_backward': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
