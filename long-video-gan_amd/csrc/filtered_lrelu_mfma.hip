@@ -35,6 +35,12 @@
 #include "lvg_common.h"
 #include "filtered_lrelu_args.h"
 
+#ifdef LVG_MARKERS     // analysis builds only (tools/isa_count.py --regions): region labels in the listing
+#define LVG_MARK(name) asm volatile("; LVGMARK " name)
+#else
+#define LVG_MARK(name)
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -70,7 +76,8 @@ struct MG
     static constexpr int TAPS   = (FU + FD + 3) / 4 * 4;
     // LDS map (bytes)
     static constexpr int OFF_TAPS = 0;
-    static constexpr int OFF_TAB  = TAPS * 4;
+    static constexpr int OFF_LUT  = TAPS * 4;                               // 16 dwords (READ mode)
+    static constexpr int OFF_TAB  = OFF_LUT + 64;
     static constexpr int OFF_X    = OFF_TAB + NIMG * 1024;
     static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2;
     static constexpr int OFF_M    = OFF_W + kUpT * SW * 2;
@@ -132,21 +139,104 @@ __device__ __forceinline__ half8 pack_chunk(const f32x16& c, int h)
     return r;
 }
 
-template <class T> __device__ __forceinline__ float load_in(const T* p);
-template <> __device__ __forceinline__ float load_in<f16_t>(const f16_t* p) { return to_acc(*p); }
-template <> __device__ __forceinline__ float load_in<bf16_t>(const bf16_t* p) { return to_acc(*p); }
+__device__ __forceinline__ uint32_t h2_bits(half2v v) { uint32_t u; __builtin_memcpy(&u, &v, 4); return u; }
+__device__ __forceinline__ half2v bits_h2(uint32_t u) { half2v v; __builtin_memcpy(&v, &u, 4); return v; }
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH, int MODE>
+// Two stored elements (element 0 in the low half of the dword) + bias -> f16 pair. bfloat16 values beyond the
+// f16 range saturate instead of turning into inf (inf * a zero tap of the banded matrix would be NaN).
+template <class T> __device__ __forceinline__ half2v pair_plus_bias(uint32_t raw, half2v bias2, float bias);
+template <> __device__ __forceinline__ half2v pair_plus_bias<f16_t>(uint32_t raw, half2v bias2, float) { return bits_h2(raw) + bias2; }
+template <> __device__ __forceinline__ half2v pair_plus_bias<bf16_t>(uint32_t raw, half2v, float bias)
+{
+    const float a = __uint_as_float(raw << 16) + bias, b = __uint_as_float(raw & 0xffff0000u) + bias;
+    half2v r;
+    r[0] = (_Float16)__builtin_fminf(__builtin_fmaxf(a, -65504.0f), 65504.0f);
+    r[1] = (_Float16)__builtin_fminf(__builtin_fmaxf(b, -65504.0f), 65504.0f);
+    return r;
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// Activation of one 32 x 32 block of U^T held as an MFMA result (register r = pixel u = (r & 3) + 8 (r >> 2) + 4 g of
+// this lane's row v), in packed f16: leaky ReLU, clamp, and the 2-bit mask codes (1 = negative, 2 = clamped).
+// Registers 4q .. 4q + 3 are the four pixels of one mask byte (mbytes[2 q]). Result: the block as 8 packed dwords =
+// the two B-operand chunks of the next MFMA. READ mode multiplies by (1, slope, 0) looked up from the stored codes.
+// The file is compiled with -fno-honor-nans (no canonicalisation ops around min / max): a NaN pre-activation
+// comes out as -clamp instead of NaN.
+template <int MODE, bool SLOPEMAX>
+__device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8], uint8_t* mbytes, const uint32_t* lut,
+                                          half2v slope2, half2v clampP, half2v clampN, uint32_t clampBits)
+{
+    #pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        half2v P[2];
+        #pragma unroll
+        for (int h = 0; h < 2; h++) { P[h][0] = (_Float16)accU[4 * q + 2 * h]; P[h][1] = (_Float16)accU[4 * q + 2 * h + 1]; }
+        if (MODE == LVG_SIGNS_READ)
+        {
+            const uint32_t bits = mbytes[2 * q];
+            #pragma unroll
+            for (int h = 0; h < 2; h++) zp[2 * q + h] = h2_bits(P[h] * bits_h2(lut[(bits >> (4 * h)) & 15u]));
+        }
+        else
+        {
+            half2v L[2];
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+            {
+                const half2v ls = P[h] * slope2;
+                if (SLOPEMAX) L[h] = __builtin_elementwise_max(P[h], ls);    // 0 <= slope <= 1
+                else
+                {
+                    short2v pi, li;
+                    __builtin_memcpy(&pi, &P[h], 4); __builtin_memcpy(&li, &ls, 4);
+                    const short2v m = pi >> 15;                              // all ones where the half is negative (sign bit: -0.0 counts)
+                    const short2v r = (li & m) | (pi & ~m);
+                    __builtin_memcpy(&L[h], &r, 4);
+                }
+            }
+            if (MODE == LVG_SIGNS_WRITE)
+            {
+                // bytes 1 and 3 of each pair carry the sign bits; "clamped" = sign bit of (clamp - |L|) as 16-bit integers
+                const uint32_t S = __builtin_amdgcn_perm(h2_bits(P[1]), h2_bits(P[0]), 0x07050301u);
+                uint32_t Tb[2];
+                #pragma unroll
+                for (int h = 0; h < 2; h++)
+                {
+                    const uint32_t a = h2_bits(L[h]) & 0x7fff7fffu;
+                    short2v cv, av; __builtin_memcpy(&cv, &clampBits, 4); __builtin_memcpy(&av, &a, 4);
+                    const short2v d = cv - av;
+                    __builtin_memcpy(&Tb[h], &d, 4);
+                }
+                const uint32_t C = __builtin_amdgcn_perm(Tb[1], Tb[0], 0x07050301u);
+                const uint32_t x = (((S & ~C) >> 7) & 0x01010101u) | ((C >> 6) & 0x02020202u);   // code 2 replaces the sign bit
+                uint32_t y = x | (x >> 6);
+                y = y | (y >> 12);
+                mbytes[2 * q] = (uint8_t)y;
+            }
+            #pragma unroll
+            for (int h = 0; h < 2; h++)
+                zp[2 * q + h] = h2_bits(__builtin_elementwise_min(__builtin_elementwise_max(L[h], clampN), clampP));
+        }
+    }
+}
+
+struct TileCoord { int tileX, tileY, ch, nb; };
+
+template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH, int MODE, bool FASTLOAD>
 __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(FlreluArgs p, int totalTiles)
 {
     typedef MG<UP, DOWN, FU, FD, TW, TH> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float*     taps = reinterpret_cast<float*>(smem + G::OFF_TAPS);        // [0, FU): up taps, [FU, FU + FD): down taps (flipped)
+    uint32_t*  lut  = reinterpret_cast<uint32_t*>(smem + G::OFF_LUT);      // READ mode: mask nibble -> pair of gradient factors
     _Float16*  tab  = reinterpret_cast<_Float16*>(smem + G::OFF_TAB);      // fragment images, 512 halves each, lane-major
     _Float16*  XL   = reinterpret_cast<_Float16*>(smem + G::OFF_X);        // input tile + bias [X_ROWS][SX]
     _Float16*  WL   = reinterpret_cast<_Float16*>(smem + G::OFF_W);        // W [128 v][SW]
     uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][32 bytes]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = sgpr(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
 
     // ---- once per workgroup: taps, fragment images, zero the padding of the input tile -------------------
@@ -164,6 +254,15 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
         taps[FU + t] = v;
     }
     for (int i = tid; i < G::X_ROWS * G::SX / 2; i += kThreads) reinterpret_cast<uint32_t*>(XL)[i] = 0u;
+    if (MODE == LVG_SIGNS_READ && tid < 16)
+    {
+        // mask codes of two neighbouring pixels -> (factor of pixel 0, factor of pixel 1): 0 -> 1, 1 -> slope, 2 / 3 -> 0
+        half2v f;
+        const int c0 = tid & 3, c1 = tid >> 2;
+        f[0] = (_Float16)(c0 == 0 ? 1.0f : (c0 == 1 ? p.slope : 0.0f));
+        f[1] = (_Float16)(c1 == 0 ? 1.0f : (c1 == 1 ? p.slope : 0.0f));
+        lut[tid] = h2_bits(f);
+    }
     __syncthreads();
 
     // Launch-constant geometry: the column shift that aligns the tile with the mask bytes in READ mode and the
@@ -198,70 +297,77 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
             tab[e] = (_Float16)v;
         }
     }
-    // (the first barrier inside the tile loop publishes the table)
+    // (barrier 1 of the first tile publishes the table)
 
-    for (int tile = blockIdx.x; tile < totalTiles; tile += gridDim.x)
+    // ---- activation constants (packed f16) -----------------------------------------------------------------
+    const _Float16 slope_h = (_Float16)p.slope;
+    const half2v slope2 = {slope_h, slope_h};
+    const bool slopeMax = p.slope <= 1.0f;                                  // lrelu(x) = max(x, slope * x) (slope >= 0 is asserted by the caller)
+    const _Float16 clamp_h = (_Float16)(p.clamp < 65504.0f ? p.clamp : 65504.0f);    // no clamp = the largest finite f16
+    const half2v clampP = {clamp_h, clamp_h}, clampN = {-clamp_h, -clamp_h};
+    const uint32_t clampBits = h2_bits(clampP);
+
+    // ---- this workgroup's contiguous range of tiles; tile -> (tileX, tileY, channel, sample) ----------------
+    const int tileBeg = (int)((int64_t)totalTiles * blockIdx.x / gridDim.x);
+    const int tileEnd = (int)((int64_t)totalTiles * (blockIdx.x + 1) / gridDim.x);
+    TileCoord cur;
     {
-        int bid = tile;
-        const int tileX = bid % p.tilesX; bid /= p.tilesX;
-        const int tileY = bid % p.tilesY; bid /= p.tilesY;
-        const int ch = bid % p.c;
-        const int nb = bid / p.c;
-        const int64_t plane = (int64_t)nb * p.c + ch;
+        int bid = tileBeg;
+        cur.tileX = bid % p.tilesX; bid /= p.tilesX;
+        cur.tileY = bid % p.tilesY; bid /= p.tilesY;
+        cur.ch = bid % p.c; cur.nb = bid / p.c;
+        cur.tileX = sgpr(cur.tileX); cur.tileY = sgpr(cur.tileY); cur.ch = sgpr(cur.ch); cur.nb = sgpr(cur.nb);
+    }
 
-        const int outX0 = tileX * TW, outY0 = tileY * TH;
-        const int uStart = outX0 * DOWN - rOff, upY0 = outY0 * DOWN;        // up-sampled pixel (0, 0) of the tile
+    // ---- input loader: thread = (row r0 of RPP, column pair qp); pass i handles row r0 + RPP * i -------------
+    constexpr int PAIRS = G::IN_N / 2, RPP = kThreads / PAIRS, NPASS = mdiv_up(G::IN_N, RPP);
+    const int ld_r0 = tid / PAIRS, ld_qp = tid - ld_r0 * PAIRS;
+    const bool ld_active = tid < RPP * PAIRS;
+    const int ld_lds0 = ld_r0 * G::SX + 2 * ld_qp;                          // halves
+    const int64_t ld_thr = (int64_t)ld_r0 * p.xs[2] + (int64_t)(2 * ld_qp) * p.xs[3];   // elements, relative to the tile's first input pixel
+    uint32_t raw[NPASS];                                                    // prefetched pairs of the NEXT tile (storage bits)
+    uint32_t mraw[4];                                                       // READ mode: prefetched mask dwords of the next tile
+    float biasN = 0.0f;
+
+    auto issue_loads = [&](const TileCoord& tc)
+    {
+        const int uStart = tc.tileX * (TW * DOWN) - rOff, upY0 = tc.tileY * (TH * DOWN);
         const int inX0 = lvg_floor_div(uStart + UP - 1 - p.px0, UP);
         const int inY0 = lvg_floor_div(upY0 + UP - 1 - p.py0, UP);
-        const int signByte0 = (uStart + p.sOfsX) >> 2;                       // exact: a multiple of 4
-        const int signY0 = upY0 + p.sOfsY;
-        const int64_t signPlane = plane * (int64_t)p.sH * p.sWBytes;
-
-        // ---- input tile (+ bias on real pixels, zero outside the image) -> XL, two columns per thread ----
+        const T* xt = (const T*)p.x + (int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1] + (int64_t)inY0 * p.xs[2] + (int64_t)inX0 * p.xs[3];
+        const uint16_t bb = ((const uint16_t*)p.b)[tc.ch];
+        biasN = (float)to_acc(((const T*)p.b)[tc.ch]);
+        const uint32_t negb = (uint32_t)(bb ^ 0x8000u) * 0x10001u;            // (-bias, -bias): + bias = 0 outside the image
+        const int ix = inX0 + 2 * ld_qp;
+        const bool c0 = ld_active && ix >= 0 && ix < p.xw, c1 = ld_active && ix + 1 >= 0 && ix + 1 < p.xw;
+        const T* pt = xt + ld_thr;
+        #pragma unroll
+        for (int i = 0; i < NPASS; i++)
         {
-            const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0] + (int64_t)ch * p.xs[1];
-            const float bias = (float)to_acc(((const T*)p.b)[ch]);
-            constexpr int PAIRS = G::IN_N / 2;
-            constexpr int TOTAL = G::IN_N * PAIRS;
-            constexpr int PER = mdiv_up(TOTAL, kThreads);
-            float v0[PER], v1[PER];
-            #pragma unroll
-            for (int i = 0; i < PER; i++)
+            const int r = ld_r0 + RPP * i, iy = inY0 + r;
+            const bool rowOk = (RPP * (i + 1) <= G::IN_N || r < G::IN_N) && iy >= 0 && iy < p.xh;
+            const T* pr = pt + (int64_t)(RPP * i) * p.xs[2];
+            uint32_t v = negb;
+            if (FASTLOAD)
             {
-                const int idx = tid + i * kThreads;
-                const int r = idx / PAIRS, q = (idx - r * PAIRS) * 2;
-                const int iy = inY0 + r, ix = inX0 + q;
-                v0[i] = 0.0f; v1[i] = 0.0f;
-                if (idx < TOTAL && iy >= 0 && iy < p.xh)
-                {
-                    const T* row = xp + (int64_t)iy * p.xs[2];
-                    if (ix >= 0 && ix < p.xw)         v0[i] = load_in<T>(row + (int64_t)ix * p.xs[3]) + bias;
-                    if (ix + 1 >= 0 && ix + 1 < p.xw) v1[i] = load_in<T>(row + (int64_t)(ix + 1) * p.xs[3]) + bias;
-                }
+                if (rowOk && c0) v = *reinterpret_cast<const uint32_t*>(pr);    // pairs are dword aligned and never straddle the image edge
             }
-            #pragma unroll
-            for (int i = 0; i < PER; i++)
+            else
             {
-                const int idx = tid + i * kThreads;
-                const int r = idx / PAIRS, q = (idx - r * PAIRS) * 2;
-                if (idx < TOTAL)
-                {
-                    // bfloat16 inputs beyond the f16 range saturate instead of turning into inf (inf * 0 taps = NaN)
-                    half2v h;
-                    h[0] = (_Float16)__builtin_fminf(__builtin_fmaxf(v0[i], -65504.0f), 65504.0f);
-                    h[1] = (_Float16)__builtin_fminf(__builtin_fmaxf(v1[i], -65504.0f), 65504.0f);
-                    *reinterpret_cast<half2v*>(XL + r * G::SX + q) = h;
-                }
+                uint32_t lo = negb & 0xffffu, hi = negb >> 16;
+                if (rowOk && c0) lo = *reinterpret_cast<const uint16_t*>(pr);
+                if (rowOk && c1) hi = *reinterpret_cast<const uint16_t*>(pr + p.xs[3]);
+                v = lo | (hi << 16);
             }
+            raw[i] = v;
         }
-        // ---- READ mode: mask tile -> ML (zero = "positive, not clamped" outside the stored plane) --------
         if (MODE == LVG_SIGNS_READ)
         {
             const int row = tid >> 1, half = tid & 1;
-            const int sy = signY0 + row;
+            const int signByte0 = (uStart + p.sOfsX) >> 2;
+            const int sy = upY0 + p.sOfsY + row;
             const bool rowOk = sy >= 0 && sy < p.sH;
-            const uint8_t* srow = p.s + signPlane + (int64_t)sy * p.sWBytes;
-            uint32_t wds[4];
+            const uint8_t* srow = p.s + ((int64_t)tc.nb * p.c + tc.ch) * (int64_t)p.sH * p.sWBytes + (int64_t)sy * p.sWBytes;
             #pragma unroll
             for (int d = 0; d < 4; d++)
             {
@@ -277,13 +383,51 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
                             if (bx0 + k >= 0 && bx0 + k < p.swLimit) v |= (uint32_t)srow[bx0 + k] << (8 * k);
                     }
                 }
-                wds[d] = v;
+                mraw[d] = v;
             }
-            *reinterpret_cast<uint4*>(ML + row * 32 + 16 * half) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
+    };
+    auto write_tile = [&]()
+    {
+        const _Float16 bh = (_Float16)biasN;
+        const half2v bias2 = {bh, bh};
+        #pragma unroll
+        for (int i = 0; i < NPASS; i++)
+        {
+            const bool ok = ld_active && (RPP * (i + 1) <= G::IN_N || ld_r0 + RPP * i < G::IN_N);
+            if (ok) *reinterpret_cast<half2v*>(XL + ld_lds0 + RPP * i * G::SX) = pair_plus_bias<T>(raw[i], bias2, biasN);
+        }
+        if (MODE == LVG_SIGNS_READ)
+            *reinterpret_cast<uint4*>(ML + (tid >> 1) * 32 + 16 * (tid & 1)) = make_uint4(mraw[0], mraw[1], mraw[2], mraw[3]);
+    };
+
+    if (tileBeg < tileEnd) { issue_loads(cur); write_tile(); }
+
+    LVG_MARK("loop");
+    for (int tile = tileBeg; tile < tileEnd; tile++)
+    {
+        const int tileX = cur.tileX, tileY = cur.tileY, ch = cur.ch, nb = cur.nb;
+        const int64_t plane = (int64_t)nb * p.c + ch;
+        const int outX0 = tileX * TW, outY0 = tileY * TH;
+        const int uStart = outX0 * DOWN - rOff, upY0 = outY0 * DOWN;        // up-sampled pixel (0, 0) of the tile
+        const int signByte0 = (uStart + p.sOfsX) >> 2;                       // exact: a multiple of 4
+        const int signY0 = upY0 + p.sOfsY;
+        const int64_t signPlane = plane * (int64_t)p.sH * p.sWBytes;
+
+        LVG_MARK("barrier1");
         __syncthreads();                                                    // barrier 1: XL (ML, table) visible; previous tile's stage D done
 
+        // ---- prefetch the next tile's input (and mask) into registers; it lands while this tile computes ----
+        LVG_MARK("prefetch");
+        TileCoord nxt = cur;
+        if (tile + 1 < tileEnd)
+        {
+            if (++nxt.tileX == p.tilesX) { nxt.tileX = 0; if (++nxt.tileY == p.tilesY) { nxt.tileY = 0; if (++nxt.ch == p.c) { nxt.ch = 0; ++nxt.nb; } } }
+            issue_loads(nxt);
+        }
+
         // ---- stage A: T'[ic][v] for this wave's 32 rows v ------------------------------------------------
+        LVG_MARK("stageA");
         half8 tpk[G::IN_BLK][2];
         {
             f32x16 accA[G::IN_BLK];
@@ -311,13 +455,13 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
         }
 
         // ---- stages B, activation, C, interleaved over the four 32-column blocks of u ---------------------
+        LVG_MARK("stageBC");
         f32x16 accW[G::OBX];
         #pragma unroll
         for (int bo = 0; bo < G::OBX; bo++)
             #pragma unroll
             for (int r = 0; r < 16; r++) accW[bo][r] = 0.0f;
-        const float slope = p.slope, clampv = p.clamp;
-        uint8_t* mrow = ML + (32 * w + n) * 32;
+        uint8_t* mrow = ML + (32 * w + n) * 32 + g;
         #pragma unroll
         for (int b = 0; b < 4; b++)
         {
@@ -334,38 +478,15 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
                     accU = mfma(fx, tpk[c >> 1][c & 1], accU);
                 }
             }
-            // activation: register r holds u = 32 b + (r & 3) + 8 (r >> 2) + 4 g of row v = 32 w + n;
-            // registers 4q .. 4q + 3 are the four pixels of mask byte 8 b + 2 q + g.
-            #pragma unroll
-            for (int q = 0; q < 4; q++)
-            {
-                uint32_t bits = 0;
-                if (MODE == LVG_SIGNS_READ) bits = mrow[8 * b + 2 * q + g];
-                #pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    float a = accU[4 * q + e];
-                    if (MODE == LVG_SIGNS_READ)
-                    {
-                        const uint32_t sb = bits >> (2 * e);
-                        if (sb & 1) a *= slope;
-                        if (sb & 2) a = 0.0f;
-                    }
-                    else
-                    {
-                        uint32_t sb = __float_as_uint(a) >> 31;                  // IEEE sign bit (-0.0 counts)
-                        if (sb) a *= slope;
-                        if (fabsf(a) > clampv) { sb = 2; a = (a < 0.0f) ? -clampv : clampv; }
-                        bits |= sb << (2 * e);
-                    }
-                    accU[4 * q + e] = a;
-                }
-                if (MODE == LVG_SIGNS_WRITE) mrow[8 * b + 2 * q + g] = (uint8_t)bits;
-            }
+            // Activation in packed f16 (act_block): registers 4q .. 4q + 3 are the four pixels of mask byte 8 b + 2 q + g.
+            uint32_t zp[8];
+            if (slopeMax) act_block<MODE, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
+            else          act_block<MODE, false>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
             #pragma unroll
             for (int h = 0; h < 2; h++)
             {
-                const half8 z = pack_chunk(accU, h);
+                half8 z;
+                __builtin_memcpy(&z, &zp[4 * h], 16);
                 const int c = 2 * b + h;
                 #pragma unroll
                 for (int bo = 0; bo < G::OBX; bo++)
@@ -377,6 +498,7 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
             }
         }
         // W[ox][v] -> WL[v][ox]: registers 4q .. 4q + 3 are four consecutive ox
+        LVG_MARK("wwrite");
         #pragma unroll
         for (int bo = 0; bo < G::OBX; bo++)
             #pragma unroll
@@ -387,9 +509,11 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
                 for (int e = 0; e < 4; e++) h[e] = (_Float16)accW[bo][4 * q + e];
                 *reinterpret_cast<half4*>(WL + (32 * w + n) * G::SW + 32 * bo + 8 * q + 4 * g) = h;
             }
-        __syncthreads();                                                    // barrier 2: WL (and ML in WRITE mode) complete
+        LVG_MARK("barrier2");
+        __syncthreads();                                                    // barrier 2: WL (and ML in WRITE mode) complete; XL / ML free
 
         // ---- WRITE mode: mask tile -> global, only the part this tile owns --------------------------------
+        LVG_MARK("maskout");
         if (MODE == LVG_SIGNS_WRITE)
         {
             const int ownBytes = (tileX == p.tilesX - 1) ? 32 : (TW * DOWN) / 4;
@@ -427,7 +551,12 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
             }
         }
 
+        // ---- the prefetched next tile -> XL (ML); stage A of this tile is behind barrier 2 -----------------
+        LVG_MARK("xwrite");
+        if (tile + 1 < tileEnd) write_tile();
+
         // ---- stage D: one 32 x 32 output block per wave ---------------------------------------------------
+        LVG_MARK("stageD");
         if (w < G::OBX * G::OBY)
         {
             const int by = w / G::OBX, bx = w - by * G::OBX;
@@ -445,18 +574,23 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
                     accY = mfma(fd, wt, accY);
                 }
             }
-            T* yp = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1];
-            const int oxl = 32 * bx + n, ox = outX0 + oxl;
-            if (oxl < TW && ox < p.yw)
+            // lanes = 32 consecutive ox of one row: each store instruction writes two 64-byte row segments
+            const int oxl = 32 * bx + n;
+            const int colLimit = min(TW, p.yw - outX0);                      // columns / rows of this tile that exist
+            const int rowLimit = min(TH, p.yh - outY0) - 32 * by - 4 * g;
+            if (oxl < colLimit)
             {
+                T* yt = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1] + (int64_t)(outY0 + 32 * by) * p.ys[2] + (int64_t)outX0 * p.ys[3];
+                T* yl = yt + (int64_t)(4 * g) * p.ys[2] + (int64_t)oxl * p.ys[3];
                 #pragma unroll
                 for (int r = 0; r < 16; r++)
                 {
-                    const int oyl = 32 * by + (r & 3) + 8 * (r >> 2) + 4 * g, oy = outY0 + oyl;
-                    if (oyl < TH && oy < p.yh) yp[(int64_t)oy * p.ys[2] + (int64_t)ox * p.ys[3]] = from_acc<T>(accY[r]);
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (rr < rowLimit) yl[(int64_t)rr * p.ys[2]] = from_acc<T>(accY[r]);
                 }
             }
         }
+        cur = nxt;
     }
 }
 
@@ -480,9 +614,17 @@ int launch_mfma(FlreluArgs& p, int mode, hipStream_t stream)
     const int64_t maxGrid = (int64_t)ncu * 3;
     const unsigned grid = (unsigned)(tiles < maxGrid ? tiles : maxGrid);
     const size_t lds = G::LDS_BYTES;
-    if (mode == LVG_SIGNS_WRITE)     hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_WRITE>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles);
-    else if (mode == LVG_SIGNS_READ) hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_READ>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles);
-    else                             hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_NONE>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles);
+    // Pairs of input columns are fetched as one dword when every pair is dword aligned and never straddles the
+    // image edge: unit x stride, even row / plane strides and width, even first input column of every tile.
+    const int rOff = (mode == LVG_SIGNS_READ) ? (p.sOfsX & 3) : 0;
+    const int inX00 = lvg_floor_div(UP - 1 - p.px0 - rOff, UP);
+    const bool fast = p.xs[3] == 1 && (p.xs[2] & 1) == 0 && (p.xs[1] & 1) == 0 && (p.xs[0] & 1) == 0 && (p.xw & 1) == 0 &&
+                      (inX00 & 1) == 0 && ((TW * DOWN / UP) & 1) == 0 && (((uintptr_t)p.x) & 3u) == 0;
+    #define LVG_MFMA_LAUNCH(M, F) hipLaunchKernelGGL((filtered_lrelu_mfma_kernel<T, UP, DOWN, FU, FD, TW, TH, M, F>), dim3(grid), dim3(kThreads), lds, stream, p, (int)tiles)
+    if (mode == LVG_SIGNS_WRITE)     { if (fast) LVG_MFMA_LAUNCH(LVG_SIGNS_WRITE, true); else LVG_MFMA_LAUNCH(LVG_SIGNS_WRITE, false); }
+    else if (mode == LVG_SIGNS_READ) { if (fast) LVG_MFMA_LAUNCH(LVG_SIGNS_READ, true);  else LVG_MFMA_LAUNCH(LVG_SIGNS_READ, false); }
+    else                             { if (fast) LVG_MFMA_LAUNCH(LVG_SIGNS_NONE, true);  else LVG_MFMA_LAUNCH(LVG_SIGNS_NONE, false); }
+    #undef LVG_MFMA_LAUNCH
     return lvg_check_launch("filtered_lrelu_mfma_kernel");
 }
 

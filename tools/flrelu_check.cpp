@@ -182,6 +182,8 @@ static int run_check(const Case& cs, int dtype)
     return fails;
 }
 
+static int g_only_impl = 0, g_reps = 10;
+
 static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 0 = fwd no signs, 2 = backward-shaped read*/)
 {
     const float gain = sqrtf(2.0f), slope = 0.2f, clamp = 256.0f;
@@ -209,6 +211,7 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
     const double gg = (double)gain * up * up / (down * down);
     for (int impl = 2; impl >= 1; impl--)
     {
+        if (g_only_impl && impl != g_only_impl) continue;
         auto once = [&]() {
             if (mode == 2)
                 return call(impl, dtype, ddy.p, ddx.p, dzb.p, (uint8_t*)ds.p, (float*)dfd.p, (float*)dfu.p, n, c, yh, yw, xh, xw, nd, nu, down, up, pp0, pq0,
@@ -221,7 +224,7 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
         if (once()) return;
         HIPCHK(hipDeviceSynchronize());
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-        const int reps = 10;
+        const int reps = g_reps;
         float best = 1e30f;
         for (int t = 0; t < 3; t++)
         {
@@ -275,6 +278,18 @@ int main(int argc, char** argv)
         for (const Case& cs : big)
             for (int mode = 0; mode <= 2; mode++) run_time(cs, 1, mode);
         run_time(big[0], 2, 1);
+    }
+    if (what == "one")      // one <L8|L10|L13> <dtype 1|2> <mode 0|1|2> <impl 1|2> [reps]: for rocprofv3
+    {
+        const Case big[] = {
+            {"L8", 8, 512, 94, 150, 2, 2, 12, 12, 9, 8, 9, 8},
+            {"L10", 8, 256, 94, 150, 4, 2, 24, 12, -6, -9, -6, -9},
+            {"L13", 8, 128, 166, 278, 2, 2, 12, 12, -11, -12, -11, -12},
+        };
+        g_only_impl = atoi(argv[5]);
+        g_reps = argc > 6 ? atoi(argv[6]) : 2;
+        for (const Case& cs : big)
+            if (std::string(cs.name) == argv[2]) run_time(cs, atoi(argv[3]), atoi(argv[4]));
     }
     return fails ? 1 : 0;
 }
