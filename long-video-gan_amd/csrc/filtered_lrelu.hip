@@ -702,7 +702,10 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     const int impl = g_flrelu_impl.load(std::memory_order_relaxed);
     const bool use_mfma = impl == 0 ? env_mfma : impl == 2;
     if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
-        return lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);
+    {
+        const int rc = lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);
+        if (rc != LVG_ERR_UNSUPPORTED) return rc;      // (planes of 2 GiB and more: the VALU kernel below)
+    }
     switch (dtype)
     {
         case LVG_F32:  return run_fused<float>(p, cfg, sign_mode, st);

@@ -41,6 +41,14 @@
 #define LVG_MARK(name)
 #endif
 
+// Tuning switches (A/B measured with tools/flrelu_check):
+#ifndef LVG_MFMA_PIPELINE
+#define LVG_MFMA_PIPELINE 1      // issue stage B of block b + 1 before the activation of block b
+#endif
+#ifndef LVG_MFMA_WAVES
+#define LVG_MFMA_WAVES 3         // __launch_bounds__ waves per SIMD (3 workgroups per CU fit the LDS)
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -77,7 +85,8 @@ struct MG
     // LDS map (bytes)
     static constexpr int OFF_TAPS = 0;
     static constexpr int OFF_LUT  = TAPS * 4;                               // 16 dwords (READ mode)
-    static constexpr int OFF_TAB  = OFF_LUT + 64;
+    static constexpr int OFF_BIAS = OFF_LUT + 64;                           // bias bits of the first 64 planes of this workgroup's range
+    static constexpr int OFF_TAB  = OFF_BIAS + 256;
     static constexpr int OFF_X    = OFF_TAB + NIMG * 1024;
     static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2;
     static constexpr int OFF_M    = OFF_W + kUpT * SW * 2;
@@ -223,21 +232,37 @@ __device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8],
     }
 }
 
-struct TileCoord { int tileX, tileY, ch, nb; };
+struct TileCoord { int tileX, tileY, ch, nb, plane; };   // plane = nb * channels + ch
 
 template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH, int MODE, bool FASTLOAD>
-__global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(FlreluArgs p, int totalTiles)
+__global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_kernel(FlreluArgs p, int totalTiles)
 {
     typedef MG<UP, DOWN, FU, FD, TW, TH> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float*     taps = reinterpret_cast<float*>(smem + G::OFF_TAPS);        // [0, FU): up taps, [FU, FU + FD): down taps (flipped)
     uint32_t*  lut  = reinterpret_cast<uint32_t*>(smem + G::OFF_LUT);      // READ mode: mask nibble -> pair of gradient factors
+    uint32_t*  biasL = reinterpret_cast<uint32_t*>(smem + G::OFF_BIAS);    // storage bits of b[channel] for the planes this workgroup visits
     _Float16*  tab  = reinterpret_cast<_Float16*>(smem + G::OFF_TAB);      // fragment images, 512 halves each, lane-major
     _Float16*  XL   = reinterpret_cast<_Float16*>(smem + G::OFF_X);        // input tile + bias [X_ROWS][SX]
     _Float16*  WL   = reinterpret_cast<_Float16*>(smem + G::OFF_W);        // W [128 v][SW]
     uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][32 bytes]
     const int tid = threadIdx.x, lane = tid & 63, w = sgpr(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
+
+    // ---- this workgroup's contiguous range of tiles; tile -> (tileX, tileY, channel, sample) ----------------
+    const int tileBeg = (int)((int64_t)totalTiles * blockIdx.x / gridDim.x);
+    const int tileEnd = (int)((int64_t)totalTiles * (blockIdx.x + 1) / gridDim.x);
+    TileCoord cur;
+    {
+        int bid = tileBeg;
+        cur.tileX = bid % p.tilesX; bid /= p.tilesX;
+        cur.tileY = bid % p.tilesY; bid /= p.tilesY;
+        cur.plane = bid;
+        cur.ch = bid % p.c; cur.nb = bid / p.c;
+        cur.tileX = sgpr(cur.tileX); cur.tileY = sgpr(cur.tileY); cur.ch = sgpr(cur.ch); cur.nb = sgpr(cur.nb); cur.plane = sgpr(cur.plane);
+    }
+    const int planeBeg = cur.plane;
+    if (tid < 64) biasL[tid] = ((const uint16_t*)p.b)[(planeBeg + tid) % p.c];
 
     // ---- once per workgroup: taps, fragment images, zero the padding of the input tile -------------------
     if (tid < FU)
@@ -307,59 +332,77 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
     const half2v clampP = {clamp_h, clamp_h}, clampN = {-clamp_h, -clamp_h};
     const uint32_t clampBits = h2_bits(clampP);
 
-    // ---- this workgroup's contiguous range of tiles; tile -> (tileX, tileY, channel, sample) ----------------
-    const int tileBeg = (int)((int64_t)totalTiles * blockIdx.x / gridDim.x);
-    const int tileEnd = (int)((int64_t)totalTiles * (blockIdx.x + 1) / gridDim.x);
-    TileCoord cur;
-    {
-        int bid = tileBeg;
-        cur.tileX = bid % p.tilesX; bid /= p.tilesX;
-        cur.tileY = bid % p.tilesY; bid /= p.tilesY;
-        cur.ch = bid % p.c; cur.nb = bid / p.c;
-        cur.tileX = sgpr(cur.tileX); cur.tileY = sgpr(cur.tileY); cur.ch = sgpr(cur.ch); cur.nb = sgpr(cur.nb);
-    }
-
-    // ---- input loader: thread = (row r0 of RPP, column pair qp); pass i handles row r0 + RPP * i -------------
+    // All per-lane address arithmetic is done ONCE here as 32-bit byte offsets from a per-tile scalar base pointer
+    // (the launcher checks that a plane spans < 2^31 bytes), so a load / store in the tile loop is
+    // "scalar base + lane offset" with no 64-bit vector math.
+    // Input loader: thread = (row r0 of RPP, column pair qp); pass i handles row r0 + RPP * i.
     constexpr int PAIRS = G::IN_N / 2, RPP = kThreads / PAIRS, NPASS = mdiv_up(G::IN_N, RPP);
     const int ld_r0 = tid / PAIRS, ld_qp = tid - ld_r0 * PAIRS;
     const bool ld_active = tid < RPP * PAIRS;
     const int ld_lds0 = ld_r0 * G::SX + 2 * ld_qp;                          // halves
-    const int64_t ld_thr = (int64_t)ld_r0 * p.xs[2] + (int64_t)(2 * ld_qp) * p.xs[3];   // elements, relative to the tile's first input pixel
+    const uint32_t ld_off0 = (uint32_t)(ld_r0 * (int)p.xs[2] + 2 * ld_qp * (int)p.xs[3]) * 2u;   // bytes from the tile's first input pixel
+    const uint32_t ld_pass = (uint32_t)(RPP * (int)p.xs[2]) * 2u;
+    const uint32_t ld_x1 = (uint32_t)((int)p.xs[3]) * 2u;
     uint32_t raw[NPASS];                                                    // prefetched pairs of the NEXT tile (storage bits)
     uint32_t mraw[4];                                                       // READ mode: prefetched mask dwords of the next tile
     float biasN = 0.0f;
+    // Stage D: this wave's output block and this lane's column.
+    const int dBy = w / G::OBX, dBx = w - dBy * G::OBX;
+    const int dOxl = 32 * dBx + n;
+    const uint32_t st_off0 = (uint32_t)(4 * g * (int)p.ys[2] + dOxl * (int)p.ys[3]) * 2u;
+    const uint32_t st_row = (uint32_t)((int)p.ys[2]) * 2u;
 
     auto issue_loads = [&](const TileCoord& tc)
     {
         const int uStart = tc.tileX * (TW * DOWN) - rOff, upY0 = tc.tileY * (TH * DOWN);
         const int inX0 = lvg_floor_div(uStart + UP - 1 - p.px0, UP);
         const int inY0 = lvg_floor_div(upY0 + UP - 1 - p.py0, UP);
-        const T* xt = (const T*)p.x + (int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1] + (int64_t)inY0 * p.xs[2] + (int64_t)inX0 * p.xs[3];
-        const uint16_t bb = ((const uint16_t*)p.b)[tc.ch];
-        biasN = (float)to_acc(((const T*)p.b)[tc.ch]);
-        const uint32_t negb = (uint32_t)(bb ^ 0x8000u) * 0x10001u;            // (-bias, -bias): + bias = 0 outside the image
-        const int ix = inX0 + 2 * ld_qp;
-        const bool c0 = ld_active && ix >= 0 && ix < p.xw, c1 = ld_active && ix + 1 >= 0 && ix + 1 < p.xw;
-        const T* pt = xt + ld_thr;
+        // plane base (64-bit) + first input pixel of the tile (32-bit element offset, may be negative)
+        // "scalar plane base + 32-bit lane offset" addressing: the tile term keeps the sum inside this block, so the
+        // compiler cannot hoist ten 64-bit lane addresses out of the tile loop (it did: +20 VGPRs and spills)
+        const char* xpl = (const char*)((const T*)p.x + ((int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1]));
+        const uint32_t xoff = (uint32_t)(inY0 * (int)p.xs[2] + inX0 * (int)p.xs[3]) * 2u + ld_off0;    // valid lanes: >= 0
+        const int bi = tc.plane - planeBeg;
+        const uint32_t bb = bi < 64 ? biasL[bi] : (uint32_t)((const uint16_t*)p.b)[tc.ch];
+        { T bt; const uint16_t b16 = (uint16_t)bb; __builtin_memcpy(&bt, &b16, 2); biasN = (float)to_acc(bt); }
+        const uint32_t negb = (bb ^ 0x8000u) * 0x10001u;                      // (-bias, -bias): + bias = 0 outside the image
         #pragma unroll
-        for (int i = 0; i < NPASS; i++)
+        for (int i = 0; i < NPASS; i++) raw[i] = negb;
+        // rows r in [rLo, rLo + span) and columns with 0 <= ix < xw exist
+        const int rLo = max(0, -inY0), span = max(0, min(G::IN_N, p.xh - inY0) - rLo);
+        const int d0 = ld_r0 - rLo;
+        const int ix = inX0 + 2 * ld_qp;
+        const bool c0 = ld_active && (uint32_t)ix < (uint32_t)p.xw, c1 = ld_active && (uint32_t)(ix + 1) < (uint32_t)p.xw;
+        if (FASTLOAD)
         {
-            const int r = ld_r0 + RPP * i, iy = inY0 + r;
-            const bool rowOk = (RPP * (i + 1) <= G::IN_N || r < G::IN_N) && iy >= 0 && iy < p.xh;
-            const T* pr = pt + (int64_t)(RPP * i) * p.xs[2];
-            uint32_t v = negb;
-            if (FASTLOAD)
+            if (c0)                                                           // pairs are dword aligned and never straddle the image edge
             {
-                if (rowOk && c0) v = *reinterpret_cast<const uint32_t*>(pr);    // pairs are dword aligned and never straddle the image edge
+                #pragma unroll
+                for (int i = 0; i < NPASS; i++)
+                {
+                    // pass i covers rows RPP * i .. RPP * i + RPP - 1: all present, none, or mixed (image top / bottom)
+                    const int lo = RPP * i - rLo;                             // uniform
+                    const char* pr = xpl + (xoff + (uint32_t)i * ld_pass);
+                    if (lo >= 0 && lo + RPP <= span) raw[i] = *reinterpret_cast<const uint32_t*>(pr);
+                    else if (lo + RPP > 0 && lo < span)
+                    {
+                        if ((uint32_t)(d0 + RPP * i) < (uint32_t)span) raw[i] = *reinterpret_cast<const uint32_t*>(pr);
+                    }
+                }
             }
-            else
+        }
+        else
+        {
+            #pragma unroll
+            for (int i = 0; i < NPASS; i++)
             {
+                const bool rowOk = (uint32_t)(d0 + RPP * i) < (uint32_t)span;
+                const uint32_t o0 = xoff + (uint32_t)i * ld_pass, o1 = o0 + ld_x1;    // (the sums must wrap in 32 bits: the tile term may be negative)
                 uint32_t lo = negb & 0xffffu, hi = negb >> 16;
-                if (rowOk && c0) lo = *reinterpret_cast<const uint16_t*>(pr);
-                if (rowOk && c1) hi = *reinterpret_cast<const uint16_t*>(pr + p.xs[3]);
-                v = lo | (hi << 16);
+                if (rowOk && c0) lo = *reinterpret_cast<const uint16_t*>(xpl + o0);
+                if (rowOk && c1) hi = *reinterpret_cast<const uint16_t*>(xpl + o1);
+                raw[i] = lo | (hi << 16);
             }
-            raw[i] = v;
         }
         if (MODE == LVG_SIGNS_READ)
         {
@@ -367,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
             const int signByte0 = (uStart + p.sOfsX) >> 2;
             const int sy = upY0 + p.sOfsY + row;
             const bool rowOk = sy >= 0 && sy < p.sH;
-            const uint8_t* srow = p.s + ((int64_t)tc.nb * p.c + tc.ch) * (int64_t)p.sH * p.sWBytes + (int64_t)sy * p.sWBytes;
+            const uint8_t* srow = p.s + (int64_t)tc.plane * ((int64_t)p.sH * p.sWBytes) + (int64_t)(sy * p.sWBytes);
             #pragma unroll
             for (int d = 0; d < 4; d++)
             {
@@ -400,6 +443,24 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
         if (MODE == LVG_SIGNS_READ)
             *reinterpret_cast<uint4*>(ML + (tid >> 1) * 32 + 16 * (tid & 1)) = make_uint4(mraw[0], mraw[1], mraw[2], mraw[3]);
     };
+    // One 32 x 32 block of U^T = A_x * T' (stage B) for column block b of the up-sampled tile.
+    auto stage_b = [&](int b, const half8 (&tpk)[G::IN_BLK][2]) -> f32x16
+    {
+        f32x16 acc;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        #pragma unroll
+        for (int t = 0; t < 2; t++)
+        {
+            if (t < UpChunks<UP>::count(b))
+            {
+                const int c = UpChunks<UP>::first(b) + t;
+                const half8 fx = lds_frag(tab, G::IMG_FX + UpChunks<UP>::cls0(b) + t * UpChunks<UP>::step(), lane);
+                acc = mfma(fx, tpk[c >> 1][c & 1], acc);
+            }
+        }
+        return acc;
+    };
 
     if (tileBeg < tileEnd) { issue_loads(cur); write_tile(); }
 
@@ -407,12 +468,7 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
     for (int tile = tileBeg; tile < tileEnd; tile++)
     {
         const int tileX = cur.tileX, tileY = cur.tileY, ch = cur.ch, nb = cur.nb;
-        const int64_t plane = (int64_t)nb * p.c + ch;
         const int outX0 = tileX * TW, outY0 = tileY * TH;
-        const int uStart = outX0 * DOWN - rOff, upY0 = outY0 * DOWN;        // up-sampled pixel (0, 0) of the tile
-        const int signByte0 = (uStart + p.sOfsX) >> 2;                       // exact: a multiple of 4
-        const int signY0 = upY0 + p.sOfsY;
-        const int64_t signPlane = plane * (int64_t)p.sH * p.sWBytes;
 
         LVG_MARK("barrier1");
         __syncthreads();                                                    // barrier 1: XL (ML, table) visible; previous tile's stage D done
@@ -422,7 +478,7 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
         TileCoord nxt = cur;
         if (tile + 1 < tileEnd)
         {
-            if (++nxt.tileX == p.tilesX) { nxt.tileX = 0; if (++nxt.tileY == p.tilesY) { nxt.tileY = 0; if (++nxt.ch == p.c) { nxt.ch = 0; ++nxt.nb; } } }
+            if (++nxt.tileX == p.tilesX) { nxt.tileX = 0; if (++nxt.tileY == p.tilesY) { nxt.tileY = 0; ++nxt.plane; if (++nxt.ch == p.c) { nxt.ch = 0; ++nxt.nb; } } }
             issue_loads(nxt);
         }
 
@@ -454,7 +510,8 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
             for (int m = 0; m < G::IN_BLK; m++) { tpk[m][0] = pack_chunk(accA[m], 0); tpk[m][1] = pack_chunk(accA[m], 1); }
         }
 
-        // ---- stages B, activation, C, interleaved over the four 32-column blocks of u ---------------------
+        // ---- stages B, activation, C over the four 32-column blocks of u, software-pipelined: the MFMAs of block
+        //      b + 1 are issued before the (vector-pipe) activation of block b, stage C of block b after it --------
         LVG_MARK("stageBC");
         f32x16 accW[G::OBX];
         #pragma unroll
@@ -462,22 +519,12 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
             #pragma unroll
             for (int r = 0; r < 16; r++) accW[bo][r] = 0.0f;
         uint8_t* mrow = ML + (32 * w + n) * 32 + g;
+        f32x16 accU = stage_b(0, tpk);
         #pragma unroll
         for (int b = 0; b < 4; b++)
         {
-            f32x16 accU;
-            #pragma unroll
-            for (int r = 0; r < 16; r++) accU[r] = 0.0f;
-            #pragma unroll
-            for (int t = 0; t < 2; t++)
-            {
-                if (t < UpChunks<UP>::count(b))
-                {
-                    const int c = UpChunks<UP>::first(b) + t;
-                    const half8 fx = lds_frag(tab, G::IMG_FX + UpChunks<UP>::cls0(b) + t * UpChunks<UP>::step(), lane);
-                    accU = mfma(fx, tpk[c >> 1][c & 1], accU);
-                }
-            }
+            f32x16 accUn;
+            if (LVG_MFMA_PIPELINE && b < 3) accUn = stage_b(b + 1, tpk);
             // Activation in packed f16 (act_block): registers 4q .. 4q + 3 are the four pixels of mask byte 8 b + 2 q + g.
             uint32_t zp[8];
             if (slopeMax) act_block<MODE, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
@@ -496,6 +543,7 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
                         accW[bo] = mfma(lds_frag(tab, G::IMG_DX + cls, lane), z, accW[bo]);
                 }
             }
+            if (b < 3) accU = LVG_MFMA_PIPELINE ? accUn : stage_b(b + 1, tpk);
         }
         // W[ox][v] -> WL[v][ox]: registers 4q .. 4q + 3 are four consecutive ox
         LVG_MARK("wwrite");
@@ -516,25 +564,28 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
         LVG_MARK("maskout");
         if (MODE == LVG_SIGNS_WRITE)
         {
+            const int uStart = outX0 * DOWN, upY0 = outY0 * DOWN;            // (sign offsets are 0 when writing)
+            const int signByte0 = uStart >> 2;
             const int ownBytes = (tileX == p.tilesX - 1) ? 32 : (TW * DOWN) / 4;
             const int ownRows  = (tileY == p.tilesY - 1) ? kUpT : TH * DOWN;
             const int row = tid >> 1, half = tid & 1;
-            const int sy = signY0 + row;
-            if (row < ownRows && sy >= 0 && sy < p.sH)
+            const int sy = upY0 + row;
+            uint8_t* splane = p.s + (int64_t)cur.plane * ((int64_t)p.sH * p.sWBytes);
+            if (row < ownRows && sy < p.sH)
             {
-                uint8_t* srow = p.s + signPlane + (int64_t)sy * p.sWBytes;
+                uint8_t* srow = splane + (uint32_t)(sy * p.sWBytes);
                 const uint4 v = *reinterpret_cast<const uint4*>(ML + row * 32 + 16 * half);
                 const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
                 #pragma unroll
                 for (int d = 0; d < 4; d++)
                 {
                     const int k0 = 16 * half + 4 * d, bx0 = signByte0 + k0;
-                    if (k0 + 4 <= ownBytes && bx0 >= 0 && bx0 + 4 <= p.swLimit) *reinterpret_cast<uint32_t*>(srow + bx0) = wds[d];
+                    if (k0 + 4 <= ownBytes && bx0 + 4 <= p.swLimit) *reinterpret_cast<uint32_t*>(srow + bx0) = wds[d];
                     else
                     {
                         #pragma unroll
                         for (int k = 0; k < 4; k++)
-                            if (k0 + k < ownBytes && bx0 + k >= 0 && bx0 + k < p.swLimit) srow[bx0 + k] = (uint8_t)(wds[d] >> (8 * k));
+                            if (k0 + k < ownBytes && bx0 + k < p.swLimit) srow[bx0 + k] = (uint8_t)(wds[d] >> (8 * k));
                     }
                 }
             }
@@ -545,8 +596,8 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
                 for (int idx = tid; idx < ownRows * padBytes; idx += kThreads)
                 {
                     const int v = idx / padBytes, k = idx - v * padBytes;
-                    const int sy2 = signY0 + v;
-                    if (sy2 >= 0 && sy2 < p.sH) p.s[signPlane + (int64_t)sy2 * p.sWBytes + p.swLimit + k] = 0;
+                    const int sy2 = upY0 + v;
+                    if (sy2 < p.sH) splane[(uint32_t)(sy2 * p.sWBytes + p.swLimit + k)] = 0;
                 }
             }
         }
@@ -559,34 +610,40 @@ __global__ __launch_bounds__(kThreads, 3) void filtered_lrelu_mfma_kernel(Flrelu
         LVG_MARK("stageD");
         if (w < G::OBX * G::OBY)
         {
-            const int by = w / G::OBX, bx = w - by * G::OBX;
             f32x16 accY;
             #pragma unroll
             for (int r = 0; r < 16; r++) accY[r] = 0.0f;
             #pragma unroll
             for (int cls = 0; cls < G::NDC; cls++)
             {
-                const int c = 2 * by * DOWN + cls;
+                const int c = 2 * dBy * DOWN + cls;
                 if (c < 8)
                 {
                     const half8 fd = lds_frag(tab, G::IMG_DY + cls, lane);
-                    const half8 wt = lds_tr_operand(WL, G::SW, 16 * c, 32 * bx, lane);
+                    const half8 wt = lds_tr_operand(WL, G::SW, 16 * c, 32 * dBx, lane);
                     accY = mfma(fd, wt, accY);
                 }
             }
             // lanes = 32 consecutive ox of one row: each store instruction writes two 64-byte row segments
-            const int oxl = 32 * bx + n;
             const int colLimit = min(TW, p.yw - outX0);                      // columns / rows of this tile that exist
-            const int rowLimit = min(TH, p.yh - outY0) - 32 * by - 4 * g;
-            if (oxl < colLimit)
+            const int rowsHere = min(TH, p.yh - outY0) - 32 * dBy;           // rows of this wave's block that exist (uniform)
+            char* ypl = (char*)((T*)p.y + ((int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1]));
+            const uint32_t yoff = (uint32_t)((outY0 + 32 * dBy) * (int)p.ys[2] + outX0 * (int)p.ys[3]) * 2u + st_off0;
+            if (dOxl < colLimit)
             {
-                T* yt = (T*)p.y + (int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1] + (int64_t)(outY0 + 32 * by) * p.ys[2] + (int64_t)outX0 * p.ys[3];
-                T* yl = yt + (int64_t)(4 * g) * p.ys[2] + (int64_t)oxl * p.ys[3];
-                #pragma unroll
-                for (int r = 0; r < 16; r++)
+                if (rowsHere >= 32)
                 {
-                    const int rr = (r & 3) + 8 * (r >> 2);
-                    if (rr < rowLimit) yl[(int64_t)rr * p.ys[2]] = from_acc<T>(accY[r]);
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        *reinterpret_cast<T*>(ypl + (yoff + (uint32_t)((r & 3) + 8 * (r >> 2)) * st_row)) = from_acc<T>(accY[r]);
+                }
+                else
+                {
+                    const int rowLimit = rowsHere - 4 * g;
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if ((r & 3) + 8 * (r >> 2) < rowLimit)
+                            *reinterpret_cast<T*>(ypl + (yoff + (uint32_t)((r & 3) + 8 * (r >> 2)) * st_row)) = from_acc<T>(accY[r]);
                 }
             }
         }
@@ -602,6 +659,10 @@ int launch_mfma(FlreluArgs& p, int mode, hipStream_t stream)
     p.tilesY = (p.yh + TH - 1) / TH;
     const int64_t tiles = (int64_t)p.tilesX * p.tilesY * p.n * p.c;
     LVG_REQUIRE(tiles <= 0x7fffffffLL, "filtered_lrelu: too many tiles for one launch");
+    // lane offsets inside a plane are 32-bit byte offsets
+    if (((int64_t)p.xh * p.xs[2] + (int64_t)p.xw * p.xs[3]) * 2 >= 0x7fffffffLL || ((int64_t)p.yh * p.ys[2] + (int64_t)p.yw * p.ys[3]) * 2 >= 0x7fffffffLL ||
+        (int64_t)p.sH * p.sWBytes >= 0x7fffffffLL || p.xs[2] < 0 || p.xs[3] < 0 || p.ys[2] < 0 || p.ys[3] < 0)
+        return LVG_ERR_UNSUPPORTED;
     // Persistent workgroups: 3 per CU fit (LDS), each walks over tiles with stride gridDim.
     static int cus[64] = {0};
     int dev = 0; (void)hipGetDevice(&dev);
@@ -611,7 +672,7 @@ int launch_mfma(FlreluArgs& p, int mode, hipStream_t stream)
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         cus[dev & 63] = ncu;
     }
-    const int64_t maxGrid = (int64_t)ncu * 3;
+    const int64_t maxGrid = (int64_t)ncu * LVG_MFMA_WAVES;
     const unsigned grid = (unsigned)(tiles < maxGrid ? tiles : maxGrid);
     const size_t lds = G::LDS_BYTES;
     // Pairs of input columns are fetched as one dword when every pair is dword aligned and never straddles the

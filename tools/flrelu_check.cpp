@@ -244,9 +244,11 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
 
 int main(int argc, char** argv)
 {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const std::string what = argc > 1 ? argv[1] : "all";
     const char* root = getenv("GRAFT_REPO_ROOT"); std::string r = root ? root : ".";
-    void* lib = dlopen((r + "/long-video-gan_amd/lib/liblvg_hip.so").c_str(), RTLD_NOW);
+    const char* libenv = getenv("LVG_LIB");
+    void* lib = dlopen(libenv ? libenv : (r + "/long-video-gan_amd/lib/liblvg_hip.so").c_str(), RTLD_NOW);
     void* orc = dlopen((r + "/oracle/_build/liblvg_oracle.so").c_str(), RTLD_NOW);
     if (!lib || !orc) { printf("dlopen failed: %s\n", dlerror()); return 2; }
     g_flrelu = (flrelu_fn)dlsym(lib, "lvg_filtered_lrelu"); g_setimpl = (setimpl_fn)dlsym(lib, "lvg_filtered_lrelu_set_impl");
