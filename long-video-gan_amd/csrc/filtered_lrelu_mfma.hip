@@ -42,6 +42,9 @@
 #endif
 
 // Tuning switches (A/B measured with tools/flrelu_check):
+#ifndef LVG_ABL
+#define LVG_ABL 0            // ablation builds only (timing experiments; results are WRONG): 1 no prefetch, 2 no y stores, 4 no activation math, 8 no stage D, 16 all y stores to plane 0 tile 0, 32 all x loads from plane 0
+#endif
 #ifndef LVG_MFMA_PIPELINE
 #define LVG_MFMA_PIPELINE 1      // issue stage B of block b + 1 before the activation of block b
 #endif
@@ -90,7 +93,8 @@ struct MG
     static constexpr int OFF_X    = OFF_TAB + NIMG * 1024;
     static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2;
     static constexpr int OFF_M    = OFF_W + kUpT * SW * 2;
-    static constexpr int LDS_BYTES = OFF_M + kUpT * 32;
+    static constexpr int SM       = 36;                                       // mask tile row stride (bytes): 9 dwords, lanes = rows hit distinct banks
+    static constexpr int LDS_BYTES = OFF_M + kUpT * SM;
     static_assert(FU % UP == 0 && FD % DOWN == 0, "filter sizes must be multiples of the rates");
     static_assert(IN_N % 2 == 0 && IN_BLK * 32 <= SX, "input tile geometry");
     static_assert((TW * DOWN) % 4 == 0 && (TW * DOWN) % UP == 0 && (TH * DOWN) % UP == 0, "tile origin must keep the mask byte and the up-sampling phase fixed");
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     _Float16*  tab  = reinterpret_cast<_Float16*>(smem + G::OFF_TAB);      // fragment images, 512 halves each, lane-major
     _Float16*  XL   = reinterpret_cast<_Float16*>(smem + G::OFF_X);        // input tile + bias [X_ROWS][SX]
     _Float16*  WL   = reinterpret_cast<_Float16*>(smem + G::OFF_W);        // W [128 v][SW]
-    uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][32 bytes]
+    uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][SM bytes, 32 used]
     const int tid = threadIdx.x, lane = tid & 63, w = sgpr(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
 
@@ -344,13 +348,15 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     const uint32_t ld_pass = (uint32_t)(RPP * (int)p.xs[2]) * 2u;
     const uint32_t ld_x1 = (uint32_t)((int)p.xs[3]) * 2u;
     uint32_t raw[NPASS];                                                    // prefetched pairs of the NEXT tile (storage bits)
-    uint32_t mraw[4];                                                       // READ mode: prefetched mask dwords of the next tile
+    uint32_t mraw[5];                                                       // READ mode: prefetched (aligned) mask dwords of the next tile
+    int mshiftN = 0, mvalidN = 0;                                           // ... their byte shift (uniform) and this thread's count of valid bytes
     float biasN = 0.0f;
     // Stage D: this wave's output block and this lane's column.
     const int dBy = w / G::OBX, dBx = w - dBy * G::OBX;
-    const int dOxl = 32 * dBx + n;
-    const uint32_t st_off0 = (uint32_t)(4 * g * (int)p.ys[2] + dOxl * (int)p.ys[3]) * 2u;
-    const uint32_t st_row = (uint32_t)((int)p.ys[2]) * 2u;
+    const uint32_t st_off0 = (uint32_t)(n * (int)p.ys[2] + (32 * dBx + 4 * g) * (int)p.ys[3]) * 2u;   // row n of the block, first of this lane's columns
+    const uint32_t st_x1 = (uint32_t)((int)p.ys[3]) * 2u;
+    // four consecutive outputs go out as one 8-byte store when they are contiguous and dword aligned
+    const bool fastStore = p.ys[3] == 1 && (p.ys[2] & 1) == 0 && (p.ys[1] & 1) == 0 && (p.ys[0] & 1) == 0 && (((uintptr_t)p.y) & 3u) == 0;
 
     auto issue_loads = [&](const TileCoord& tc)
     {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         // plane base (64-bit) + first input pixel of the tile (32-bit element offset, may be negative)
         // "scalar plane base + 32-bit lane offset" addressing: the tile term keeps the sum inside this block, so the
         // compiler cannot hoist ten 64-bit lane addresses out of the tile loop (it did: +20 VGPRs and spills)
-        const char* xpl = (const char*)((const T*)p.x + ((int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1]));
+        const char* xpl = (const char*)((const T*)p.x + ((LVG_ABL & 32) ? 0 : ((int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1])));
         const uint32_t xoff = (uint32_t)(inY0 * (int)p.xs[2] + inX0 * (int)p.xs[3]) * 2u + ld_off0;    // valid lanes: >= 0
         const int bi = tc.plane - planeBeg;
         const uint32_t bb = bi < 64 ? biasL[bi] : (uint32_t)((const uint16_t*)p.b)[tc.ch];
@@ -406,27 +412,24 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         }
         if (MODE == LVG_SIGNS_READ)
         {
+            // 16 bytes of one mask row per thread, fetched as the 5 aligned dwords that cover them (rows of the mask
+            // plane are dword aligned, the tile's first byte is not); write_tile() shifts them into place.
             const int row = tid >> 1, half = tid & 1;
             const int signByte0 = (uStart + p.sOfsX) >> 2;
             const int sy = upY0 + p.sOfsY + row;
-            const bool rowOk = sy >= 0 && sy < p.sH;
-            const uint8_t* srow = p.s + (int64_t)tc.plane * ((int64_t)p.sH * p.sWBytes) + (int64_t)(sy * p.sWBytes);
+            const bool rowOk = (uint32_t)sy < (uint32_t)p.sH;
+            const uint8_t* spl = p.s + (int64_t)tc.plane * ((int64_t)p.sH * p.sWBytes);
+            const int b0 = signByte0 + 16 * half, a0 = b0 & ~3;
+            const uint32_t rowOff = (uint32_t)(sy * p.sWBytes);
+            mshiftN = signByte0 & 3;
+            mvalidN = p.swLimit - b0;                                        // bytes of this thread's 16 that carry pixels (may be <= 0 or >= 16)
             #pragma unroll
-            for (int d = 0; d < 4; d++)
+            for (int j = 0; j < 5; j++)
             {
-                const int bx0 = signByte0 + 16 * half + 4 * d;
+                const int bx = a0 + 4 * j;
                 uint32_t v = 0;
-                if (rowOk)
-                {
-                    if ((signByte0 & 3) == 0 && bx0 >= 0 && bx0 + 4 <= p.swLimit) v = *reinterpret_cast<const uint32_t*>(srow + bx0);
-                    else
-                    {
-                        #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if (bx0 + k >= 0 && bx0 + k < p.swLimit) v |= (uint32_t)srow[bx0 + k] << (8 * k);
-                    }
-                }
-                mraw[d] = v;
+                if (rowOk && bx >= 0 && bx + 4 <= p.sWBytes) v = *reinterpret_cast<const uint32_t*>(spl + (rowOff + (uint32_t)bx));
+                mraw[j] = v;
             }
         }
     };
@@ -441,7 +444,17 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             if (ok) *reinterpret_cast<half2v*>(XL + ld_lds0 + RPP * i * G::SX) = pair_plus_bias<T>(raw[i], bias2, biasN);
         }
         if (MODE == LVG_SIGNS_READ)
-            *reinterpret_cast<uint4*>(ML + (tid >> 1) * 32 + 16 * (tid & 1)) = make_uint4(mraw[0], mraw[1], mraw[2], mraw[3]);
+        {
+            uint32_t* m = reinterpret_cast<uint32_t*>(ML + (tid >> 1) * G::SM + 16 * (tid & 1));
+            #pragma unroll
+            for (int d = 0; d < 4; d++)
+            {
+                uint32_t v = __builtin_amdgcn_alignbyte(mraw[d + 1], mraw[d], (uint32_t)mshiftN);
+                const int nv = mvalidN - 4 * d;                              // bytes at and beyond swLimit carry no pixels
+                if (nv < 4) v = nv <= 0 ? 0u : (v & ((1u << (8 * nv)) - 1u));
+                m[d] = v;
+            }
+        }
     };
     // One 32 x 32 block of U^T = A_x * T' (stage B) for column block b of the up-sampled tile.
     auto stage_b = [&](int b, const half8 (&tpk)[G::IN_BLK][2]) -> f32x16
@@ -462,7 +475,58 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         return acc;
     };
 
+    // Stage D of one tile: Y^T[ox][oy] = W^T * D_y^T from WL (all waves' rows), one 32 x 32 output block per wave.
+    // Lanes = 32 output rows, registers 4q .. 4q + 3 = four consecutive ox -> 8-byte stores. `store` = false computes
+    // without writing (first trip of the pipelined loop: WL holds nothing yet).
+    auto stage_d = [&](const TileCoord& tc, bool store)
+    {
+        if (w < G::OBX * G::OBY && !(LVG_ABL & 8))
+        {
+            const int outX0 = tc.tileX * TW, outY0 = tc.tileY * TH;
+            f32x16 accY;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) accY[r] = 0.0f;
+            #pragma unroll
+            for (int cls = 0; cls < G::NDC; cls++)
+            {
+                const int c = 2 * dBy * DOWN + cls;
+                if (c < 8)
+                {
+                    const half8 fd = lds_frag(tab, G::IMG_DY + cls, lane);
+                    const half8 wt = lds_tr_operand(WL, G::SW, 16 * c, 32 * dBx, lane);
+                    accY = mfma(wt, fd, accY);
+                }
+            }
+            const int rowsHere = min(TH, p.yh - outY0) - 32 * dBy;           // rows of this wave's block that exist (uniform)
+            const int colRoom = min(TW, p.yw - outX0) - 32 * dBx - 4 * g;    // columns from this lane's first one that exist
+            if (store && n < rowsHere && !(LVG_ABL & 2))
+            {
+                char* ypl = (char*)((T*)p.y + ((LVG_ABL & 16) ? 0 : ((int64_t)tc.nb * p.ys[0] + (int64_t)tc.ch * p.ys[1])));
+                const uint32_t yoff = (uint32_t)((((LVG_ABL & 16) ? 0 : outY0) + 32 * dBy) * (int)p.ys[2] + ((LVG_ABL & 16) ? 0 : outX0) * (int)p.ys[3]) * 2u + st_off0;
+                #pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    if (fastStore && 8 * q + 4 <= colRoom)
+                    {
+                        T t4[4];
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) t4[e] = from_acc<T>(accY[4 * q + e]);
+                        uint2 v; __builtin_memcpy(&v, t4, 8);
+                        *reinterpret_cast<uint2*>(ypl + (yoff + 16u * q)) = v;
+                    }
+                    else
+                    {
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (8 * q + e < colRoom) *reinterpret_cast<T*>(ypl + (yoff + (uint32_t)(8 * q + e) * st_x1)) = from_acc<T>(accY[4 * q + e]);
+                    }
+                }
+            }
+        }
+    };
+
     if (tileBeg < tileEnd) { issue_loads(cur); write_tile(); }
+    TileCoord prv = cur;
 
     LVG_MARK("loop");
     for (int tile = tileBeg; tile < tileEnd; tile++)
@@ -471,7 +535,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         const int outX0 = tileX * TW, outY0 = tileY * TH;
 
         LVG_MARK("barrier1");
-        __syncthreads();                                                    // barrier 1: XL (ML, table) visible; previous tile's stage D done
+        __syncthreads();                                                    // barrier X: XL (ML, table) of this tile and WL of the previous tile visible
 
         // ---- prefetch the next tile's input (and mask) into registers; it lands while this tile computes ----
         LVG_MARK("prefetch");
@@ -479,7 +543,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         if (tile + 1 < tileEnd)
         {
             if (++nxt.tileX == p.tilesX) { nxt.tileX = 0; if (++nxt.tileY == p.tilesY) { nxt.tileY = 0; ++nxt.plane; if (++nxt.ch == p.c) { nxt.ch = 0; ++nxt.nb; } } }
-            issue_loads(nxt);
+            if (!(LVG_ABL & 1)) issue_loads(nxt);
         }
 
         // ---- stage A: T'[ic][v] for this wave's 32 rows v ------------------------------------------------
@@ -510,6 +574,11 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             for (int m = 0; m < G::IN_BLK; m++) { tpk[m][0] = pack_chunk(accA[m], 0); tpk[m][1] = pack_chunk(accA[m], 1); }
         }
 
+        // ---- stage D of the PREVIOUS tile: independent of everything above, so its LDS-read -> 5-MFMA chain -> store
+        //      latency overlaps with stage A / B of this tile instead of sitting alone between two barriers ----------
+        LVG_MARK("stageD");
+        stage_d(prv, tile > tileBeg);
+
         // ---- stages B, activation, C over the four 32-column blocks of u, software-pipelined: the MFMAs of block
         //      b + 1 are issued before the (vector-pipe) activation of block b, stage C of block b after it --------
         LVG_MARK("stageBC");
@@ -518,7 +587,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         for (int bo = 0; bo < G::OBX; bo++)
             #pragma unroll
             for (int r = 0; r < 16; r++) accW[bo][r] = 0.0f;
-        uint8_t* mrow = ML + (32 * w + n) * 32 + g;
+        uint8_t* mrow = ML + (32 * w + n) * G::SM + g;
         f32x16 accU = stage_b(0, tpk);
         #pragma unroll
         for (int b = 0; b < 4; b++)
@@ -527,7 +596,8 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             if (LVG_MFMA_PIPELINE && b < 3) accUn = stage_b(b + 1, tpk);
             // Activation in packed f16 (act_block): registers 4q .. 4q + 3 are the four pixels of mask byte 8 b + 2 q + g.
             uint32_t zp[8];
-            if (slopeMax) act_block<MODE, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
+            if (LVG_ABL & 4) { for (int i = 0; i < 8; i++) { half2v t; t[0] = (_Float16)accU[2 * i]; t[1] = (_Float16)accU[2 * i + 1]; zp[i] = h2_bits(t); } }
+            else if (slopeMax) act_block<MODE, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
             else          act_block<MODE, false>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
             #pragma unroll
             for (int h = 0; h < 2; h++)
@@ -545,6 +615,9 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             }
             if (b < 3) accU = LVG_MFMA_PIPELINE ? accUn : stage_b(b + 1, tpk);
         }
+        LVG_MARK("barrier2");
+        __syncthreads();                                                    // barrier Y: every wave is done reading XL and WL (and writing ML in WRITE mode)
+
         // W[ox][v] -> WL[v][ox]: registers 4q .. 4q + 3 are four consecutive ox
         LVG_MARK("wwrite");
         #pragma unroll
@@ -557,8 +630,6 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
                 for (int e = 0; e < 4; e++) h[e] = (_Float16)accW[bo][4 * q + e];
                 *reinterpret_cast<half4*>(WL + (32 * w + n) * G::SW + 32 * bo + 8 * q + 4 * g) = h;
             }
-        LVG_MARK("barrier2");
-        __syncthreads();                                                    // barrier 2: WL (and ML in WRITE mode) complete; XL / ML free
 
         // ---- WRITE mode: mask tile -> global, only the part this tile owns --------------------------------
         LVG_MARK("maskout");
@@ -566,7 +637,6 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         {
             const int uStart = outX0 * DOWN, upY0 = outY0 * DOWN;            // (sign offsets are 0 when writing)
             const int signByte0 = uStart >> 2;
-            const int ownBytes = (tileX == p.tilesX - 1) ? 32 : (TW * DOWN) / 4;
             const int ownRows  = (tileY == p.tilesY - 1) ? kUpT : TH * DOWN;
             const int row = tid >> 1, half = tid & 1;
             const int sy = upY0 + row;
@@ -574,18 +644,46 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             if (row < ownRows && sy < p.sH)
             {
                 uint8_t* srow = splane + (uint32_t)(sy * p.sWBytes);
-                const uint4 v = *reinterpret_cast<const uint4*>(ML + row * 32 + 16 * half);
-                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-                #pragma unroll
-                for (int d = 0; d < 4; d++)
+                const uint32_t* m = reinterpret_cast<const uint32_t*>(ML + row * G::SM + 16 * half);
+                const uint32_t wds[4] = {m[0], m[1], m[2], m[3]};
+                if (tileX != p.tilesX - 1)
                 {
-                    const int k0 = 16 * half + 4 * d, bx0 = signByte0 + k0;
-                    if (k0 + 4 <= ownBytes && bx0 + 4 <= p.swLimit) *reinterpret_cast<uint32_t*>(srow + bx0) = wds[d];
-                    else
+                    // interior tile: it owns the first OWN bytes of every row, all of them inside the plane
+                    constexpr int OWN = (TW * DOWN) / 4;
+                    #pragma unroll
+                    for (int hh = 0; hh < 2; hh++)
                     {
-                        #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if (k0 + k < ownBytes && bx0 + k < p.swLimit) srow[bx0 + k] = (uint8_t)(wds[d] >> (8 * k));
+                        if (half == hh)
+                        {
+                            #pragma unroll
+                            for (int d = 0; d < 4; d++)
+                            {
+                                constexpr int dummy = 0; (void)dummy;
+                                const int k0 = 16 * hh + 4 * d;                       // compile-time after unrolling
+                                if (k0 + 4 <= OWN) *reinterpret_cast<uint32_t*>(srow + signByte0 + k0) = wds[d];
+                                else
+                                {
+                                    #pragma unroll
+                                    for (int k = 0; k < 4; k++)
+                                        if (k0 + k < OWN) srow[signByte0 + k0 + k] = (uint8_t)(wds[d] >> (8 * k));
+                                }
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    #pragma unroll
+                    for (int d = 0; d < 4; d++)
+                    {
+                        const int k0 = 16 * half + 4 * d, bx0 = signByte0 + k0;
+                        if (bx0 + 4 <= p.swLimit) *reinterpret_cast<uint32_t*>(srow + bx0) = wds[d];
+                        else
+                        {
+                            #pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (bx0 + k < p.swLimit) srow[bx0 + k] = (uint8_t)(wds[d] >> (8 * k));
+                        }
                     }
                 }
             }
@@ -602,52 +700,18 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             }
         }
 
-        // ---- the prefetched next tile -> XL (ML); stage A of this tile is behind barrier 2 -----------------
+        // ---- the prefetched next tile -> XL (ML); stage A of this tile is behind barrier Y -----------------
         LVG_MARK("xwrite");
-        if (tile + 1 < tileEnd) write_tile();
+        if (tile + 1 < tileEnd && !(LVG_ABL & 1)) write_tile();
 
-        // ---- stage D: one 32 x 32 output block per wave ---------------------------------------------------
-        LVG_MARK("stageD");
-        if (w < G::OBX * G::OBY)
-        {
-            f32x16 accY;
-            #pragma unroll
-            for (int r = 0; r < 16; r++) accY[r] = 0.0f;
-            #pragma unroll
-            for (int cls = 0; cls < G::NDC; cls++)
-            {
-                const int c = 2 * dBy * DOWN + cls;
-                if (c < 8)
-                {
-                    const half8 fd = lds_frag(tab, G::IMG_DY + cls, lane);
-                    const half8 wt = lds_tr_operand(WL, G::SW, 16 * c, 32 * dBx, lane);
-                    accY = mfma(fd, wt, accY);
-                }
-            }
-            // lanes = 32 consecutive ox of one row: each store instruction writes two 64-byte row segments
-            const int colLimit = min(TW, p.yw - outX0);                      // columns / rows of this tile that exist
-            const int rowsHere = min(TH, p.yh - outY0) - 32 * dBy;           // rows of this wave's block that exist (uniform)
-            char* ypl = (char*)((T*)p.y + ((int64_t)nb * p.ys[0] + (int64_t)ch * p.ys[1]));
-            const uint32_t yoff = (uint32_t)((outY0 + 32 * dBy) * (int)p.ys[2] + outX0 * (int)p.ys[3]) * 2u + st_off0;
-            if (dOxl < colLimit)
-            {
-                if (rowsHere >= 32)
-                {
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        *reinterpret_cast<T*>(ypl + (yoff + (uint32_t)((r & 3) + 8 * (r >> 2)) * st_row)) = from_acc<T>(accY[r]);
-                }
-                else
-                {
-                    const int rowLimit = rowsHere - 4 * g;
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        if ((r & 3) + 8 * (r >> 2) < rowLimit)
-                            *reinterpret_cast<T*>(ypl + (yoff + (uint32_t)((r & 3) + 8 * (r >> 2)) * st_row)) = from_acc<T>(accY[r]);
-                }
-            }
-        }
+        prv = cur;
         cur = nxt;
+    }
+    // stage D of the last tile
+    if (tileBeg < tileEnd)
+    {
+        __syncthreads();
+        stage_d(prv, true);
     }
 }
 
