@@ -95,6 +95,23 @@ class OpTimer:
             return streams * ysum.element_size()
         wrap(lres, 'tap_gather_forward', lambda a: 'tapconv_epilogue_fwd', tap_fwd_bytes)
         wrap(lres, 'tap_gather_backward', lambda a: 'tapconv_epilogue_bwd', tap_bwd_bytes)
+        # filtered_lrelu._fused(x, fu, fd, b, si, up, down, ...) -> (y, so, rc): (N_in + N_out) * s + mask bytes
+        # (written in the forward of a training pass, read in its backward) -- SURVEY.md 8(d)
+        from torch_utils.ops import filtered_lrelu
+
+        def fl_bytes(args, out):
+            x, si = args[0], args[4]
+            y, so, rc = out
+            if rc < 0 or y is None:
+                return 0
+            mask = so.numel() if so is not None else (si.numel() if si is not None else 0)
+            return (x.numel() + y.numel()) * x.element_size() + mask
+
+        def fl_name(args):
+            x, si, up, down = args[0], args[4], args[5], args[6]
+            mode = 'bwd' if si is not None else 'fwd'
+            return f'filtered_lrelu_u{up}d{down}_{mode}' if x.dtype != torch.float32 else f'filtered_lrelu_f32_u{up}d{down}_{mode}'
+        wrap(filtered_lrelu, '_fused', fl_name, fl_bytes)
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step
@@ -108,7 +125,8 @@ class OpTimer:
         side = torch.cuda.Stream()
         by_op = {}
         for call in self.calls:
-            by_op.setdefault(call[0], []).append(call)
+            if call[4] > 0:
+                by_op.setdefault(call[0], []).append(call)
         for op, calls in by_op.items():
             g = torch.cuda.CUDAGraph()
             keep = []                                            # distinct output buffer per launch, as in the step
@@ -163,6 +181,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--forward-only', action='store_true', help='time G forward alone (frames/sec/GPU lres-G forward)')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the forward-only / MFMA / super-resolution legs appended to the N=1 line')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the step from a captured hipGraph (removes ~2800 host launches per step)')
     args = ap.parse_args()
@@ -323,9 +342,112 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = _cpu_baseline(forward_only=args.forward_only)
+        if world == 1 and not args.no_extra_legs and not args.forward_only:
+            # Same default invocation, further evidence: the headline forward-only rate, the
+            # dense-contraction (MFMA) figure of the step, and BASELINE.json configs[3] (super-resolution pair)
+            # with the filtered_lrelu roofline. Failures here never take the main line down.
+            del graph
+            for name, leg in (('forward_only', lambda: _forward_only_leg(G, B, T, dtype)),
+                              ('mfma', lambda: _mfma_leg(step, elapsed / args.steps)),
+                              ('sres', lambda: _sres_leg(dev, timer))):
+                try:
+                    result[name] = leg()
+                except Exception as err:  # pylint: disable=broad-except
+                    result[name] = {'error': f'{type(err).__name__}: {err}'[:300]}
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / f16 MFMA ~2.5 PFLOP/s
+
+
+def _forward_only_leg(G, B, T, dtype, steps=6):
+    """BASELINE.json's headline metric: frames/sec of the low-resolution generator FORWARD at 128 x 36 x 64
+    (inference: no gradient, no mask), replayed from a hipGraph like the main step."""
+    with torch.no_grad():
+        for _ in range(2):
+            G(B, T, dtype=dtype)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            G(B, T, dtype=dtype)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    del g
+    return {'metric': 'frames/sec/GPU lres-G forward 128x36x64', 'value': round(B * T / dt, 1), 'unit': 'frames/s',
+            'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'hipgraph'}
+
+
+def _mfma_leg(step, sec_per_step):
+    """Dense-contraction FLOPs of one step (convolutions, GEMMs; forward and backward, counted at the dispatcher by
+    torch.utils.flop_counter) over the measured step time, against the dense 16-bit MFMA peak. This is the
+    END-TO-END figure: the time includes everything that is not a contraction. Per-kernel MFMA time is in profiles/."""
+    from torch.utils.flop_counter import FlopCounterMode
+    with FlopCounterMode(display=False) as fc:
+        step()
+    torch.cuda.synchronize()
+    flops = float(fc.get_total_flops())
+    tf = flops / sec_per_step / 1e12
+    return {'flops_per_step': int(flops), 'achieved_tflops': round(tf, 1), 'peak_tflops': MFMA_PEAK_TFLOPS, 'frac': round(tf / MFMA_PEAK_TFLOPS, 4),
+            'scope': 'all dense contractions of the timed lres step / whole step time (end to end)'}
+
+
+def _sres_leg(dev, timer, segments=2, steps=4, warmup=2):
+    """BASELINE.json configs[3]: generator_sres + discriminator_sres on 8-frame 144x256 segments (+-4 context frames of
+    36x64 input), one generator update = G forward -> D forward -> softplus(-logits).mean().backward() -> Adam, f16
+    activations in the high-resolution layers as the reference (num_fp16_res = 4). Eager launches. The
+    filtered_lrelu launches of one step are then re-timed per kernel family (OpTimer) for the roofline."""
+    from torch.utils.flop_counter import FlopCounterMode
+    from lvg.train_sres import SuperResTrainer
+    torch.manual_seed(0)
+    tr = SuperResTrainer(device=dev, compute_dtype=torch.float16, augment_real_sign_target=None, augment_p_init=0.0,
+                         in_augment_strength=0.0, lr_cond_prob=1.0, overlap_grad_sync=False, with_ema=False)
+    lr = (torch.rand(segments, 3, tr.context_seq_length, 36, 64, device=dev) * 2 - 1)
+
+    def step():
+        tr.update_G(lr)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    frames = segments * tr.seq_length
+    with FlopCounterMode(display=False) as fc:
+        step()
+    torch.cuda.synchronize()
+    flops = float(fc.get_total_flops())
+    timer.calls.clear()
+    timer.enabled = True
+    step()
+    timer.enabled = False
+    ops = {k: v for k, v in timer.measure().items() if k.startswith('filtered_lrelu')}
+    tot_ms = sum(v['total_ms'] for v in ops.values())
+    tot_b = sum(v['bytes'] for v in ops.values())
+    n = sum(v['launches'] for v in ops.values())
+    worst = min(ops.values(), key=lambda v: v['gbps']) if ops else None
+    gb = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    out = {'metric': 'frames/sec sres G+D 8-frame 144x256 forward+backward (generator update)', 'value': round(frames / dt, 2), 'unit': 'frames/s',
+           'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warmup, 'dtype': 'f16', 'launch_mode': 'eager',
+           'config': {'workload': f'generator_sres + discriminator_sres, {segments} segments x 8 frames 144x256 from 36x64 (+-4 context), Adam step', 'global_batch': segments},
+           'roofline': {'bound': 'hbm', 'kernel': 'filtered_lrelu', 'achieved': round(gb, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gb / HBM_PEAK_GBPS, 4),
+                        'launches': n, 'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2), 'algorithmic_bytes_per_launch': int(tot_b / max(n, 1)),
+                        'traffic': _pmc_traffic('filtered_lrelu_mfma'),
+                        'measured_on': 'all fused filtered_lrelu launches of one step (forward with mask write, backward with mask read), captured once each into a hipGraph per family, replayed 3x between HIP events',
+                        'families': {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1)) for k, v in ops.items()},
+                        'slowest_family_gbps': round(worst['gbps'], 1) if worst else None},
+           'step_ms_in_filtered_lrelu': round(tot_ms, 3),
+           'mfma': {'flops_per_step': int(flops), 'achieved_tflops': round(flops / dt / 1e12, 1), 'peak_tflops': MFMA_PEAK_TFLOPS,
+                    'frac': round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4), 'scope': 'all dense contractions / whole step time (end to end)'}}
+    return out
 
 
 def _pmc_traffic(kernel):
