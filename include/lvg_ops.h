@@ -185,6 +185,29 @@ int lvg_tapconv_epilogue_backward(const void* dout, const void* ysum, const floa
                                   int64_t frames, int channels, int pixels, int taps, int64_t tap_shift,
                                   int dtype, int act, float alpha, float gain, float clamp, void* stream);
 
+/*
+ * Prologue / epilogue of the 2-D style-modulated convolution of the super-resolution generator, fused with the
+ * NCHW <-> NHWC layout change (csrc/modconv2d_layout.hip). float16 / bfloat16 only; p = y * W + x.
+ *
+ * lvg_modconv2d_nchw_to_nhwc:  dst[n, p, c] = src[n, c, p] * scale[n, c], src = src_a (c_a channels) followed by src_b
+ *   (c_b channels, may be NULL / 0); channels c_a + c_b .. c_dst - 1 of dst are zero (c_dst % 8 == 0). scale: float32
+ *   [n, c_a + c_b] or NULL. With oth (NHWC [n, p, c_oth], c_oth % 8 == 0) and partial (float32 [n, ceil(hw / 64), c_a + c_b]):
+ *   partial[n, t, c] = sum over the 64 pixels of tile t of src[n, c, p] * oth[n, p, c]  (sum over t = the gradient of scale
+ *   of the inverse transform; no atomics, fixed summation order).
+ * lvg_modconv2d_nhwc_to_nchw:  dst[n, c, p] = src[n, p, c] * scale[n, c] for c < c_dst (src has c_src >= c_dst channels,
+ *   c_src % 8 == 0; scale float32 [n, c_dst] or NULL). With oth_a / oth_b (NCHW, c_a + c_b <= c_src channels) and partial
+ *   (float32 [n, ceil(hw / 64), c_a + c_b]): partial[n, t, c] = sum over tile t of src[n, p, c] * oth[n, c, p].
+ *
+ * Replace the reference's Python-level  x * styles  /  x * dcoefs  around the grouped convolution of
+ * modulated_conv2d (model/generator_sres.py:24-67; there the style is folded into per-sample weights) and the
+ * torch.cat with the conditioning frames (model/generator_sres.py:463). No single reference entry point: the
+ * binding is this library's own (long-video-gan_amd/torch_utils/ops/modconv2d_layout.py).
+ */
+int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                               int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream);
+int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, const void* oth_a, const void* oth_b, void* dst, float* partial,
+                               int64_t n, int64_t hw, int c_src, int c_dst, int c_a, int c_b, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

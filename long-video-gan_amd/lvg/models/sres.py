@@ -23,6 +23,7 @@ DiscriminatorEpilogue :392, VideoDiscriminator :458). What is different, on purp
 """
 
 import math
+import os
 from typing import Iterator, List, Optional
 
 import numpy as np
@@ -33,9 +34,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import torch_utils.distributed as dist_utils
-from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, upfirdn2d
+from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, modconv2d_layout, upfirdn2d
 
 from .lres import FullyConnectedLayer, _linear_filter
+
+# 16-bit layers of the generator: dense convolution on channels-last (MFMA implicit-GEMM) kernels between the fused
+# prologue / epilogue of torch_utils.ops.modconv2d_layout. LVG_SRES_CHANNELS_LAST=0 keeps the NCHW convolution.
+CHANNELS_LAST = os.environ.get('LVG_SRES_CHANNELS_LAST', '1') == '1'
 
 SQRT_HALF = math.sqrt(0.5)
 
@@ -84,20 +89,36 @@ class KaiserUpsample(KaiserResample):
 # --------------------------------------------------------------------------------------------------
 # Generator.
 
+def modulation_terms2d(weight: torch.Tensor, style: torch.Tensor, demodulate: bool = True, input_gain: Optional[torch.Tensor] = None,
+                       low_precision: bool = False):
+    """(weight', mod [N, Ci], demod [N, Co] or None), all float32, such that
+    conv2d(x * mod, weight') * demod  ==  the reference's modulated_conv2d(x, weight, style) (generator_sres.py:24-67).
+
+    With `low_precision` the 1 / sqrt(fan_in) part of the demodulation is moved into the weight, so the un-demodulated
+    convolution output stays O(1) in float16 (the reference's convolution output is demodulated through its weights,
+    :50-58); demod is computed from the scaled weight and compensates exactly."""
+    if demodulate:
+        weight = weight * weight.square().mean(dim=(1, 2, 3), keepdim=True).rsqrt()
+        style = style * style.square().mean().rsqrt()          # one statistic over the whole batch, as the reference
+        if low_precision:
+            weight = weight * (1.0 / math.sqrt(weight.shape[1] * weight.shape[2] * weight.shape[3]))
+    mod = style if input_gain is None else style * input_gain
+    demod = None
+    if demodulate:
+        energy = weight.square().sum(dim=(2, 3))                # [Co, Ci]
+        demod = torch.matmul(style.square(), energy.t()).add(1e-8 * (1.0 / (weight.shape[1] * weight.shape[2] * weight.shape[3]) if low_precision else 1.0)).rsqrt()     # [N, Co]
+    return weight, mod, demod
+
+
 def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, demodulate: bool = True,
                      padding: int = 0, input_gain: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [N, Ci, H, W] (any float dtype); weight [Co, Ci, k, k] and style [N, Ci] float32.
 
     Returns conv2d(x, w * style_n) (demodulated per sample and output channel when asked), computed
-    as conv2d(x * style) * demod with the shared weight."""
-    if demodulate:
-        weight = weight * weight.square().mean(dim=(1, 2, 3), keepdim=True).rsqrt()
-        style = style * style.square().mean().rsqrt()          # one statistic over the whole batch, as the reference
-    mod = style if input_gain is None else style * input_gain
+    as conv2d(x * mod) * demod with the shared weight."""
+    weight, mod, demod = modulation_terms2d(weight, style, demodulate, input_gain, low_precision=x.dtype != torch.float32)
     y = conv2d_gradfix.conv2d(input=x * mod.to(x.dtype)[:, :, None, None], weight=weight.to(x.dtype), padding=padding)
-    if demodulate:
-        energy = weight.square().sum(dim=(2, 3))                # [Co, Ci]
-        demod = torch.matmul(style.square(), energy.t()).add(1e-8).rsqrt()     # [N, Co]
+    if demod is not None:
         y = y * demod.to(y.dtype)[:, :, None, None]
     return y
 
@@ -197,10 +218,27 @@ class SynthesisLayer(nn.Module):
         hi = total - lo
         self.padding = [int(lo[0]), int(hi[0]), int(lo[1]), int(hi[1])]
 
-    def forward(self, x: torch.Tensor, w: torch.Tensor, force_fp32: bool = False, update_emas: bool = False) -> torch.Tensor:
-        assert x.shape[1:] == (self.in_channels, int(self.in_size[1]), int(self.in_size[0])), x.shape
+    def forward(self, x: Optional[torch.Tensor], w: torch.Tensor, force_fp32: bool = False, update_emas: bool = False,
+                cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: the layer input [N, in_channels, H, W] as in the reference (previous output and conditioning frames
+        concatenated), or -- with `cond` given -- the previous layer's output alone (None for the first layer): the
+        concatenation then happens inside the fused prologue of the channels-last path."""
+        low_precision = self.use_fp16 and not force_fp32 and (cond if x is None else x).device.type == 'cuda'
+        dtype = self.compute_dtype if low_precision else torch.float32
+        fused = cond is not None and low_precision and CHANNELS_LAST and dtype in (torch.float16, torch.bfloat16)
+        if cond is not None and not fused:
+            x = cond if x is None else torch.cat((x, cond.to(x.dtype)), dim=1)
+            cond = None
+        if fused:
+            assert (0 if x is None else x.shape[1]) + cond.shape[1] == self.in_channels
+        else:
+            assert x.shape[1:] == (self.in_channels, int(self.in_size[1]), int(self.in_size[0])), x.shape
         if update_emas:
-            mag = x.detach().float().square().mean()
+            if fused:       # mean square over the concatenated input
+                parts = [t.detach().float().square().sum() for t in (x, cond) if t is not None]
+                mag = sum(parts) / float(sum(t.numel() for t in (x, cond) if t is not None))
+            else:
+                mag = x.detach().float().square().mean()
             world = dist_utils.get_world_size()
             if world > 1:
                 torch.distributed.all_reduce(mag)
@@ -211,10 +249,12 @@ class SynthesisLayer(nn.Module):
         style = self.affine(w)
         if self.is_torgb:
             style = style * (1 / math.sqrt(self.in_channels * self.conv_kernel ** 2))
-        low_precision = self.use_fp16 and not force_fp32 and x.device.type == 'cuda'
-        dtype = self.compute_dtype if low_precision else torch.float32
-        x = modulated_conv2d(x.to(dtype), self.weight, style, demodulate=not self.is_torgb,
-                             padding=self.conv_kernel - 1, input_gain=input_gain)
+        if fused:
+            weight, mod, demod = modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=input_gain, low_precision=True)
+            x = modconv2d_layout.modulated_conv2d(None if x is None else x.to(dtype), cond.to(dtype), weight, mod, demod, padding=self.conv_kernel - 1)
+        else:
+            x = modulated_conv2d(x.to(dtype), self.weight, style, demodulate=not self.is_torgb,
+                                 padding=self.conv_kernel - 1, input_gain=input_gain)
         if not x.is_contiguous():          # a 1x1 conv may hand back channels-last strides; the fused kernel tiles NCHW planes
             x = x.contiguous()
         x = filtered_lrelu.filtered_lrelu(
@@ -290,8 +330,7 @@ class SynthesisNetwork(nn.Module):
         ws = ws.float().unbind(dim=1)
         x = self.input(ws[0].size(0)) if self.fourfeats else None
         for layer, w, cond in zip(self.layers(), ws, conds):
-            x = cond if x is None else torch.cat((x, cond.to(x.dtype)), dim=1)
-            x = layer(x, w, **layer_kwargs)
+            x = layer(x, w, cond=cond, **layer_kwargs)
         if self.output_scale != 1:
             x = x * self.output_scale
         return x.float()

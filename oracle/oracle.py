@@ -217,3 +217,27 @@ def modconv_epilogue(z, pre=None, b=None, res=None, post=None, taps=1, shift=1, 
                                     ctypes.c_int(ACT_IDS[act]), ctypes.c_double(alpha), ctypes.c_double(gain), ctypes.c_double(clamp))
     assert rc == 0, rc
     return out, ysum, float(msq.value)
+
+
+def modconv2d_prologue(x, cond, mod, c_pad):
+    """cat(x, cond) * mod with zero channels up to c_pad. x may be None. NCHW in, NCHW out."""
+    cond = _f64(cond)
+    n, cb, h, w = cond.shape
+    x64 = _f64(x)
+    ca = 0 if x is None else x64.shape[1]
+    out = np.empty([n, c_pad, h, w], dtype=np.float64)
+    m = _f64(mod)
+    rc = lib().orc_modconv2d_prologue(_dp(x64), _dp(cond), _dp(m), _dp(out), ctypes.c_int64(n), ca, cb, c_pad, ctypes.c_int64(h * w))
+    assert rc == 0, rc
+    return out
+
+
+def modconv2d_epilogue(y, demod, c_out):
+    """y[:, :c_out] * demod. NCHW in, NCHW out."""
+    y = _f64(y)
+    n, c_pad, h, w = y.shape
+    out = np.empty([n, c_out, h, w], dtype=np.float64)
+    d = _f64(demod)
+    rc = lib().orc_modconv2d_epilogue(_dp(y), _dp(d), _dp(out), ctypes.c_int64(n), c_pad, c_out, ctypes.c_int64(h * w))
+    assert rc == 0, rc
+    return out
