@@ -181,6 +181,10 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--forward-only', action='store_true', help='time G forward alone (frames/sec/GPU lres-G forward)')
+    ap.add_argument('--workload', default='update_G', choices=['update_G', 'train_lres'],
+                    help='update_G: BASELINE configs[1] (default, the contract line). train_lres: the full iteration of train_lres.py:216-230 '
+                         '(configs[2] body: update_G + update_D + R1 every 16th step + EMA, batch 32 / world, 2 micro-batches, 160-frame generator '
+                         'clips cropped to 128, DiffAugment + temporal-scale augment) with backward-overlapped bucketed all-reduce, eager launches')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the forward-only / MFMA / super-resolution legs appended to the N=1 line')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the step from a captured hipGraph (removes ~2800 host launches per step)')
@@ -205,6 +209,11 @@ def main():
 
     dtype = dict(bf16=torch.bfloat16, fp32=torch.float32, fp16=torch.float16)[args.dtype]
     dev = torch.device('cuda', local_rank)
+    if args.workload == 'train_lres':
+        _train_lres_workload(args, world, rank, dev, dtype)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     torch.manual_seed(0)                       # same random-init weights on every rank
     G = VideoGenerator().to(dev).requires_grad_(True).train()
     D = VideoDiscriminator(seq_length=args.frames, max_edge=64).to(dev).requires_grad_(False).train()
@@ -357,6 +366,53 @@ def main():
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def _train_lres_workload(args, world, rank, dev, dtype):
+    """BASELINE.json configs[2] step body on synthetic video: LowResTrainer.train_step (reference train_lres.py:216-230,
+    model/video_gan_lres.py:100-214) -- update_G, update_D, R1 on every 16th step, generator EMA -- total batch 32 split
+    over the ranks, 2 micro-batches, G run at 160 frames and randomly cropped to 128, DiffAugment + temporal-scale
+    augmentation in front of D. Gradients: FlatGradSync with overlap=True (each 128 MB bucket is all-reduced over
+    RCCL from an autograd hook while the rest of the last backward still runs). Eager launches (the collectives
+    cannot be captured into a hipGraph on this stack). One JSON line on rank 0, frames/s over all ranks."""
+    from lvg.train_lres import LowResTrainer
+    total_batch = 32
+    assert total_batch % world == 0
+    B = total_batch // world
+    accum = 2 if B % 2 == 0 else 1
+    torch.manual_seed(0)
+    tr = LowResTrainer(seq_length=args.frames, device=dev, compute_dtype=dtype, G_grad_accum=accum, D_grad_accum=accum,
+                       overlap_grad_sync=True, with_ema=True)
+    torch.manual_seed(1 + rank)
+    real = torch.rand(B, 3, args.frames, 36, 64, device=dev) * 2 - 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    step_no = 1
+    for _ in range(args.warmup):
+        tr.train_step(step_no, real); step_no += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step(step_no, real); step_no += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    r1_steps = sum(1 for k in range(args.warmup + 1, args.warmup + args.steps + 1) if k % 16 == 0)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'frames/sec train_lres iteration (update_G + update_D + R1/16 + EMA), 128-frame 36x64 clips',
+            'value': round(total_batch * args.frames * args.steps / elapsed, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'launch_mode': 'eager',
+            'config': {'workload': f'train_lres.py step body, total batch {total_batch} ({B}/GPU, {accum} micro-batches), G at {args.frames + 32} frames cropped to {args.frames}, '
+                                   f'DiffAugment + temporal-scale augment, R1 steps in the timed region: {r1_steps}', 'global_batch': total_batch,
+                       'frames_per_clip': args.frames, 'parallelism': f'dp{world}', 'grad_sync': 'FlatGradSync(overlap=True), 128 MB buckets'}}), flush=True)
 
 
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / f16 MFMA ~2.5 PFLOP/s
