@@ -75,29 +75,32 @@ def _check_scalars(up, down, gain, slope, clamp):
 
 @misc.profiled_function
 def _filtered_lrelu_ref(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False):
-    """The op as a chain of bias_act / upfirdn2d calls (CPU path and impl='ref'); materialises the
-    up-sampled intermediate, so it needs up**2 times the memory of the fused kernel."""
+    """The op as its definition reads, one stock-PyTorch step per stage (CPU tensors and impl='ref'). The
+    up-sampled intermediate is materialised, so this needs up**2 times the memory of the fused kernels, and a
+    16-bit tensor is rounded after every stage instead of once."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
-    fu_w, fu_h = _get_filter_size(fu)
-    fd_w, fd_h = _get_filter_size(fd)
+    _check_scalars(up, down, gain, slope, clamp)
     if b is not None:
         assert isinstance(b, torch.Tensor) and b.dtype == x.dtype
         misc.assert_shape(b, [x.shape[1]])
-    _check_scalars(up, down, gain, slope, clamp)
+    (fu_w, fu_h), (fd_w, fd_h) = _get_filter_size(fu), _get_filter_size(fd)
     px0, px1, py0, py1 = _parse_padding(padding)
-    n, c, in_h, in_w = x.shape
-    in_dtype = x.dtype
-    out_w = (in_w * up + (px0 + px1) - (fu_w - 1) - (fd_w - 1) + (down - 1)) // down
-    out_h = (in_h * up + (py0 + py1) - (fu_h - 1) - (fd_h - 1) + (down - 1)) // down
+    n, c, h, w = x.shape
+    # sizes after "up-sample + pad + filter" (valid region) and after "filter + keep every down-th sample"
+    mid_w, mid_h = w * up + px0 + px1 - (fu_w - 1), h * up + py0 + py1 - (fu_h - 1)
+    want = [n, c, (mid_h - (fd_h - 1) + (down - 1)) // down, (mid_w - (fd_w - 1) + (down - 1)) // down]
 
-    x = bias_act.bias_act(x=x, b=b)
-    x = upfirdn2d.upfirdn2d(x=x, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up**2, flip_filter=flip_filter)
-    x = bias_act.bias_act(x=x, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
-    x = upfirdn2d.upfirdn2d(x=x, f=fd, down=down, flip_filter=flip_filter)
-
-    misc.assert_shape(x, [n, c, out_h, out_w])
-    assert x.dtype == in_dtype
-    return x
+    y = x if b is None else x + b.reshape(1, -1, 1, 1)
+    y = upfirdn2d.upfirdn2d(x=y, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)     # zero-stuffing loses up**2 of the signal power
+    y = torch.nn.functional.leaky_relu(y, slope)
+    if gain != 1:
+        y = y * gain
+    if clamp is not None:
+        y = y.clamp(-clamp, clamp)
+    y = upfirdn2d.upfirdn2d(x=y, f=fd, down=down, flip_filter=flip_filter)
+    misc.assert_shape(y, want)
+    assert y.dtype == x.dtype
+    return y
 
 #----------------------------------------------------------------------------
 # HIP path.

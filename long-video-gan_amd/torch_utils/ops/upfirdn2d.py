@@ -24,36 +24,35 @@ def _init():
         _plugin = _hip.lib()
     return True
 
-def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    assert isinstance(scaling, (list, tuple))
-    assert all(isinstance(x, int) for x in scaling)
-    sx, sy = scaling
-    assert sx >= 1 and sy >= 1
-    return sx, sy
+def _xy(value, what='factor'):
+    """int or [x, y] -> (x, y), both >= 1."""
+    pair = (value, value) if isinstance(value, int) else tuple(value)
+    if len(pair) != 2 or not all(isinstance(v, int) and v >= 1 for v in pair):
+        raise AssertionError(f'{what} must be a positive int or an [x, y] pair of them, got {value!r}')
+    return pair
 
-def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple))
-    assert all(isinstance(x, int) for x in padding)
-    if len(padding) == 2:
-        padx, pady = padding
-        padding = [padx, padx, pady, pady]
-    padx0, padx1, pady0, pady1 = padding
-    return padx0, padx1, pady0, pady1
+def _pad4(padding):
+    """int, [x, y] or [x0, x1, y0, y1] -> (x0, x1, y0, y1); entries may be negative (= crop)."""
+    vals = [padding] * 2 if isinstance(padding, int) else list(padding)
+    assert all(isinstance(v, int) for v in vals), f'padding entries must be ints, got {padding!r}'
+    if len(vals) == 2:
+        vals = [vals[0], vals[0], vals[1], vals[1]]
+    assert len(vals) == 4, 'padding must have 1, 2 or 4 entries'
+    return tuple(vals)
 
-def _get_filter_size(f):
-    """(width, height) of a filter tensor; None counts as 1x1."""
+def _filter_wh(f):
+    """(width, height) of a filter tensor; None is the 1x1 identity. A 1-D filter reports (taps, taps'),
+    taps' = taps as stored in dim 0 -- callers that use it on both axes set height = width themselves."""
     if f is None:
         return 1, 1
-    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    assert isinstance(f, torch.Tensor) and 1 <= f.ndim <= 2, 'filter must be a 1-D or 2-D tensor'
     with misc.suppress_tracer_warnings():
-        fw, fh = int(f.shape[-1]), int(f.shape[0])
-    misc.assert_shape(f, [fh, fw][:f.ndim])
-    assert fw >= 1 and fh >= 1
-    return fw, fh
+        width, height = int(f.shape[-1]), int(f.shape[0])
+    assert width >= 1 and height >= 1
+    return width, height
+
+# names the reference module exposes (model code and pickles may reach for them)
+_parse_scaling, _parse_padding, _get_filter_size = _xy, _pad4, _filter_wh
 
 #----------------------------------------------------------------------------
 
@@ -100,37 +99,36 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
 
 @misc.profiled_function
 def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
-    """The op written with stock PyTorch ops (CPU path and impl='ref')."""
+    """The op spelled out with stock PyTorch ops (CPU tensors and impl='ref'), one step per line of the
+    definition in `upfirdn2d()`: zero-stuff, pad / crop, correlate each plane with the taps, decimate.
+    Like the reference's definition, `gain` goes into the taps (as gain ** (ndim / 2) per 1-D pass) before
+    they are cast to x's dtype."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
-    if f is None:
-        f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
-    assert f.dtype == torch.float32 and not f.requires_grad
-    n, c, ih, iw = x.shape
-    upx, upy = _parse_scaling(up)
-    downx, downy = _parse_scaling(down)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    assert iw * upx + padx0 + padx1 >= f.shape[-1] and ih * upy + pady0 + pady1 >= f.shape[0]
+    taps = torch.ones([1, 1], dtype=torch.float32, device=x.device) if f is None else f
+    assert isinstance(taps, torch.Tensor) and 1 <= taps.ndim <= 2 and taps.dtype == torch.float32 and not taps.requires_grad
+    (ux, uy), (dx, dy), (px0, px1, py0, py1) = _xy(up, 'up'), _xy(down, 'down'), _pad4(padding)
+    n, c, h, w = x.shape
+    assert w * ux + px0 + px1 >= taps.shape[-1] and h * uy + py0 + py1 >= taps.shape[0], 'padded input smaller than the filter'
 
-    # zero insertion
-    x = x.reshape([n, c, ih, 1, iw, 1])
-    x = torch.nn.functional.pad(x, [0, upx - 1, 0, 0, 0, upy - 1])
-    x = x.reshape([n, c, ih * upy, iw * upx])
-    # pad, then crop for the negative entries
-    x = torch.nn.functional.pad(x, [max(padx0, 0), max(padx1, 0), max(pady0, 0), max(pady1, 0)])
-    x = x[:, :, max(-pady0, 0): x.shape[2] - max(-pady1, 0), max(-padx0, 0): x.shape[3] - max(-padx1, 0)]
-    # depthwise convolution(s)
-    f = f * (gain ** (f.ndim / 2))
-    f = f.to(x.dtype)
-    if not flip_filter:
-        f = f.flip(list(range(f.ndim)))
-    f = f[np.newaxis, np.newaxis].repeat([c, 1] + [1] * f.ndim)
-    if f.ndim == 4:
-        x = conv2d_gradfix.conv2d(input=x, weight=f, groups=c)
+    # 1. one sample every (uy, ux) grid points, zeros in between
+    if ux > 1 or uy > 1:
+        grid = x.new_zeros([n, c, h * uy, w * ux])
+        grid[:, :, ::uy, ::ux] = x
+        x = grid
+    # 2. constant-mode padding takes negative widths as cropping
+    if px0 or px1 or py0 or py1:
+        x = torch.nn.functional.pad(x, [px0, px1, py0, py1])
+    # 3. per-plane correlation = grouped convolution with one (shared) kernel per channel; a true convolution
+    #    unless flip_filter, hence the reversal
+    taps = taps * (gain ** (taps.ndim / 2))
+    taps = (taps if flip_filter else taps.flip(list(range(taps.ndim)))).to(x.dtype)
+    if taps.ndim == 2:
+        x = conv2d_gradfix.conv2d(input=x, weight=taps.expand(c, 1, -1, -1), groups=c)
     else:
-        x = conv2d_gradfix.conv2d(input=x, weight=f.unsqueeze(2), groups=c)
-        x = conv2d_gradfix.conv2d(input=x, weight=f.unsqueeze(3), groups=c)
-    return x[:, :, ::downy, ::downx]
+        x = conv2d_gradfix.conv2d(input=x, weight=taps.reshape(1, 1, 1, -1).expand(c, 1, 1, -1), groups=c)      # along x
+        x = conv2d_gradfix.conv2d(input=x, weight=taps.reshape(1, 1, -1, 1).expand(c, 1, -1, 1), groups=c)      # along y
+    # 4. decimate
+    return x[:, :, ::dy, ::dx]
 
 #----------------------------------------------------------------------------
 # HIP path.
@@ -200,23 +198,25 @@ def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
 
         @staticmethod
         def backward(ctx, dy): # pylint: disable=arguments-differ
+            # The adjoint of "zero-stuff by up, pad, correlate with f, decimate by down" is the same op with the
+            # factors swapped and the filter reversed; the paddings below make its output exactly x-sized:
+            # leading pad = taps - 1 - pad0 (the adjoint of a valid correlation is a full one, minus the forward
+            # pad), trailing pad = whatever is left to reach in * up samples before the new decimation.
+            assert not ctx.needs_input_grad[1], 'the filter is a constant'
+            if not ctx.needs_input_grad[0]:
+                return None, None
             f = ctx.f
-            _, _, ih, iw = ctx.x_shape
-            _, _, oh, ow = dy.shape
-            fw, fh = _get_filter_size(f)
+            fw, fh = _filter_wh(f)
             if f is not None and f.ndim == 1:
                 fh = fw
-            p = [
-                fw - padx0 - 1,
-                iw * upx - ow * downx + padx0 - upx + 1,
-                fh - pady0 - 1,
-                ih * upy - oh * downy + pady0 - upy + 1,
-            ]
-            dx = None
-            if ctx.needs_input_grad[0]:
-                dx = _upfirdn2d_cuda(up=[downx, downy], down=[upx, upy], padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
-            assert not ctx.needs_input_grad[1]
-            return dx, None
+            ih, iw = ctx.x_shape[2:]
+            oh, ow = dy.shape[2:]
+            lead_x, lead_y = fw - 1 - padx0, fh - 1 - pady0
+            trail_x = iw * upx - (ow * downx - padx0) - (upx - 1)
+            trail_y = ih * upy - (oh * downy - pady0) - (upy - 1)
+            adjoint = _upfirdn2d_cuda(up=[downx, downy], down=[upx, upy], padding=[lead_x, trail_x, lead_y, trail_y],
+                                      flip_filter=(not flip_filter), gain=gain)
+            return adjoint.apply(dy, f), None
 
     _upfirdn2d_cuda_cache[key] = Upfirdn2dCuda
     return Upfirdn2dCuda
