@@ -89,7 +89,8 @@ struct MG
     static constexpr int OFF_TAPS = 0;
     static constexpr int OFF_LUT  = TAPS * 4;                               // 16 dwords (READ mode)
     static constexpr int OFF_BIAS = OFF_LUT + 64;                           // bias bits of the first 64 planes of this workgroup's range
-    static constexpr int OFF_TAB  = OFF_BIAS + 256;
+    static constexpr int OFF_TMAX = OFF_BIAS + 256;                         // 2 dwords: max |x + bias| (f16 bits) of the tile in XL / of the tile being written
+    static constexpr int OFF_TAB  = OFF_TMAX + 16;
     static constexpr int OFF_X    = OFF_TAB + NIMG * 1024;
     static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2;
     static constexpr int OFF_M    = OFF_W + kUpT * SW * 2;
@@ -175,9 +176,11 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 // this lane's row v), in packed f16: leaky ReLU, clamp, and the 2-bit mask codes (1 = negative, 2 = clamped).
 // Registers 4q .. 4q + 3 are the four pixels of one mask byte (mbytes[2 q]). Result: the block as 8 packed dwords =
 // the two B-operand chunks of the next MFMA. READ mode multiplies by (1, slope, 0) looked up from the stored codes.
+// CLAMP = false is used for tiles whose input is provably too small to reach the clamp (see `xLimitBits` in the kernel):
+// the clamp and its flag arithmetic are then no-ops and are skipped.
 // The file is compiled with -fno-honor-nans (no canonicalisation ops around min / max): a NaN pre-activation
 // comes out as -clamp instead of NaN.
-template <int MODE, bool SLOPEMAX>
+template <int MODE, bool SLOPEMAX, bool CLAMP>
 __device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8], uint8_t* mbytes, const uint32_t* lut,
                                           half2v slope2, half2v clampP, half2v clampN, uint32_t clampBits)
 {
@@ -214,24 +217,28 @@ __device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8],
             {
                 // bytes 1 and 3 of each pair carry the sign bits; "clamped" = sign bit of (clamp - |L|) as 16-bit integers
                 const uint32_t S = __builtin_amdgcn_perm(h2_bits(P[1]), h2_bits(P[0]), 0x07050301u);
-                uint32_t Tb[2];
-                #pragma unroll
-                for (int h = 0; h < 2; h++)
+                uint32_t x = (S >> 7) & 0x01010101u;
+                if (CLAMP)
                 {
-                    const uint32_t a = h2_bits(L[h]) & 0x7fff7fffu;
-                    short2v cv, av; __builtin_memcpy(&cv, &clampBits, 4); __builtin_memcpy(&av, &a, 4);
-                    const short2v d = cv - av;
-                    __builtin_memcpy(&Tb[h], &d, 4);
+                    uint32_t Tb[2];
+                    #pragma unroll
+                    for (int h = 0; h < 2; h++)
+                    {
+                        const uint32_t a = h2_bits(L[h]) & 0x7fff7fffu;
+                        short2v cv, av; __builtin_memcpy(&cv, &clampBits, 4); __builtin_memcpy(&av, &a, 4);
+                        const short2v d = cv - av;
+                        __builtin_memcpy(&Tb[h], &d, 4);
+                    }
+                    const uint32_t C = __builtin_amdgcn_perm(Tb[1], Tb[0], 0x07050301u);
+                    x = (((S & ~C) >> 7) & 0x01010101u) | ((C >> 6) & 0x02020202u);   // code 2 replaces the sign bit
                 }
-                const uint32_t C = __builtin_amdgcn_perm(Tb[1], Tb[0], 0x07050301u);
-                const uint32_t x = (((S & ~C) >> 7) & 0x01010101u) | ((C >> 6) & 0x02020202u);   // code 2 replaces the sign bit
                 uint32_t y = x | (x >> 6);
                 y = y | (y >> 12);
                 mbytes[2 * q] = (uint8_t)y;
             }
             #pragma unroll
             for (int h = 0; h < 2; h++)
-                zp[2 * q + h] = h2_bits(__builtin_elementwise_min(__builtin_elementwise_max(L[h], clampN), clampP));
+                zp[2 * q + h] = CLAMP ? h2_bits(__builtin_elementwise_min(__builtin_elementwise_max(L[h], clampN), clampP)) : h2_bits(L[h]);
         }
     }
 }
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     float*     taps = reinterpret_cast<float*>(smem + G::OFF_TAPS);        // [0, FU): up taps, [FU, FU + FD): down taps (flipped)
     uint32_t*  lut  = reinterpret_cast<uint32_t*>(smem + G::OFF_LUT);      // READ mode: mask nibble -> pair of gradient factors
     uint32_t*  biasL = reinterpret_cast<uint32_t*>(smem + G::OFF_BIAS);    // storage bits of b[channel] for the planes this workgroup visits
+    uint32_t*  tmax = reinterpret_cast<uint32_t*>(smem + G::OFF_TMAX);     // see xLimitBits
     _Float16*  tab  = reinterpret_cast<_Float16*>(smem + G::OFF_TAB);      // fragment images, 512 halves each, lane-major
     _Float16*  XL   = reinterpret_cast<_Float16*>(smem + G::OFF_X);        // input tile + bias [X_ROWS][SX]
     _Float16*  WL   = reinterpret_cast<_Float16*>(smem + G::OFF_W);        // W [128 v][SW]
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     }
     const int planeBeg = cur.plane;
     if (tid < 64) biasL[tid] = ((const uint16_t*)p.b)[(planeBeg + tid) % p.c];
+    if (tid < 2) tmax[tid] = 0u;
 
     // ---- once per workgroup: taps, fragment images, zero the padding of the input tile -------------------
     if (tid < FU)
@@ -335,6 +344,25 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     const _Float16 clamp_h = (_Float16)(p.clamp < 65504.0f ? p.clamp : 65504.0f);    // no clamp = the largest finite f16
     const half2v clampP = {clamp_h, clamp_h}, clampN = {-clamp_h, -clamp_h};
     const uint32_t clampBits = h2_bits(clampP);
+    // No pre-activation of a tile can exceed  scale * l1(up taps per phase)^2 * max |x + bias|  in magnitude (and leaky
+    // ReLU with slope <= 1 only shrinks it), so tiles whose input maximum stays below clamp / that factor (5 % margin
+    // for the f16 roundings) skip the clamp and the "clamped" flag arithmetic: xLimitBits = that threshold as f16 bits
+    // (positive f16 numbers order like their bit patterns; inf / NaN inputs compare above every finite threshold).
+    uint32_t xLimitBits = 0;
+    {
+        float l1 = 0.0f;
+        for (int ph = 0; ph < UP; ph++)
+        {
+            float a = 0.0f;
+            for (int k = ph; k < FU; k += UP) a += fabsf(taps[k]);
+            l1 = fmaxf(l1, a);
+        }
+        const float lim = p.clamp / ((float)(UP * UP) * p.gain * l1 * l1 * 1.05f + 1e-30f);
+        const _Float16 lh = (_Float16)fminf(lim, 60000.0f);
+        uint16_t lb; __builtin_memcpy(&lb, &lh, 2);
+        xLimitBits = ((float)lh <= lim && lb > 0) ? lb : (lb > 0 ? lb - 1u : 0u);      // round down
+        if (!(p.slope <= 1.0f)) xLimitBits = 0;
+    }
 
     // All per-lane address arithmetic is done ONCE here as 32-bit byte offsets from a per-tile scalar base pointer
     // (the launcher checks that a plane spans < 2^31 bytes), so a load / store in the tile loop is
@@ -358,57 +386,45 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     // four consecutive outputs go out as one 8-byte store when they are contiguous and dword aligned
     const bool fastStore = p.ys[3] == 1 && (p.ys[2] & 1) == 0 && (p.ys[1] & 1) == 0 && (p.ys[0] & 1) == 0 && (((uintptr_t)p.y) & 3u) == 0;
 
+    // Loads are UNCONDITIONAL from offsets clamped into the plane (no execution-mask juggling, no per-pass scalar
+    // control flow); which of them are real pixels is decided when the tile is written to LDS: rows by one unsigned
+    // compare per pass, columns by poisoning the row counter of lanes whose column pair lies outside the image.
+    uint32_t ldRowN = 0;                                                    // next tile: this lane's first row minus the first valid row (poisoned: never valid)
+    uint32_t ldColN = 0;                                                    // next tile, slow path: bit 0 / 1 = column ix / ix + 1 inside the image
+    int ldSpanN = 0;                                                        // next tile: number of valid rows
+    uint32_t negbN = 0;                                                     // next tile: (-bias, -bias) in storage bits
     auto issue_loads = [&](const TileCoord& tc)
     {
         const int uStart = tc.tileX * (TW * DOWN) - rOff, upY0 = tc.tileY * (TH * DOWN);
         const int inX0 = lvg_floor_div(uStart + UP - 1 - p.px0, UP);
         const int inY0 = lvg_floor_div(upY0 + UP - 1 - p.py0, UP);
-        // plane base (64-bit) + first input pixel of the tile (32-bit element offset, may be negative)
         // "scalar plane base + 32-bit lane offset" addressing: the tile term keeps the sum inside this block, so the
         // compiler cannot hoist ten 64-bit lane addresses out of the tile loop (it did: +20 VGPRs and spills)
         const char* xpl = (const char*)((const T*)p.x + ((LVG_ABL & 32) ? 0 : ((int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1])));
-        const uint32_t xoff = (uint32_t)(inY0 * (int)p.xs[2] + inX0 * (int)p.xs[3]) * 2u + ld_off0;    // valid lanes: >= 0
         const int bi = tc.plane - planeBeg;
         const uint32_t bb = bi < 64 ? biasL[bi] : (uint32_t)((const uint16_t*)p.b)[tc.ch];
         { T bt; const uint16_t b16 = (uint16_t)bb; __builtin_memcpy(&bt, &b16, 2); biasN = (float)to_acc(bt); }
-        const uint32_t negb = (bb ^ 0x8000u) * 0x10001u;                      // (-bias, -bias): + bias = 0 outside the image
-        #pragma unroll
-        for (int i = 0; i < NPASS; i++) raw[i] = negb;
-        // rows r in [rLo, rLo + span) and columns with 0 <= ix < xw exist
-        const int rLo = max(0, -inY0), span = max(0, min(G::IN_N, p.xh - inY0) - rLo);
-        const int d0 = ld_r0 - rLo;
+        negbN = (bb ^ 0x8000u) * 0x10001u;                                    // (-bias, -bias): + bias = 0 outside the image
+        const int rLo = max(0, -inY0);
+        ldSpanN = max(0, min(G::IN_N, p.xh - inY0) - rLo);
         const int ix = inX0 + 2 * ld_qp;
-        const bool c0 = ld_active && (uint32_t)ix < (uint32_t)p.xw, c1 = ld_active && (uint32_t)(ix + 1) < (uint32_t)p.xw;
-        if (FASTLOAD)
+        const bool c0 = (uint32_t)ix < (uint32_t)p.xw, c1 = (uint32_t)(ix + 1) < (uint32_t)p.xw;
+        ldColN = (c0 ? 1u : 0u) | (c1 ? 2u : 0u);
+        ldRowN = (FASTLOAD ? c0 : (c0 || c1)) ? (uint32_t)(ld_r0 - rLo) : 0x40000000u;
+        // last byte offset a load may start at (the wrap of a negative offset is far above it)
+        const uint32_t lastEl = (uint32_t)((p.xh - 1) * (int)p.xs[2] + (p.xw - 1) * (int)p.xs[3]) * 2u;
+        uint32_t off = (uint32_t)(inY0 * (int)p.xs[2] + inX0 * (int)p.xs[3]) * 2u + ld_off0;
+        #pragma unroll
+        for (int i = 0; i < NPASS; i++)
         {
-            if (c0)                                                           // pairs are dword aligned and never straddle the image edge
+            if (FASTLOAD) raw[i] = *reinterpret_cast<const uint32_t*>(xpl + min(off, lastEl - 2u));   // pairs are dword aligned, never straddle the edge
+            else
             {
-                #pragma unroll
-                for (int i = 0; i < NPASS; i++)
-                {
-                    // pass i covers rows RPP * i .. RPP * i + RPP - 1: all present, none, or mixed (image top / bottom)
-                    const int lo = RPP * i - rLo;                             // uniform
-                    const char* pr = xpl + (xoff + (uint32_t)i * ld_pass);
-                    if (lo >= 0 && lo + RPP <= span) raw[i] = *reinterpret_cast<const uint32_t*>(pr);
-                    else if (lo + RPP > 0 && lo < span)
-                    {
-                        if ((uint32_t)(d0 + RPP * i) < (uint32_t)span) raw[i] = *reinterpret_cast<const uint32_t*>(pr);
-                    }
-                }
-            }
-        }
-        else
-        {
-            #pragma unroll
-            for (int i = 0; i < NPASS; i++)
-            {
-                const bool rowOk = (uint32_t)(d0 + RPP * i) < (uint32_t)span;
-                const uint32_t o0 = xoff + (uint32_t)i * ld_pass, o1 = o0 + ld_x1;    // (the sums must wrap in 32 bits: the tile term may be negative)
-                uint32_t lo = negb & 0xffffu, hi = negb >> 16;
-                if (rowOk && c0) lo = *reinterpret_cast<const uint16_t*>(xpl + o0);
-                if (rowOk && c1) hi = *reinterpret_cast<const uint16_t*>(xpl + o1);
+                const uint32_t lo = *reinterpret_cast<const uint16_t*>(xpl + min(off, lastEl));
+                const uint32_t hi = *reinterpret_cast<const uint16_t*>(xpl + min(off + ld_x1, lastEl));
                 raw[i] = lo | (hi << 16);
             }
+            off += ld_pass;
         }
         if (MODE == LVG_SIGNS_READ)
         {
@@ -433,15 +449,45 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             }
         }
     };
+    int slotW = 0;                                                          // tmax slot of the tile being written (alternates)
     auto write_tile = [&]()
     {
         const _Float16 bh = (_Float16)biasN;
         const half2v bias2 = {bh, bh};
-        #pragma unroll
-        for (int i = 0; i < NPASS; i++)
+        uint32_t mx2 = 0;
+        if (ld_active)
         {
-            const bool ok = ld_active && (RPP * (i + 1) <= G::IN_N || ld_r0 + RPP * i < G::IN_N);
-            if (ok) *reinterpret_cast<half2v*>(XL + ld_lds0 + RPP * i * G::SX) = pair_plus_bias<T>(raw[i], bias2, biasN);
+            #pragma unroll
+            for (int i = 0; i < NPASS; i++)
+            {
+                const bool rowOk = (ldRowN + (uint32_t)(RPP * i)) < (uint32_t)ldSpanN;
+                uint32_t v = rowOk ? raw[i] : negbN;
+                if (!FASTLOAD)                                                // one of the two columns may lie outside the image
+                    v = (v & ((ldColN & 1u) ? 0xffffu : 0u)) | (v & ((ldColN & 2u) ? 0xffff0000u : 0u)) |
+                        (negbN & (((ldColN & 1u) ? 0u : 0xffffu) | ((ldColN & 2u) ? 0u : 0xffff0000u)));
+                const half2v hv = pair_plus_bias<T>(v, bias2, biasN);
+                *reinterpret_cast<half2v*>(XL + ld_lds0 + RPP * i * G::SX) = hv;
+                if (MODE != LVG_SIGNS_READ)
+                {
+                    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+                    const uint32_t ab = h2_bits(hv) & 0x7fff7fffu;
+                    ushort2v am, cm; __builtin_memcpy(&am, &ab, 4); __builtin_memcpy(&cm, &mx2, 4);
+                    cm = __builtin_elementwise_max(cm, am);
+                    __builtin_memcpy(&mx2, &cm, 4);
+                }
+            }
+        }
+        if (MODE != LVG_SIGNS_READ)
+        {
+            // wave maximum (DPP butterfly inside rows of 16, then row broadcasts), one LDS atomic per wave
+            uint32_t m = max(mx2 & 0xffffu, mx2 >> 16);
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, false));    // row_half_mirror
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, false));    // row_mirror
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, false));    // row_bcast15 -> rows 1, 3
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x143, 0xc, 0xf, false));    // row_bcast31 -> rows 2, 3
+            if (lane == 63) atomicMax(&tmax[slotW], m);
         }
         if (MODE == LVG_SIGNS_READ)
         {
@@ -537,6 +583,12 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         LVG_MARK("barrier1");
         __syncthreads();                                                    // barrier X: XL (ML, table) of this tile and WL of the previous tile visible
 
+        // tmax[slotR] = max |x + bias| of the tile now in XL (written before barrier X); the other slot is cleared here for
+        // the tile written after barrier Y
+        const int slotR = (tile - tileBeg) & 1;
+        const bool noClamp = MODE != LVG_SIGNS_READ && tmax[slotR] < xLimitBits;
+        if (tid == 0) tmax[slotR ^ 1] = 0u;
+
         // ---- prefetch the next tile's input (and mask) into registers; it lands while this tile computes ----
         LVG_MARK("prefetch");
         TileCoord nxt = cur;
@@ -597,8 +649,13 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             // Activation in packed f16 (act_block): registers 4q .. 4q + 3 are the four pixels of mask byte 8 b + 2 q + g.
             uint32_t zp[8];
             if (LVG_ABL & 4) { for (int i = 0; i < 8; i++) { half2v t; t[0] = (_Float16)accU[2 * i]; t[1] = (_Float16)accU[2 * i + 1]; zp[i] = h2_bits(t); } }
-            else if (slopeMax) act_block<MODE, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
-            else          act_block<MODE, false>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
+            else if (MODE == LVG_SIGNS_READ) act_block<MODE, true, false>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
+            else if (slopeMax)
+            {
+                if (noClamp) act_block<MODE, true, false>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
+                else         act_block<MODE, true, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
+            }
+            else act_block<MODE, false, true>(accU, zp, mrow + 8 * b, lut, slope2, clampP, clampN, clampBits);
             #pragma unroll
             for (int h = 0; h < 2; h++)
             {
@@ -702,6 +759,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
 
         // ---- the prefetched next tile -> XL (ML); stage A of this tile is behind barrier Y -----------------
         LVG_MARK("xwrite");
+        slotW = ((tile - tileBeg) & 1) ^ 1;
         if (tile + 1 < tileEnd && !(LVG_ABL & 1)) write_tile();
 
         prv = cur;
