@@ -48,9 +48,6 @@
 #ifndef LVG_MFMA_PIPELINE
 #define LVG_MFMA_PIPELINE 1      // issue stage B of block b + 1 before the activation of block b
 #endif
-#ifndef LVG_MFMA_WAVES
-#define LVG_MFMA_WAVES 3         // __launch_bounds__ waves per SIMD (3 workgroups per CU fit the LDS)
-#endif
 
 namespace {
 
@@ -65,7 +62,7 @@ constexpr int kUpT = 128;       // edge of the up-sampled tile (4 blocks of 32)
 
 constexpr int mdiv_up(int a, int b) { return (a + b - 1) / b; }
 
-template <int UP, int DOWN, int FU, int FD, int TW, int TH>
+template <int UP, int DOWN, int FU, int FD, int TW, int TH, int MODE>
 struct MG
 {
     static constexpr int KU     = FU / UP;                                  // taps per output of an up stage
@@ -73,17 +70,27 @@ struct MG
     static constexpr int IN_BLK = mdiv_up(IN_N, 32);                        // 32-blocks of input columns (stage A's M)
     static constexpr int IN_CH  = ((((kUpT - 1 + UP - 1) / UP) + KU - 1) >> 4) + 1;   // 16-chunks of input rows / columns
     static constexpr int X_ROWS = IN_CH * 16;
-    static constexpr int SX     = 96;                                       // X row stride (halves); SX/2 = 48 mod 64 spreads the transpose reads
+    static constexpr int SX     = 80;                                       // X row stride (halves). Narrower than the 96 columns stage A's transpose reads span for
+                                                                            // UP = 2: columns 80..95 of a row alias the next row's first 16 (finite data); they only
+                                                                            // feed rows 80..95 of T', which nothing reads.
     static constexpr int OBX    = mdiv_up(TW, 32);
     static constexpr int OBY    = mdiv_up(TH, 32);
-    static constexpr int SW     = OBX * 32 + 4;                             // W row stride (halves): 8-byte column writes of 16 rows hit 32 distinct banks
+    static constexpr int SW     = (OBX == 2) ? 60 : OBX * 32 + 4;           // W row stride (halves): 8-byte column writes of 16 rows hit 32 distinct banks; with two
+                                                                            // 32-column blocks only 60 columns are kept (TW <= 56; the last 4 would be discarded anyway)
     static constexpr int NUC    = (UP == 2) ? 2 : (UP == 4 ? 3 : 1);        // distinct band offsets of an up stage
     static constexpr int NDC    = ((31 * DOWN + FD - 1 + 3) >> 4) + 1;      // ... of a down stage (+3: READ-mode column shift)
     static constexpr int IMG_FY = 0;                                        // fragment images: A_y natural k order (stage A)
     static constexpr int IMG_FX = NUC;                                      //                  A_x permuted k order, scaled (stage B)
     static constexpr int IMG_DX = 2 * NUC;                                  //                  D_x permuted (stage C)
-    static constexpr int IMG_DY = 2 * NUC + NDC;                            //                  D_y natural (stage D)
-    static constexpr int NIMG   = 2 * NUC + 2 * NDC;
+    // D_y (stage D, natural k order) equals D_x except for the READ-mode column shift: without it stage D reads the D_x
+    // images with two 8-byte reads per lane (lds_frag_nat_from_perm) and no separate images exist.
+    static constexpr bool SHARE_D = MODE != LVG_SIGNS_READ;
+    static constexpr int IMG_DY = SHARE_D ? IMG_DX : 2 * NUC + NDC;         //                  D_y natural (stage D)
+    static constexpr int NIMG   = 2 * NUC + (SHARE_D ? 1 : 2) * NDC;
+    static constexpr bool HAS_M = MODE != LVG_SIGNS_NONE;                   // mask tile in LDS (assembling the dwords in registers measured slower)
+    // Register budget: 4 waves per SIMD (128 VGPRs) where the kernel fits without spilling (measured with
+    // -Rpass-analysis=kernel-resource-usage), else 3 (168 VGPRs).
+    static constexpr int WAVES  = (MODE == LVG_SIGNS_NONE || UP == 4 || (MODE == LVG_SIGNS_READ && DOWN == 4)) ? 4 : 3;
     static constexpr int TAPS   = (FU + FD + 3) / 4 * 4;
     // LDS map (bytes)
     static constexpr int OFF_TAPS = 0;
@@ -92,16 +99,17 @@ struct MG
     static constexpr int OFF_TMAX = OFF_BIAS + 256;                         // 2 dwords: max |x + bias| (f16 bits) of the tile in XL / of the tile being written
     static constexpr int OFF_TAB  = OFF_TMAX + 16;
     static constexpr int OFF_X    = OFF_TAB + NIMG * 1024;
-    static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2;
-    static constexpr int OFF_M    = OFF_W + kUpT * SW * 2;
+    static constexpr int OFF_W    = OFF_X + X_ROWS * SX * 2 + 64;           // (+64: the aliased reads of the last row stay inside the allocation)
+    static constexpr int OFF_M    = OFF_W + kUpT * SW * 2 + 16;
     static constexpr int SM       = 36;                                       // mask tile row stride (bytes): 9 dwords, lanes = rows hit distinct banks
-    static constexpr int LDS_BYTES = OFF_M + kUpT * SM;
+    static constexpr int LDS_BYTES = OFF_M + (HAS_M ? kUpT * SM : 0);
     static_assert(FU % UP == 0 && FD % DOWN == 0, "filter sizes must be multiples of the rates");
-    static_assert(IN_N % 2 == 0 && IN_BLK * 32 <= SX, "input tile geometry");
+    static_assert(IN_N % 2 == 0 && IN_N <= SX && IN_CH * 16 <= SX, "input tile geometry");
     static_assert((TW * DOWN) % 4 == 0 && (TW * DOWN) % UP == 0 && (TH * DOWN) % UP == 0, "tile origin must keep the mask byte and the up-sampling phase fixed");
     static_assert((TW - 1) * DOWN + FD - 1 + 3 < kUpT && (TH - 1) * DOWN + FD - 1 < kUpT, "tile does not fit the 128 x 128 up-sampled block");
     static_assert(OBX * OBY <= 4, "stage D: one output block per wave");
     static_assert(LDS_BYTES <= 64 * 1024, "LDS budget");
+    static constexpr int CU_WGS = (160 * 1024 / LDS_BYTES) < WAVES ? (160 * 1024 / LDS_BYTES) : WAVES;   // resident workgroups per CU
     static_assert(OFF_TAB % 16 == 0 && OFF_X % 16 == 0 && OFF_W % 16 == 0 && OFF_M % 16 == 0, "alignment");
 };
 
@@ -120,6 +128,19 @@ template <int UP> struct UpChunks
 __device__ __forceinline__ half8 lds_frag(const _Float16* tab, int img, int lane)
 {
     return *reinterpret_cast<const half8*>(tab + img * 512 + lane * 8);
+}
+
+// The natural-order fragment (k = 8 g + j) out of a PERMUTED image: its first four k live in the image of lane (row, g' = 0),
+// halves 4 g .. 4 g + 3, the last four in lane (row, g' = 1) at the same halves.
+__device__ __forceinline__ half8 lds_frag_nat_from_perm(const _Float16* tab, int img, int lane)
+{
+    const int row = lane & 31, g = lane >> 5;
+    const half4 lo = *reinterpret_cast<const half4*>(tab + img * 512 + row * 8 + 4 * g);
+    const half4 hi = *reinterpret_cast<const half4*>(tab + img * 512 + (32 + row) * 8 + 4 * g);
+    half8 r;
+    __builtin_memcpy(&r, &lo, 8);
+    __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &hi, 8);
+    return r;
 }
 
 // MFMA operand (lane: index = lane & 31 along the COLUMNS of a row-major LDS matrix, k = 8 * (lane >> 5) + j along
@@ -246,9 +267,9 @@ __device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8],
 struct TileCoord { int tileX, tileY, ch, nb, plane; };   // plane = nb * channels + ch
 
 template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH, int MODE, bool FASTLOAD>
-__global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_kernel(FlreluArgs p, int totalTiles)
+__global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVES)) void filtered_lrelu_mfma_kernel(FlreluArgs p, int totalTiles)
 {
-    typedef MG<UP, DOWN, FU, FD, TW, TH> G;
+    typedef MG<UP, DOWN, FU, FD, TW, TH, MODE> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float*     taps = reinterpret_cast<float*>(smem + G::OFF_TAPS);        // [0, FU): up taps, [FU, FU + FD): down taps (flipped)
     uint32_t*  lut  = reinterpret_cast<uint32_t*>(smem + G::OFF_LUT);      // READ mode: mask nibble -> pair of gradient factors
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
     _Float16*  tab  = reinterpret_cast<_Float16*>(smem + G::OFF_TAB);      // fragment images, 512 halves each, lane-major
     _Float16*  XL   = reinterpret_cast<_Float16*>(smem + G::OFF_X);        // input tile + bias [X_ROWS][SX]
     _Float16*  WL   = reinterpret_cast<_Float16*>(smem + G::OFF_W);        // W [128 v][SW]
-    uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][SM bytes, 32 used]
+    uint8_t*   ML   = smem + G::OFF_M;                                     // mask tile [128 v][SM bytes, 32 used] (not with MODE NONE)
     const int tid = threadIdx.x, lane = tid & 63, w = sgpr(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
 
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         if (t < p.fdN) v = p.fd ? p.fd[p.flip ? t : p.fdN - 1 - t] : 1.0f;
         taps[FU + t] = v;
     }
-    for (int i = tid; i < G::X_ROWS * G::SX / 2; i += kThreads) reinterpret_cast<uint32_t*>(XL)[i] = 0u;
+    for (int i = tid; i < (G::X_ROWS * G::SX + 32) / 2; i += kThreads) reinterpret_cast<uint32_t*>(XL)[i] = 0u;
     if (MODE == LVG_SIGNS_READ && tid < 16)
     {
         // mask codes of two neighbouring pixels -> (factor of pixel 0, factor of pixel 1): 0 -> 1, 1 -> slope, 2 / 3 -> 0
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
         for (int e = tid; e < G::NIMG * 512; e += kThreads)
         {
             const int img = e >> 9, idx = e & 511, L = idx >> 3, j = idx & 7, row = L & 31, gg = L >> 5;
-            const bool perm = img >= G::IMG_FX && img < G::IMG_DY;
+            const bool perm = img >= G::IMG_FX && img < G::IMG_DX + G::NDC;
             const int k = perm ? ((j & 3) + 8 * (j >> 2) + 4 * gg) : (8 * gg + j);
             float v = 0.0f;
             if (img < G::IMG_DX)
@@ -327,8 +348,8 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
             }
             else
             {
-                const bool isX = img < G::IMG_DY;
-                const int cls = isX ? img - G::IMG_DX : img - G::IMG_DY;
+                const bool isX = img < G::IMG_DX + G::NDC;
+                const int cls = isX ? img - G::IMG_DX : img - (G::IMG_DX + G::NDC);
                 const int t = 16 * cls + k - (isX ? rOff : 0) - row * DOWN;
                 if (t >= 0 && t < FD) v = taps[FU + t];
             }
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
                 const int c = 2 * dBy * DOWN + cls;
                 if (c < 8)
                 {
-                    const half8 fd = lds_frag(tab, G::IMG_DY + cls, lane);
+                    const half8 fd = G::SHARE_D ? lds_frag_nat_from_perm(tab, G::IMG_DX + cls, lane) : lds_frag(tab, G::IMG_DY + cls, lane);
                     const half8 wt = lds_tr_operand(WL, G::SW, 16 * c, 32 * dBx, lane);
                     accY = mfma(wt, fd, accY);
                 }
@@ -685,7 +706,8 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
                 half4 h;
                 #pragma unroll
                 for (int e = 0; e < 4; e++) h[e] = (_Float16)accW[bo][4 * q + e];
-                *reinterpret_cast<half4*>(WL + (32 * w + n) * G::SW + 32 * bo + 8 * q + 4 * g) = h;
+                if (32 * bo + 8 * q + 8 <= G::SW || 32 * bo + 8 * q + 4 * g + 4 <= G::SW)      // (the last 4 of 64 columns are not kept)
+                    *reinterpret_cast<half4*>(WL + (32 * w + n) * G::SW + 32 * bo + 8 * q + 4 * g) = h;
             }
 
         // ---- WRITE mode: mask tile -> global, only the part this tile owns --------------------------------
@@ -776,7 +798,9 @@ __global__ __launch_bounds__(kThreads, LVG_MFMA_WAVES) void filtered_lrelu_mfma_
 template <class T, int UP, int DOWN, int FU, int FD, int TW, int TH>
 int launch_mfma(FlreluArgs& p, int mode, hipStream_t stream)
 {
-    typedef MG<UP, DOWN, FU, FD, TW, TH> G;
+    typedef MG<UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_READ> GR;
+    typedef MG<UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_WRITE> GW;
+    typedef MG<UP, DOWN, FU, FD, TW, TH, LVG_SIGNS_NONE> GN;
     p.tilesX = (p.yw + TW - 1) / TW;
     p.tilesY = (p.yh + TH - 1) / TH;
     const int64_t tiles = (int64_t)p.tilesX * p.tilesY * p.n * p.c;
@@ -794,9 +818,9 @@ int launch_mfma(FlreluArgs& p, int mode, hipStream_t stream)
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         cus[dev & 63] = ncu;
     }
-    const int64_t maxGrid = (int64_t)ncu * LVG_MFMA_WAVES;
+    const int64_t maxGrid = (int64_t)ncu * (mode == LVG_SIGNS_READ ? GR::CU_WGS : (mode == LVG_SIGNS_WRITE ? GW::CU_WGS : GN::CU_WGS));
     const unsigned grid = (unsigned)(tiles < maxGrid ? tiles : maxGrid);
-    const size_t lds = G::LDS_BYTES;
+    const size_t lds = mode == LVG_SIGNS_READ ? GR::LDS_BYTES : (mode == LVG_SIGNS_WRITE ? GW::LDS_BYTES : GN::LDS_BYTES);
     // Pairs of input columns are fetched as one dword when every pair is dword aligned and never straddles the
     // image edge: unit x stride, even row / plane strides and width, even first input column of every tile.
     const int rOff = (mode == LVG_SIGNS_READ) ? (p.sOfsX & 3) : 0;
