@@ -219,7 +219,8 @@ def main():
     D = VideoDiscriminator(seq_length=args.frames, max_edge=64).to(dev).requires_grad_(False).train()
     ddp.broadcast_module(G)
     ddp.broadcast_module(D)
-    opt = torch.optim.Adam(G.parameters(), lr=0.003, betas=(0.0, 0.99))
+    from lvg.optim import FlatAdam
+    opt = FlatAdam(G.parameters(), lr=0.003, betas=(0.0, 0.99))       # one fused HIP launch over the flat parameter / moment / gradient buffers
     # Gradient exchange: ONE flat buffer (the .grad tensors are views into it), all-reduced after the
     # backward pass in 128 MB buckets. The compute part of the step is replayed from a hipGraph; the RCCL
     # collective and the optimizer stay outside the graph (an RCCL all-reduce inside a captured graph aborts

@@ -208,6 +208,19 @@ int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float
 int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, const void* oth_a, const void* oth_b, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_src, int c_dst, int c_a, int c_b, int dtype, void* stream);
 
+/*
+ * Adam step over one flat float32 range, optionally followed by the exponential moving average of the updated
+ * weights, in one pass (csrc/optim.hip):
+ *   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ *   p_ema += (p - p_ema) * ema_weight            (p_ema may be NULL)
+ * torch.optim.Adam's arithmetic (amsgrad off, no weight decay); all ranges 16-byte aligned, `step` >= 1 is the
+ * update count of this range. Replaces the reference's torch.optim.Adam.step() (model/video_gan_lres.py:83-90, used
+ * at :132, :176, :203) and the lerp of update_G_ema (:208-214); no single reference entry point -- the binding is
+ * this library's own (long-video-gan_amd/lvg/optim.py).
+ */
+int lvg_adam_step(float* p, const float* g, float* m, float* v, float* p_ema, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int64_t step, float ema_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

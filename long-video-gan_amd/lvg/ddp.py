@@ -61,12 +61,14 @@ class FlatGradSync:
         assert self.params, 'no parameters'
         dev, dtype = self.params[0].device, self.params[0].dtype
         sizes = [p.numel() for p in self.params]
-        self.flat = torch.zeros(sum(sizes), device=dev, dtype=dtype)
-        # Buckets follow REVERSE parameter order (roughly the order gradients become ready).
+        # every slice starts on a 16-byte boundary (4 floats): the same layout as lvg.optim.flatten_parameters, so the fused
+        # optimizer kernel can treat a run of parameters and the matching run of gradients as two flat ranges
         offs, o = [], 0
         for n in sizes:
             offs.append(o)
-            o += n
+            o += (n + 3) // 4 * 4
+        self.flat = torch.zeros(o, device=dev, dtype=dtype)
+        # Buckets follow REVERSE parameter order (roughly the order gradients become ready).
         self.views = [self.flat[o:o + n].view_as(p) for p, o, n in zip(self.params, offs, sizes)]
         self.buckets = []   # (start, end, [param indices])
         end, members, count = len(self.flat), [], 0

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ddp
+from .optim import FlatAdam
 from .augment import diff_augment, temporal_scale_augment
 from .models import lres as lres_models
 from .models.lres import VideoDiscriminator, VideoGenerator
@@ -35,8 +36,12 @@ class LowResTrainer:
         for net in (self.G, self.D):
             ddp.broadcast_module(net, src=0)
         self.G_ema = copy.deepcopy(self.G).eval() if with_ema else None
-        self.G_opt = torch.optim.Adam(self.G.parameters(), lr=G_lrate, betas=(0.0, G_beta2))
-        self.D_opt = torch.optim.Adam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
+        # One flat buffer per network for parameters, moments (FlatAdam) and gradients (FlatGradSync, same slice layout): an
+        # optimizer step is one streaming launch, with the generator EMA of the parameters folded in (update_G_ema keeps the buffers).
+        self.G_opt = FlatAdam(self.G.parameters(), lr=G_lrate, betas=(0.0, G_beta2),
+                              ema_params=self.G_ema.parameters() if self.G_ema is not None else None)
+        self.D_opt = FlatAdam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
+        self._step = 0
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
         self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
 
@@ -55,7 +60,13 @@ class LowResTrainer:
         return self.D(video, dtype=self.dtype)
 
     # ------------------------------------------------------------------------------------------
-    def update_G(self, batch: int) -> None:
+    def _ema_beta(self, step: int) -> float:
+        halflife = math.log(self.G_ema_beta, 0.5) * (self.G_ema_warmup_steps + 1) / (step + 1)
+        return min(0.5 ** halflife, self.G_ema_beta)
+
+    def update_G(self, batch: int, ema_step: Optional[int] = None) -> None:
+        """`ema_step`: fold this iteration's generator-EMA update of the PARAMETERS into the optimizer pass (they do not
+        change again before `update_G_ema(ema_step)`, which then only has the buffers left)."""
         assert batch % self.G_grad_accum == 0
         self.G.requires_grad_(True)
         self.G_sync.zero()
@@ -66,7 +77,9 @@ class LowResTrainer:
             F.softplus(-logits).mean().backward()
         self.G.requires_grad_(False)
         self.G_sync.finish(gain=1 / self.G_grad_accum)
-        self.G_opt.step()
+        fuse = ema_step is not None and self.G_ema is not None
+        self.G_opt.step(ema_weight=(1.0 - self._ema_beta(ema_step)) if fuse else None)
+        self._ema_fused_for = ema_step if fuse else None
 
     def update_D(self, real_video: torch.Tensor) -> None:
         assert real_video.size(0) % self.D_grad_accum == 0
@@ -105,15 +118,16 @@ class LowResTrainer:
     def update_G_ema(self, step: int) -> None:
         if self.G_ema is None:
             return
-        halflife = math.log(self.G_ema_beta, 0.5) * (self.G_ema_warmup_steps + 1) / (step + 1)
-        beta = min(0.5 ** halflife, self.G_ema_beta)
-        src = list(self.G.parameters()) + list(self.G.buffers())
-        dst = list(self.G_ema.parameters()) + list(self.G_ema.buffers())
+        beta = self._ema_beta(step)
+        src, dst = list(self.G.buffers()), list(self.G_ema.buffers())
+        if getattr(self, '_ema_fused_for', None) != step:                 # parameters not already done inside update_G
+            src, dst = list(self.G.parameters()) + src, list(self.G_ema.parameters()) + dst
+        self._ema_fused_for = None
         torch._foreach_lerp_(dst, src, 1.0 - beta)
 
     def train_step(self, step: int, real_video: torch.Tensor, r1_interval: int = 16) -> None:
         """One iteration of the reference loop (train_lres.py:216-230)."""
-        self.update_G(real_video.size(0))
+        self.update_G(real_video.size(0), ema_step=step)
         self.update_D(real_video)
         if r1_interval > 0 and step % r1_interval == 0:
             self.update_r1(real_video, gain=r1_interval)

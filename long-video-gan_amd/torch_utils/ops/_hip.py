@@ -32,6 +32,7 @@ _SIGNATURES = {
     'lvg_tapconv_epilogue': [_vp] * 8 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_modconv2d_nchw_to_nhwc': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nhwc_to_nchw': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
+    'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
     'lvg_tapconv_epilogue_backward': [_vp] * 10 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
 }
 

@@ -24,7 +24,7 @@ def test_train_step_runs_and_updates_parameters():
     ema_mag = [b for n, b in tr.G.named_buffers() if n.endswith('magnitude_ema')]
     assert any(float(b) != 1.0 for b in ema_mag)                  # update_D ran G with beta = 0.999
     # gradients live in the persistent flat buffers
-    assert tr.G_sync.flat.numel() == sum(p.numel() for p in tr.G.parameters())
+    assert tr.G_sync.flat.numel() >= sum(p.numel() for p in tr.G.parameters())      # (slices are padded to 16-byte boundaries)
 
 
 def test_update_r1_gradients_match_reference_golden():
