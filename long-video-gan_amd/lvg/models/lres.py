@@ -350,6 +350,11 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
 # Measured on MI355X (bench.py, batch 8): 78.0 -> 75.3 ms/step (13.2k -> 13.6k frames/s); parity-green on CPU
 # and GPU. On by default since round 2 (LVG_TAP_STACK=0 restores the kt-convolution form).
 TAP_STACK = os.environ.get('LVG_TAP_STACK', '1') == '1'
+# The style / demodulation / weight-normalisation chains of all generator layers depend only on the latents, not on
+# the activations: issue them on a second HIP stream (forked after the latents, joined per layer by an event) so their
+# ~1500 sub-10-us launches -- forward and, since autograd replays a node on its forward stream, backward -- run beside
+# the convolutions instead of between them. Inside a captured hipGraph this becomes a parallel branch.
+SIDE_STREAM_TERMS = os.environ.get('LVG_SIDE_STREAM_TERMS', '1') == '1'
 
 
 SECOND_ORDER = False      # True inside `second_order()`: layers must build a graph that can be differentiated twice
@@ -669,9 +674,19 @@ class Synthesis3dResBlock(nn.Module):
         return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
 
 
+    def frame_terms(self, latent: torch.Tensor, dtype: torch.dtype):
+        """Everything `forward_frames` needs that depends on the latent only: (weight, modulation, demodulation) of both
+        convolutions, weights already in the compute dtype."""
+        n, c, t = latent.shape
+        lat = latent.permute(2, 0, 1).reshape(t * n, c)                         # rows ordered (t n), like the frames
+        w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True)
+        w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True)
+        return w0.to(dtype), mod_0, demod_0, w1.to(dtype), mod_1, demod_1
+
     def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
-                       out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """Same layer in time-major frames layout: x [(T N), C, H, W], latent [N, L, T].
+                       out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None, terms=None) -> torch.Tensor:
+        """Same layer in time-major frames layout: x [(T N), C, H, W], latent [N, L, T]; `terms` = `frame_terms(latent,
+        dtype)` when the caller computed them ahead (on another stream).
 
         Elementwise passes over the activations are the HBM-bound part of the block, so scalars are folded
         into small tensors instead of being applied to the activations: the input-magnitude gain goes into
@@ -679,12 +694,10 @@ class Synthesis3dResBlock(nn.Module):
         weights and the demodulation of conv 1, and (skip + conv1 * demod) is one addcmul."""
         if dtype is None:
             dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
-        n, c, t = latent.shape
-        lat = latent.permute(2, 0, 1).reshape(t * n, c)                         # rows ordered (t n), like the frames
+        n = latent.shape[0]
         x = x.to(dtype)
         track = self.magnitude_ema and magnitude_ema_beta != 1
-        w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True)
-        w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True)
+        w0, mod_0, demod_0, w1, mod_1, demod_1 = terms if terms is not None else self.frame_terms(latent, dtype)
 
         # conv 0: modulate (one pass, which also measures E[x^2]) -> conv -> fused epilogue
         xm = modconv_epilogue(x, post=mod_0, want_msq=track)
@@ -693,7 +706,7 @@ class Synthesis3dResBlock(nn.Module):
             gain_0 = self.input_magnitude_ema_0.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_0(x)
         xm = xm[0] if track else xm
         # conv 0 and its epilogue: demodulation * input gain, bias, activation, clamp AND the modulation of conv 1
-        hm = temporal_conv_epilogue(xm, w0.to(dtype), n, self.padding[1:], pre=(demod_0 if gain_0 is None else demod_0 * gain_0),
+        hm = temporal_conv_epilogue(xm, w0, n, self.padding[1:], pre=(demod_0 if gain_0 is None else demod_0 * gain_0),
                                     b=self.bias_0.to(dtype), post=mod_1, act=self.activation, clamp=self.activation_clamp, want_msq=track)
         gain_1 = None
         if self.magnitude_ema:
@@ -706,7 +719,7 @@ class Synthesis3dResBlock(nn.Module):
         skip = pointwise_conv(x, w_skip.to(dtype))
         # conv 1: h = skip + conv * (demodulation * gain * sqrt(1/2)), one pass
         scale_1 = demod_1 * SQRT_HALF if gain_1 is None else demod_1 * (gain_1 * SQRT_HALF)
-        h = temporal_conv_epilogue(hm, w1.to(dtype), n, self.padding[1:], pre=scale_1, res=skip)
+        h = temporal_conv_epilogue(hm, w1, n, self.padding[1:], pre=scale_1, res=skip)
         if self.temporal_up:
             h = resample_time_frames(h, self.temporal_upsample.filter, n, up=self.temporal_upsample.scale)
         h = crop_frames(h, n, seq_length=out_seq_length)
@@ -738,14 +751,20 @@ class ToRGB(nn.Module):
         y = modulated_conv3d(x, self.weight, style, gain, (0, 0, 0), False, dtype)
         return bias_act.bias_act(y, self.bias.to(dtype), act='linear', clamp=self.activation_clamp)
 
-    def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        if dtype is None:
-            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+    def frame_terms(self, latent: torch.Tensor, dtype: torch.dtype):
         n, c, t = latent.shape
         style = self.affine(latent.permute(2, 0, 1).reshape(t * n, c)).reshape(t, n, -1)
+        weight, mod, _ = modulation_terms(self.weight, style, False)
+        return weight, mod
+
+    def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None,
+                       terms=None) -> torch.Tensor:
+        if dtype is None:
+            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+        n = latent.shape[0]
         x = x.to(dtype)
         track = self.magnitude_ema and magnitude_ema_beta != 1
-        weight, mod, _ = modulation_terms(self.weight, style, False)
+        weight, mod = terms if terms is not None else self.frame_terms(latent, dtype)
         xm = modconv_epilogue(x, post=mod, want_msq=track)
         if self.magnitude_ema:                                                  # scalar gain folded into the 3 x Ci weight
             gain = self.input_magnitude_ema.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema(x)
@@ -845,22 +864,47 @@ class VideoGenerator(nn.Module):
         x = (temporal_input.permute(2, 0, 1)[:, :, :, None, None] + self.spatial_input[0, :, 0]) * SQRT_HALF
         x = _cl(x.reshape(in_len * n, 512, x.shape[3], x.shape[4]))
         feats = []
-        wi = 0
-        for layer, length in zip(self.temporal_layers, lengths):
-            x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, length, dtype=dtype)
-            if return_features:
+        layers = list(self.temporal_layers) + list(self.spatial_layers) + [self.to_rgb]
+        lengths = list(lengths) + [None] * (len(layers) - len(lengths))
+        terms = self._terms_ahead(layers, latent_ws, x, dtype)
+        for wi, (layer, length) in enumerate(zip(layers, lengths)):
+            extra = {} if layer is self.to_rgb else {'out_seq_length': length}
+            x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype, terms=terms(wi), **extra)
+            if return_features and layer is not self.to_rgb:
                 feats.append(video_from_frames(x, n))
-            wi += 1
-        for layer in self.spatial_layers:
-            x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
-            if return_features:
-                feats.append(video_from_frames(x, n))
-            wi += 1
-        rgb = self.to_rgb.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype)
+        rgb = x
         video = video_from_frames(rgb.float() * self.output_scale, n).contiguous()
         if return_features:
             return feats + [video]
         return video
+
+    def _terms_ahead(self, layers, latent_ws, x: torch.Tensor, dtype: Optional[torch.dtype]):
+        """Issue every layer's `frame_terms` on a side stream (SIDE_STREAM_TERMS); returns `get(i)`, which makes the current
+        stream wait for layer i's terms and hands them over (None: the layer computes them itself)."""
+        if not (SIDE_STREAM_TERMS and x.is_cuda):
+            return lambda i: None
+        main = torch.cuda.current_stream(x.device)
+        side = getattr(self, '_terms_stream', None)
+        if side is None or side.device != x.device:
+            side = self._terms_stream = torch.cuda.Stream(x.device)
+        side.wait_stream(main)
+        ready = []
+        with torch.cuda.stream(side):
+            for layer, latent in zip(layers, latent_ws):
+                use16 = getattr(layer, 'use_float16', False)
+                layer_dtype = dtype if dtype is not None else (torch.float16 if use16 else torch.float32)
+                out = layer.frame_terms(latent, layer_dtype)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ready.append((out, ev))
+
+        def get(i):
+            out, ev = ready[i]
+            main.wait_event(ev)
+            for tensor in out:
+                tensor.record_stream(main)
+            return out
+        return get
 
     def _temporal_input(self, latent_ws: List[torch.Tensor]) -> torch.Tensor:
         w0 = latent_ws.pop(0)
