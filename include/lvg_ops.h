@@ -10,6 +10,9 @@
  *   lvg_filtered_lrelu      <- filtered_lrelu()      torch_utils/ops/filtered_lrelu.cpp:16
  *   lvg_filtered_lrelu_act  <- filtered_lrelu_act_() torch_utils/ops/filtered_lrelu.cpp:213
  *   lvg_tapconv_epilogue[_backward]  (same, with the temporal-tap sum of a tap-stacked convolution)
+ *   lvg_conv3d_frames       (the dense contraction itself + the two epilogues above: F.conv3d of
+ *                           temporal_modulated_conv3d, model/generator_lres.py:119, which the reference
+ *                           hands to cuDNN)
  *   lvg_modconv_epilogue[_backward]  (no pybind counterpart: fuses the modulated-conv epilogue the
  *                           reference spells in Python, model/generator_lres.py:101-123,570-574)
  *
@@ -174,6 +177,27 @@ int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const v
                          void* out, void* ysum, float* msq,
                          int64_t frames, int channels, int pixels, int taps, int64_t tap_shift,
                          int dtype, int act, float alpha, float gain, float clamp, void* stream);
+
+/*
+ * Implicit-GEMM convolution on the matrix cores with the temporal-tap sum and the epilogue above fused on
+ * store (16-bit channels-last frames; csrc/conv3d_igemm.hip). Replaces F.conv3d of the reference's
+ * temporal_modulated_conv3d (model/generator_lres.py:119, padding = k // 2: :544-548) together with
+ * lvg_tapconv_epilogue / lvg_modconv_epilogue:
+ *   x [frames, H, W, ci]; w [kt, kh, kw, co, ci] (tap-major, input channel fastest)
+ *   acc[f,h,v,o] = sum_{dt,dh,dw,c} x[f + (dt-kt/2)*frame_shift, h+dh-kh/2, v+dw-kw/2, c] * w[dt,dh,dw,o,c]   (zero outside)
+ *   out = clamp(act(acc * pre[f,o] + b[o] + res[f,h,v,o]) * gain, +-clamp) * post[f,o];  ysum = acc (may be NULL)
+ *   msq_partial[i] = sum over workgroup i of (value before post)^2, i < lvg_conv3d_frames_workgroups(...)
+ *                    (fixed summation order: reproducible; the caller adds them up; may be NULL)
+ * Returns LVG_ERR_UNSUPPORTED when no kernel exists for the shape (ci % 64, co % 64, <= 32 taps, odd kernel
+ * sizes, frames*h*w < 2^31): the caller then takes the library convolution + lvg_tapconv_epilogue.
+ */
+int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
+                      void* out, void* ysum, float* msq_partial,
+                      int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
+                      int dtype, int act, float alpha, float gain, float clamp, void* stream);
+
+/* Workgroups lvg_conv3d_frames launches for this shape (= length of msq_partial); 0 = unsupported shape. */
+int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw);
 
 /*
  * Backward of lvg_tapconv_epilogue from dout and the saved ysum; the gradient is written already scattered

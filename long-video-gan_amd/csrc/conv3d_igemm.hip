@@ -1,0 +1,496 @@
+// conv3d_igemm.hip -- the dense contraction of the modulated convolutions as a hand-written implicit GEMM
+// on the gfx950 matrix cores, with the temporal-tap sum and the modulated-conv epilogue fused on store.
+//
+// Replaces, for 16-bit channels-last frames, the pair (MIOpen igemm convolution over tap-stacked output
+// channels -> tapconv_epilogue / modconv_epilogue kernel) of the reference's `temporal_modulated_conv3d`
+// (model/generator_lres.py:83-125) and its bias_act (:570): the convolution output never makes a round trip
+// through HBM before the epilogue, and the kt temporal taps are part of the K loop instead of kt x the output.
+//
+//   x   [M = frames*H*W][Ci]            time-major channels-last frames (frame f = t * clips + n)
+//   w   [kt][kh][kw][Co][Ci]            tap-major, input channel fastest
+//   acc[m][co] = sum_{dt,dh,dw,ci} x[m + (dt-kt/2)*tShift + (dh-kh/2)*W + (dw-kw/2)][ci] * w[dt][dh][dw][co][ci]
+//               (terms whose source pixel leaves the frame -- rows, columns or time -- are zero: 'same' padding)
+//   out[m][co] = clamp(act(acc * pre[f][co] + b[co] + res[m][co]) * gain) * post[f][co]      ysum = acc (saved)
+//
+// GEMM view: D[co][pixel] = W[co][k] * X[k][pixel], k = (dt, dh, dw, ci). One workgroup (4 waves) owns 128
+// consecutive pixels x BN output channels; a wave owns 64 pixels x BN/2 channels as 2 x (BN/64) MFMA blocks
+// (v_mfma_f32_32x32x16, weights = A operand, pixels = B operand: a lane of the result holds ONE pixel and 4
+// consecutive output channels per register quad -> 8-byte channels-last stores).
+//
+// What makes it implicit: in channels-last memory the pixels a 128-pixel tile needs for ALL kh x kw spatial taps
+// are one contiguous band of 128 + 2 * (kh/2 * W + kw/2) pixel rows (a tap is a constant shift of the flattened
+// pixel index; what wraps around a row / frame edge is masked at fragment-read time). The band of one
+// (temporal tap, 64-channel chunk) is brought into LDS ONCE and feeds kh*kw K-steps; only the weight tile
+// (BN x 64) is loaded per K-step. Staging is LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no
+// ds_write pass): the LDS image is lane-linear, so the bank swizzle (16-byte chunk c of row r lives at chunk
+// c ^ ((r >> 1) & 7): conflict-free `ds_read_b128` for any tap shift, since the 16-lane read groups cover 16
+// rows that are distinct modulo 16) is applied to the per-lane SOURCE address. Weight tiles are double-buffered
+// per K-step, bands per (temporal tap, chunk), their loads spread over the taps of the previous band.
+//
+// A register-staged variant of the same schedule (global_load_dwordx4 -> ds_write_b128) is kept behind
+// LVG_CONV_STAGE=reg for A/B measurements.
+
+#include "epilogue_common.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+struct ConvArgs
+{
+    const void*  x;
+    const void*  w;
+    const float* pre;
+    const void*  b;
+    const void*  res;
+    const float* post;
+    void*        out;
+    void*        ysum;
+    float*       msqPartial;   // one float per workgroup (sum of squares of the value before `post`), or NULL
+    int64_t      M;            // frames * H * W
+    int64_t      tShift;       // pixels between consecutive time steps (= clips * H * W)
+    int          H, W, Ci, Co, kt, kh, kw;
+    int          reach;        // (kh/2) * W + kw/2: pixels of halo on each side of a tile
+    int          bandRows;     // 128 + 2 * reach, rounded up to a multiple of 8
+    int          nABuf;        // 2 when there is more than one band per tile
+    int          nTiles;       // Co / BN
+    float        slopeNeg;     // activation as max-free form: u > 0 ? u : u * slopeNeg (linear 1, relu 0, lrelu alpha)
+    float        gain, clamp;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <class T> struct Mma;
+template <> struct Mma<bf16_t>
+{
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, const f32x16& c)
+    {
+        bf16x8 av, bv;
+        __builtin_memcpy(&av, &a, 16);
+        __builtin_memcpy(&bv, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t>
+{
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, const f32x16& c)
+    {
+        f16x8 av, bv;
+        __builtin_memcpy(&av, &a, 16);
+        __builtin_memcpy(&bv, &b, 16);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+    }
+};
+
+constexpr int kBM = 128;      // pixels per workgroup
+constexpr int kBK = 64;       // input channels per K-step (one 128-byte LDS row)
+constexpr int kRowBytes = kBK * 2;
+
+// One 1-KiB piece (8 LDS rows x 128 B) per wave instruction: lane -> (row in piece, physical chunk).
+// Returns the LOGICAL 16-byte chunk this lane must fetch so that the lane-linear LDS image is the swizzled one.
+__device__ __forceinline__ int piece_chunk(int piece, int lane)
+{
+    const int row = piece * 8 + (lane >> 3);
+    return (lane & 7) ^ ((row >> 1) & 7);
+}
+
+// LDS-DMA of 16 bytes per lane: LDS address = ldsPiece (wave-uniform, via M0) + lane * 16. Issued as inline assembly
+// on purpose: hipcc orders every later ds_read behind a `__builtin_amdgcn_global_load_lds` it has seen (s_waitcnt
+// vmcnt(0) before the first fragment read of the K-step, i.e. no overlap of the prefetch with the MFMAs of the
+// same wave); an asm statement is outside its bookkeeping, the kernel waits (vmcnt) itself before the barrier
+// that publishes the tile.
+template <bool GLDS>
+__device__ __forceinline__ void stage16(const unsigned char* src, uint32_t ldsPiece, uint4& reg)
+{
+    if (GLDS)
+    {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(ldsPiece) : "memory");
+    }
+    else
+        reg = *reinterpret_cast<const uint4*>(src);
+}
+
+template <class T, int BN, bool GLDS>
+__global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NCB = BN / 64;                 // 32-channel MFMA blocks per wave
+    constexpr int NBI = BN / 32;                 // weight pieces per wave and K-step
+    constexpr int MAXAI = 4;                     // band pieces per wave and K-step (host guarantees)
+    constexpr int bBytes = BN * kRowBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware tile order: the dispatcher puts workgroup b on XCD b % 8; give every XCD a contiguous range of
+    // tiles (channel tile fastest), so that the workgroups sharing an L2 share bands and walk the weights together.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+    const int mt = tile / p.nTiles, nt = tile - mt * p.nTiles;
+    const int64_t m0 = (int64_t)mt * kBM;
+    const int co0 = nt * BN;
+
+    const int aBytes = p.bandRows * kRowBytes;
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)smem;                 // generic -> LDS byte address (low 32 bits)
+    const int aOff = 0, bOff = p.nABuf * aBytes;
+
+    const int ntap = p.kh * p.kw;
+    const int nchunk = p.Ci / kBK;
+    const int nMacro = p.kt * nchunk;
+    const int nSteps = nMacro * ntap;
+    const int nAI = p.bandRows >> 3;                                   // band pieces in total
+    const int aPerStep = (nAI + 4 * ntap - 1) / (4 * ntap);           // per wave and K-step (<= MAXAI)
+    const int pt = p.kt >> 1;
+
+    const unsigned char* const xb = static_cast<const unsigned char*>(p.x);
+    const unsigned char* const wb = static_cast<const unsigned char*>(p.w);
+    const int64_t rowStrideX = (int64_t)p.Ci * 2;
+
+    // ---- staging -----------------------------------------------------------------------------------------------
+    // Per lane and piece the source offset inside a tile is fixed: (row in tile) * row stride + swizzled chunk.
+    uint4 regB[NBI], regA[MAXAI];
+    int bLaneOff[NBI];
+    #pragma unroll
+    for (int i = 0; i < NBI; i++)
+    {
+        const int piece = wave * NBI + i;
+        bLaneOff[i] = (piece * 8 + (lane >> 3)) * (int)rowStrideX + piece_chunk(piece, lane) * 16;
+    }
+    // weight tile of (temporal tap dt, chunk kc, spatial tap) -> LDS buffer `buf`
+    auto issueB = [&](int dt, int kc, int tap, int buf)
+    {
+        const unsigned char* base = wb + ((int64_t)(dt * ntap + tap) * p.Co + co0) * rowStrideX + kc * kRowBytes;
+        #pragma unroll
+        for (int i = 0; i < NBI; i++)
+            stage16<GLDS>(base + bLaneOff[i], ldsBase + bOff + buf * bBytes + (wave * NBI + i) * 1024, regB[i]);
+    };
+    // band pieces of (dt, kc) that this wave brings in during K-step `tapSlot` of the previous band
+    auto issueA = [&](int dt, int kc, int tapSlot, int buf)
+    {
+        const int64_t g0 = m0 - p.reach + (int64_t)(dt - pt) * p.tShift;
+        #pragma unroll
+        for (int i = 0; i < MAXAI; i++)
+        {
+            const int piece = (tapSlot * aPerStep + i) * 4 + wave;
+            if (i < aPerStep && piece < nAI)
+            {
+                int64_t g = g0 + piece * 8 + (lane >> 3);
+                g = g < 0 ? 0 : (g >= p.M ? p.M - 1 : g);            // clamped rows are only ever read masked
+                const unsigned char* src = xb + g * rowStrideX + kc * kRowBytes + piece_chunk(piece, lane) * 16;
+                stage16<GLDS>(src, ldsBase + aOff + buf * aBytes + piece * 1024, regA[i]);
+            }
+        }
+    };
+    auto commitB = [&](int buf)
+    {
+        if (!GLDS)
+        {
+            #pragma unroll
+            for (int i = 0; i < NBI; i++)
+                *reinterpret_cast<uint4*>(smem + bOff + buf * bBytes + (wave * NBI + i) * 1024 + lane * 16) = regB[i];
+        }
+    };
+    auto commitA = [&](int tapSlot, int buf)
+    {
+        if (!GLDS)
+        {
+            #pragma unroll
+            for (int i = 0; i < MAXAI; i++)
+            {
+                const int piece = (tapSlot * aPerStep + i) * 4 + wave;
+                if (i < aPerStep && piece < nAI)
+                    *reinterpret_cast<uint4*>(smem + aOff + buf * aBytes + piece * 1024 + lane * 16) = regA[i];
+            }
+        }
+    };
+
+    // ---- which (temporal tap, spatial tap) pairs read a real pixel, per lane and pixel block -------------------
+    uint32_t vmask[2];
+    int jrow[2];
+    #pragma unroll
+    for (int pb = 0; pb < 2; pb++)
+    {
+        const int j = wr * 64 + pb * 32 + l31;
+        jrow[pb] = j;
+        const int64_t m = m0 + j;
+        uint32_t mask = 0;
+        if (m < p.M)
+        {
+            const uint32_t row = (uint32_t)m / (uint32_t)p.W;         // M < 2^31 (host check)
+            const int ww = (int)((uint32_t)m - row * (uint32_t)p.W);
+            const int hh = (int)(row % (uint32_t)p.H);
+            uint32_t sp = 0;
+            for (int dh = 0; dh < p.kh; dh++)
+                for (int dw = 0; dw < p.kw; dw++)
+                {
+                    const int y = hh + dh - (p.kh >> 1), x = ww + dw - (p.kw >> 1);
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W) sp |= 1u << (dh * p.kw + dw);
+                }
+            for (int dt = 0; dt < p.kt; dt++)
+            {
+                const int64_t ms = m + (int64_t)(dt - pt) * p.tShift;
+                if (ms >= 0 && ms < p.M) mask |= sp << (dt * ntap);
+            }
+        }
+        vmask[pb] = mask;
+    }
+
+    f32x16 acc[NCB][2];
+    #pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+        #pragma unroll
+        for (int pb = 0; pb < 2; pb++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[cb][pb][r] = 0.f;
+
+    // LDS offsets of the weight fragments (fixed): row = wc * BN/2 + cb * 32 + l31
+    int wRowOff[NCB], wKey[NCB];
+    #pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+    {
+        const int row = wc * (BN / 2) + cb * 32 + l31;
+        wRowOff[cb] = row * kRowBytes;
+        wKey[cb] = (row >> 1) & 7;
+    }
+
+    // ---- prologue: first band, first weight tile ----------------------------------------------------------------
+    for (int t = 0; t < ntap; t++)
+    {
+        issueA(0, 0, t, 0);
+        commitA(t, 0);
+    }
+    issueB(0, 0, 0, 0);
+    commitB(0);
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- K loop: (dt, kc) = band, (dh, dw) = spatial tap inside it; n* = the same counters one K-step ahead ------
+    int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
+    int ndt = 0, nkc = 0, ntp = 0;
+    for (int step = 0; step < nSteps; step++)
+    {
+        if (++ntp == ntap) { ntp = 0; if (++nkc == nchunk) { nkc = 0; ndt++; } }
+        const bool moreB = step + 1 < nSteps;
+        const bool moreA = macro + 1 < nMacro;
+        const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;               // the band after this one
+        const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
+        if (moreB) issueB(ndt, nkc, ntp, (step + 1) & 1);
+        if (moreA) issueA(mdt, mkc, tap, (macro + 1) & 1);
+
+        const unsigned char* aBuf = smem + aOff + (macro & 1) * aBytes;   // nABuf == 1 only when there is one band
+        const unsigned char* bBuf = smem + bOff + (step & 1) * bBytes;
+        const int shift = dh * p.W + dw;
+        const int bit = dt * ntap + tap;
+        int xRowOff[2], xKey[2];
+        uint32_t sel[2];
+        #pragma unroll
+        for (int pb = 0; pb < 2; pb++)
+        {
+            const int rb = jrow[pb] + shift;
+            xRowOff[pb] = rb * kRowBytes;
+            xKey[pb] = (rb >> 1) & 7;
+            sel[pb] = ((vmask[pb] >> bit) & 1u) ? 0xffffffffu : 0u;
+        }
+        #pragma unroll
+        for (int ks = 0; ks < kBK / 16; ks++)
+        {
+            const int c = 2 * ks + hi;
+            uint4 wf[NCB], xf[2];
+            #pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                wf[cb] = *reinterpret_cast<const uint4*>(bBuf + wRowOff[cb] + ((c ^ wKey[cb]) << 4));
+            #pragma unroll
+            for (int pb = 0; pb < 2; pb++)
+            {
+                xf[pb] = *reinterpret_cast<const uint4*>(aBuf + xRowOff[pb] + ((c ^ xKey[pb]) << 4));
+                xf[pb].x &= sel[pb]; xf[pb].y &= sel[pb]; xf[pb].z &= sel[pb]; xf[pb].w &= sel[pb];
+            }
+            #pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                #pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+                    acc[cb][pb] = Mma<T>::run(wf[cb], xf[pb], acc[cb][pb]);
+        }
+
+        if (moreB) commitB((step + 1) & 1);
+        if (moreA) commitA(tap, (macro + 1) & 1);
+        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (++dw == p.kw) { dw = 0; dh++; }
+        if (++tap == ntap) { tap = 0; dh = 0; dw = 0; macro++; kc = mkc; dt = mdt; }
+    }
+
+    // ---- epilogue: registers -> out / ysum (8-byte channels-last stores), per-workgroup sum of squares ----------
+    const T* bias = static_cast<const T*>(p.b);
+    const T* res  = static_cast<const T*>(p.res);
+    T* out  = static_cast<T*>(p.out);
+    T* ysum = static_cast<T*>(p.ysum);
+    const uint32_t hw = (uint32_t)(p.H * p.W);
+    float sq = 0.f;
+    #pragma unroll
+    for (int pb = 0; pb < 2; pb++)
+    {
+        const int64_t m = m0 + jrow[pb];
+        if (m >= p.M) continue;
+        const int64_t f = (uint32_t)m / hw;
+        #pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+            #pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+            {
+                const int co = co0 + wc * (BN / 2) + cb * 32 + 8 * qd + 4 * hi;
+                float pre4[4] = {1.f, 1.f, 1.f, 1.f}, post4[4] = {1.f, 1.f, 1.f, 1.f}, add4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.pre)  { const float4 v = *reinterpret_cast<const float4*>(p.pre + f * p.Co + co);  pre4[0] = v.x; pre4[1] = v.y; pre4[2] = v.z; pre4[3] = v.w; }
+                if (p.post) { const float4 v = *reinterpret_cast<const float4*>(p.post + f * p.Co + co); post4[0] = v.x; post4[1] = v.y; post4[2] = v.z; post4[3] = v.w; }
+                if (bias)
+                {
+                    uint2 raw = *reinterpret_cast<const uint2*>(bias + co);
+                    T t4[4];
+                    __builtin_memcpy(t4, &raw, 8);
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
+                }
+                if (res)
+                {
+                    uint2 raw = *reinterpret_cast<const uint2*>(res + m * p.Co + co);
+                    T t4[4];
+                    __builtin_memcpy(t4, &raw, 8);
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
+                }
+                T o4[4], y4[4];
+                #pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    const float a = acc[cb][pb][qd * 4 + e];
+                    const float u = fmaf(a, pre4[e], add4[e]);
+                    float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
+                    if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
+                    sq = fmaf(g, g, sq);
+                    o4[e] = from_acc<T>(g * post4[e]);
+                    y4[e] = from_acc<T>(a);
+                }
+                uint2 ov, yv;
+                __builtin_memcpy(&ov, o4, 8);
+                __builtin_memcpy(&yv, y4, 8);
+                *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
+                if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
+            }
+    }
+    if (p.msqPartial)
+    {
+        sq = wave_sum(sq);
+        float* red = reinterpret_cast<float*>(smem);        // the K loop ended with a barrier: LDS is free
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) p.msqPartial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+struct Plan
+{
+    int bn, bandRows, nABuf, ldsBytes;
+    int64_t mTiles;
+};
+
+// Tile choice: 128 output channels per workgroup when two workgroups still fit the 160 KiB of a CU, else 64.
+int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl)
+{
+    const int reach = (kh / 2) * W + kw / 2;
+    pl.bandRows = (int)lvg_ceil_div(kBM + 2 * reach, 8) * 8;
+    pl.nABuf = (kt * (Ci / kBK) > 1) ? 2 : 1;
+    pl.mTiles = lvg_ceil_div(M, kBM);
+    const int aBytes = pl.nABuf * pl.bandRows * kRowBytes;
+    const char* force = getenv("LVG_CONV_BN");
+    int bn = (Co % 128 == 0 && aBytes + 2 * 128 * kRowBytes <= 80 * 1024) ? 128 : 64;
+    if (force && atoi(force) == 64) bn = 64;
+    if (force && atoi(force) == 128 && Co % 128 == 0) bn = 128;
+    pl.bn = bn;
+    pl.ldsBytes = aBytes + 2 * bn * kRowBytes;
+    if (pl.ldsBytes > 160 * 1024) return -1;
+    return 0;
+}
+
+template <class T, int BN, bool GLDS>
+int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
+{
+    auto kern = conv3d_igemm_kernel<T, BN, GLDS>;
+    if (pl.ldsBytes > 64 * 1024)
+    {
+        // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            lvg_set_error("conv3d_frames: cannot opt in to %d bytes of LDS", pl.ldsBytes);
+            return LVG_ERR_LAUNCH;
+        }
+    }
+    const int64_t blocks = pl.mTiles * a.nTiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), pl.ldsBytes, stream, a);
+    return lvg_check_launch("conv3d_frames");
+}
+
+} // namespace
+
+extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
+{
+    Plan pl;
+    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0) return 0;
+    if (make_plan(frames * h * w, w, ci, co, kt, kh, kw, pl) != 0) return 0;
+    return pl.mTiles * (co / pl.bn);
+}
+
+extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
+                                 void* out, void* ysum, float* msq_partial,
+                                 int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
+                                 int dtype, int act, float alpha, float gain, float clamp, void* stream)
+{
+    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv3d_frames: float16 / bfloat16 only (dtype %d)", dtype);
+    LVG_REQUIRE(frames > 0 && h > 0 && wd > 0, "conv3d_frames: empty input");
+    LVG_REQUIRE((kt & 1) && (kh & 1) && (kw & 1) && kt >= 1 && kh >= 1 && kw >= 1, "conv3d_frames: odd kernel sizes only");
+    LVG_REQUIRE(act == LVG_ACT_LINEAR || act == LVG_ACT_RELU || act == LVG_ACT_LRELU, "conv3d_frames: linear / relu / lrelu only");
+    LVG_REQUIRE(lvg_aligned16(x) && lvg_aligned16(w) && lvg_aligned16(out) && lvg_aligned16(ysum) && lvg_aligned16(res)
+                && lvg_aligned16(pre) && lvg_aligned16(post) && lvg_aligned16(b), "conv3d_frames: pointers must be 16-byte aligned");
+    if (ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32 || frames * h * wd >= (int64_t)1 << 31)
+    {
+        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d (Ci %% 64, Co %% 64, <= 32 taps)", ci, co, kt, kh, kw);
+        return LVG_ERR_UNSUPPORTED;
+    }
+    Plan pl;
+    if (make_plan(frames * h * wd, wd, ci, co, kt, kh, kw, pl) != 0 || lvg_ceil_div(pl.bandRows / 8, 4 * kh * kw) > 4)
+    {
+        lvg_set_error("conv3d_frames: frame width %d needs a %d-row band: no kernel", wd, pl.bandRows);
+        return LVG_ERR_UNSUPPORTED;
+    }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.pre = pre; a.b = b; a.res = res; a.post = post;
+    a.out = out; a.ysum = ysum; a.msqPartial = msq_partial;
+    a.M = frames * h * wd;
+    a.tShift = frame_shift * h * wd;
+    a.H = h; a.W = wd; a.Ci = ci; a.Co = co; a.kt = kt; a.kh = kh; a.kw = kw;
+    a.reach = (kh / 2) * wd + kw / 2;
+    a.bandRows = pl.bandRows;
+    a.nABuf = pl.nABuf;
+    a.nTiles = co / pl.bn;
+    a.slopeNeg = act == LVG_ACT_LINEAR ? 1.f : (act == LVG_ACT_RELU ? 0.f : alpha);
+    a.gain = gain;
+    a.clamp = clamp;
+    const char* st = getenv("LVG_CONV_STAGE");
+    const bool glds = !(st && strcmp(st, "reg") == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == LVG_BF16)
+    {
+        if (pl.bn == 128) return glds ? launch<bf16_t, 128, true>(a, pl, s) : launch<bf16_t, 128, false>(a, pl, s);
+        return glds ? launch<bf16_t, 64, true>(a, pl, s) : launch<bf16_t, 64, false>(a, pl, s);
+    }
+    if (pl.bn == 128) return glds ? launch<f16_t, 128, true>(a, pl, s) : launch<f16_t, 128, false>(a, pl, s);
+    return glds ? launch<f16_t, 64, true>(a, pl, s) : launch<f16_t, 64, false>(a, pl, s);
+}

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 import torch_utils.distributed as dist_utils
 import contextlib
 
-from torch_utils.ops import bias_act, upfirdn2d
+from torch_utils.ops import bias_act, conv3d_frames, upfirdn2d
 from torch_utils.ops.modconv_epilogue import modconv_epilogue, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
@@ -357,6 +357,21 @@ TAP_STACK = os.environ.get('LVG_TAP_STACK', '1') == '1'
 SIDE_STREAM_TERMS = os.environ.get('LVG_SIDE_STREAM_TERMS', '1') == '1'
 
 
+# The dense contraction of the generator's 16-bit modulated convolutions on the hand-written implicit-GEMM kernel
+# (csrc/conv3d_igemm.hip: temporal taps inside the K loop, epilogue fused on store) instead of MIOpen's igemm over
+# tap-stacked output channels + the tap-gather epilogue kernel. LVG_HAND_CONV=0 restores the MIOpen route; shapes the
+# kernel does not cover (float32, Ci or Co not a multiple of 64) take it anyway.
+HAND_CONV = os.environ.get('LVG_HAND_CONV', '1') == '1'
+
+
+def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) -> bool:
+    if not (HAND_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)):
+        return False
+    if tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
+        return False
+    return conv3d_frames.supported(_cl(x), weight)
+
+
 SECOND_ORDER = False      # True inside `second_order()`: layers must build a graph that can be differentiated twice
 
 
@@ -399,11 +414,16 @@ class _TapConvEpilogue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, pre, b, res, post, n, padding_hw, act, clamp, want_msq):
         kt = weight.shape[2]
-        wst = _cl(stack_taps(weight))
-        z = _cl(F.conv2d(_cl(x), wst, padding=padding_hw))
         # a bare temporal sum (no scale / bias / activation) IS its own saved sum: nothing extra is written
         plain = pre is None and b is None and res is None and post is None and act == 'linear' and clamp is None
-        out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq, keep_sum=not plain)
+        if _hand_conv_takes(x, weight, padding_hw):
+            # contraction, temporal sum and epilogue in ONE hand-written MFMA kernel (csrc/conv3d_igemm.hip)
+            out, ysum, msq = conv3d_frames.conv3d_frames_forward(_cl(x), weight, n, pre, b, res, post, act=act, clamp=clamp,
+                                                                 want_msq=want_msq, keep_sum=not plain)
+        else:
+            wst = _cl(stack_taps(weight))
+            z = _cl(F.conv2d(_cl(x), wst, padding=padding_hw))
+            out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq, keep_sum=not plain)
         ctx.save_for_backward(x, weight, out if plain else ysum, pre, b, res, post)
         ctx.cfg = (n, list(padding_hw), act, clamp)
         if want_msq:
@@ -436,7 +456,8 @@ def temporal_conv_epilogue(x: torch.Tensor, weight: torch.Tensor, n: int, paddin
     `clamp(act(y * pre + b + res) * gain) * post` (pre / post float32 [(T N), C], res like the output).
     Returns `out` or `(out, mean_square)`. With TAP_STACK the kt taps are one convolution and their sum is
     taken inside the epilogue kernel; otherwise kt convolutions are accumulated and the epilogue runs on the sum."""
-    if TAP_STACK and not SECOND_ORDER and weight.shape[2] > 1 and (res is None or (act == 'linear' and clamp is None and post is None)):
+    fused = weight.shape[2] > 1 or (_hand_conv_takes(x, weight, padding_hw) and tuple(weight.shape[2:]) != (1, 1, 1))
+    if TAP_STACK and not SECOND_ORDER and fused and (res is None or (act == 'linear' and clamp is None and post is None)):
         out, msq = _TapConvEpilogue.apply(x, weight, pre, b, res, post, n, tuple(padding_hw), act, clamp, bool(want_msq))
         return (out, msq) if want_msq else out
     y = temporal_conv_frames(x, weight, n, padding_hw)

@@ -30,6 +30,8 @@ _SIGNATURES = {
     'lvg_modconv_epilogue': [_vp] * 6 + [_i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_modconv_epilogue_backward': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_tapconv_epilogue': [_vp] * 8 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
+    'lvg_conv3d_frames': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
+    'lvg_conv3d_frames_workgroups': [_i64] + [_i32] * 7,
     'lvg_modconv2d_nchw_to_nhwc': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nhwc_to_nchw': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
@@ -48,7 +50,7 @@ def lib():
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_int64 if name == 'lvg_conv3d_frames_workgroups' else ctypes.c_int
         _lib = handle
     return _lib
 

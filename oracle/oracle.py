@@ -219,6 +219,20 @@ def modconv_epilogue(z, pre=None, b=None, res=None, post=None, taps=1, shift=1, 
     return out, ysum, float(msq.value)
 
 
+def conv3d_frames(x, w, shift=1):
+    """conv3d with 'same' zero padding over time-major frames (orc_conv3d_frames).
+    x [frames, Ci, H, W] (frame f = t * shift + n), w [Co, Ci, kt, kh, kw] -> y [frames, Co, H, W]."""
+    x, w = _f64(x), _f64(w)
+    f, ci, h, wd = x.shape
+    co, ci2, kt, kh, kw = w.shape
+    assert ci == ci2
+    y = np.empty((f, co, h, wd), dtype=np.float64)
+    rc = lib().orc_conv3d_frames(_dp(x), _dp(w), _dp(y), ctypes.c_int64(f), ctypes.c_int(ci), ctypes.c_int(co), ctypes.c_int(h),
+                                 ctypes.c_int(wd), ctypes.c_int(kt), ctypes.c_int(kh), ctypes.c_int(kw), ctypes.c_int64(shift))
+    assert rc == 0, rc
+    return y
+
+
 def modconv2d_prologue(x, cond, mod, c_pad):
     """cat(x, cond) * mod with zero channels up to c_pad. x may be None. NCHW in, NCHW out."""
     cond = _f64(cond)

@@ -1,0 +1,213 @@
+"""Hand-written implicit-GEMM convolution with fused temporal taps + epilogue (csrc/conv3d_igemm.hip,
+torch_utils/ops/conv3d_frames.py).
+
+CPU: the oracle's conv3d restatement (+ the modulation algebra) against vectors produced by the REFERENCE's
+`temporal_modulated_conv3d` + bias_act (tests/golden/make_golden_modconv3d.py), and the shipped plain-PyTorch
+definition against the oracle.
+GPU: HIP vs oracle on seeded ragged cases (f16 / bf16; tile seams, frame / clip borders, every epilogue input),
+HIP vs the reference golden, and at BASELINE.json configs[1] sizes the size-independent property
+"a one-hot kernel is a zero-padded shift" (bit-exact) plus agreement with the MIOpen route inside the generator block."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers.modconv3d_inputs import inputs
+from torch_utils.ops import conv3d_frames as cf
+
+
+def _modulation(weight, style, gain):
+    """numpy restatement of generator_lres.py:97-112 -> (scaled weight, modulation [N,Ci,T], demodulation [N,Co,T])."""
+    w = weight / np.abs(weight).max(axis=(1, 2, 3, 4), keepdims=True)
+    s = style / np.abs(style).max(axis=(1, 2), keepdims=True)
+    w = w / math.sqrt(np.prod(w.shape[1:]))
+    demod = 1.0 / np.sqrt(np.einsum('oizyx,nit->not', w ** 2, s ** 2) + 1e-8)
+    return w, s * gain, demod
+
+
+def _frames(v):
+    """[N, C, T, H, W] -> time-major frames [(T N), C, H, W]"""
+    n, c, t, h, w = v.shape
+    return np.ascontiguousarray(v.transpose(2, 0, 1, 3, 4)).reshape(t * n, c, h, w)
+
+
+def _video(fr, n):
+    tn, c, h, w = fr.shape
+    return fr.reshape(tn // n, n, c, h, w).transpose(1, 2, 0, 3, 4)
+
+
+@pytest.mark.parametrize('name', ['k333', 'k133', 'k311'])
+def test_oracle_matches_reference_modulated_conv3d(oracle, name):
+    g = load_golden('modconv3d')
+    x, weight, style, bias, gain = [t.double().numpy() for t in inputs(name)]
+    n = x.shape[0]
+    w, mod, demod = _modulation(weight, style, float(gain))
+    xm = x * mod[:, :, :, None, None]
+    y = oracle.conv3d_frames(_frames(xm), w, shift=n)
+    y = _video(y, n) * demod[:, :, :, None, None]
+    np.testing.assert_allclose(y, g[name + '_conv'], rtol=2e-4, atol=2e-5)
+    z = oracle.bias_act(y, bias, dim=1, act='lrelu', clamp=2.0)
+    np.testing.assert_allclose(z, g[name + '_act'], rtol=2e-4, atol=2e-5)
+
+
+def _case(seed, t, n, ci, co, h, w, kt, kh, kw, dtype, device, with_res=False):
+    g = torch.Generator().manual_seed(seed)
+    f = t * n
+    x = torch.randn(f, ci, h, w, generator=g).to(dtype).to(device).contiguous(memory_format=torch.channels_last)
+    weight = (torch.randn(co, ci, kt, kh, kw, generator=g) / math.sqrt(ci * kt * kh * kw)).to(dtype).to(device)
+    pre = (0.5 + torch.rand(f, co, generator=g)).to(device)
+    post = None if with_res else torch.randn(f, co, generator=g).to(device)
+    b = None if with_res else (0.3 * torch.randn(co, generator=g)).to(dtype).to(device)
+    res = torch.randn(f, co, h, w, generator=g).to(dtype).to(device).contiguous(memory_format=torch.channels_last) if with_res else None
+    return x, weight, pre, b, res, post
+
+
+def _np(t):
+    return None if t is None else t.detach().double().cpu().numpy()
+
+
+def _oracle_all(oracle, x, weight, n, pre, b, res, post, act, clamp):
+    acc = oracle.conv3d_frames(_np(x), _np(weight), shift=n)
+    out, ysum, msq = oracle.modconv_epilogue(acc, _np(pre), _np(b), _np(res), _np(post), taps=1, shift=n, act=act, clamp=clamp)
+    return out, acc, msq
+
+
+@pytest.mark.parametrize('kt,kh,kw,with_res', [(3, 3, 3, False), (1, 3, 3, True), (3, 1, 1, False)])
+def test_plain_definition_matches_oracle_cpu(oracle, kt, kh, kw, with_res):
+    x, weight, pre, b, res, post = _case(1, 4, 2, 8, 16, 3, 5, kt, kh, kw, torch.float32, 'cpu', with_res)
+    act, clamp = ('linear', None) if with_res else ('lrelu', 1.5)
+    out, ysum, msq = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act=act, clamp=clamp, want_msq=True)
+    o_out, o_acc, o_msq = _oracle_all(oracle, x, weight, 2, pre, b, res, post, act, clamp)
+    np.testing.assert_allclose(out.numpy(), o_out, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ysum.numpy(), o_acc, rtol=1e-4, atol=1e-5)
+    assert abs(float(msq) - o_msq) <= 1e-4 * o_msq
+
+
+GPU_CASES = [
+    # t, n, ci, co,  h,  w, kt, kh, kw, with_res     (pixels = t*n*h*w: ragged against the 128-pixel tile on purpose)
+    (5, 2, 64, 64, 6, 7, 3, 3, 3, False),            # several clips per tile row, clip borders inside tiles
+    (3, 2, 64, 128, 5, 9, 1, 3, 3, True),            # spatial only + residual, BN = 128
+    (6, 1, 128, 64, 3, 4, 3, 1, 1, False),           # temporal only, two channel chunks
+    (4, 3, 128, 192, 9, 16, 3, 3, 3, False),         # two chunks x three taps: band double buffering, Co = 3 x 64
+    (2, 2, 64, 64, 18, 32, 1, 3, 3, False),          # W = 32: band of 194 rows
+    (1, 2, 64, 64, 36, 64, 1, 3, 3, True),           # W = 64: band of 258 rows, single band
+    (7, 1, 256, 128, 5, 8, 3, 3, 3, False),          # four chunks
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', GPU_CASES)
+def test_hip_matches_oracle_gpu(oracle, case, dtype):
+    t, n, ci, co, h, w, kt, kh, kw, with_res = case
+    x, weight, pre, b, res, post = _case(7, t, n, ci, co, h, w, kt, kh, kw, dtype, 'cuda', with_res)
+    assert cf.supported(x, weight)
+    act, clamp = ('linear', None) if with_res else ('lrelu', 1.5)
+    out, ysum, msq = cf.conv3d_frames_forward(x, weight, n, pre, b, res, post, act=act, clamp=clamp, want_msq=True)
+    o_out, o_acc, o_msq = _oracle_all(oracle, x, weight, n, pre, b, res, post, act, clamp)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # one output rounding; accumulation is float32
+    np.testing.assert_allclose(_np(ysum), o_acc, rtol=1.5 * eps, atol=eps * 0.05)
+    np.testing.assert_allclose(_np(out), o_out, rtol=1.5 * eps, atol=eps * 0.05)
+    assert abs(float(msq) - o_msq) <= 1e-3 * o_msq
+    # the no-statistic / no-saved-sum launch writes the same `out`
+    out2, ysum2, msq2 = cf.conv3d_frames_forward(x, weight, n, pre, b, res, post, act=act, clamp=clamp, want_msq=False, keep_sum=False)
+    assert ysum2 is None and msq2 is None and torch.equal(out, out2)
+
+
+@pytest.mark.gpu
+def test_staging_variants_agree_bitwise_gpu(monkeypatch):
+    """LDS-DMA staging and the register-staged variant run the same arithmetic in the same order."""
+    x, weight, pre, b, res, post = _case(3, 4, 2, 128, 128, 9, 16, 3, 3, 3, torch.bfloat16, 'cuda')
+    a = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
+    monkeypatch.setenv('LVG_CONV_STAGE', 'reg')
+    r = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
+    monkeypatch.setenv('LVG_CONV_STAGE', 'glds')
+    monkeypatch.setenv('LVG_CONV_BN', '64')
+    s = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
+    assert torch.equal(a, r) and torch.equal(a, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['k333', 'k133', 'k311'])
+def test_hip_matches_reference_golden_gpu(name):
+    """Reference temporal_modulated_conv3d + bias_act (float32, CPU) vs the fused kernel on bf16 frames."""
+    g = load_golden('modconv3d')
+    x, weight, style, bias, gain = inputs(name)
+    n = x.shape[0]
+    w, mod, demod = _modulation(weight.double().numpy(), style.double().numpy(), float(gain))
+    dev = 'cuda'
+    fr = lambda a: torch.tensor(np.ascontiguousarray(a.transpose(2, 0, 1)).reshape(-1, a.shape[1]), dtype=torch.float32, device=dev)
+    xm = torch.tensor(_frames(x.double().numpy() * mod[:, :, :, None, None]), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    # weights are O(1/sqrt(fan_in)): scale up into the well-resolved bf16 range and fold the factor into `pre`
+    scale = float(np.abs(w).max())
+    wb = torch.tensor(w / scale, device=dev).to(torch.bfloat16)
+    out, ysum, _ = cf.conv3d_frames_forward(xm, wb, n, pre=fr(demod) * scale, b=bias.to(dev).to(torch.bfloat16), act='lrelu', clamp=2.0)
+    got = _video(_np(out), n)
+    np.testing.assert_allclose(got, g[name + '_act'], rtol=0, atol=3e-2)       # bf16 inputs, weights and output (values up to 2)
+    assert np.abs(got - g[name + '_act']).mean() < 4e-3
+
+
+FULL_SHAPES = [
+    # BASELINE.json configs[1] (8 clips): frames, ci, co, h, w, kt, kh, kw, clips
+    (80 * 8, 512, 512, 9, 16, 3, 3, 3, 8),
+    (128 * 8, 128, 128, 18, 32, 1, 3, 3, 8),
+    (128 * 8, 64, 64, 36, 64, 1, 3, 3, 8),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', FULL_SHAPES)
+def test_one_hot_kernel_is_a_zero_padded_shift_full_size_gpu(shape):
+    """Size-independent property at the full configs[1] sizes: with weight[o, c, dt, dh, dw] = [o == c] for ONE tap the
+    convolution is a shift with zero fill -- bit-exact, which checks every tile seam, band offset and border mask."""
+    f, ci, co, h, w, kt, kh, kw, n = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(f, ci, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    for (dt, dh, dw) in {(0, 0, 0), (kt - 1, kh - 1, kw - 1), (kt // 2, 0, kw - 1), (kt - 1, kh // 2, 0)}:
+        weight = torch.zeros(co, ci, kt, kh, kw, dtype=torch.bfloat16, device='cuda')
+        idx = torch.arange(min(ci, co), device='cuda')
+        weight[idx, idx, dt, dh, dw] = 1
+        out, _, _ = cf.conv3d_frames_forward(x, weight, n, keep_sum=False)
+        st, sh, sw = dt - kt // 2, dh - kh // 2, dw - kw // 2
+        v = x.reshape(f // n, n, ci, h, w)
+        ref = torch.zeros_like(v)
+        t = f // n
+        ts, td = slice(max(st, 0), t + min(st, 0)), slice(max(-st, 0), t + min(-st, 0))
+        hs, hd = slice(max(sh, 0), h + min(sh, 0)), slice(max(-sh, 0), h + min(-sh, 0))
+        ws, wd = slice(max(sw, 0), w + min(sw, 0)), slice(max(-sw, 0), w + min(-sw, 0))
+        ref[td, :, :, hd, wd] = v[ts, :, :, hs, ws]
+        assert torch.equal(out, ref.reshape(f, ci, h, w)), (dt, dh, dw)
+
+
+@pytest.mark.gpu
+def test_generator_block_hand_conv_vs_miopen_route_gpu(monkeypatch):
+    """One temporal residual block (forward + all gradients) in bf16 on the hand-written kernel and on the MIOpen +
+    tap-gather route, both against the same block in float32: the hand-written route may not be further from the
+    float32 result than the route it replaces (beyond noise), and the two 16-bit routes agree within bf16 bands."""
+    from lvg.models import lres
+    torch.manual_seed(0)
+    blk = lres.Synthesis3dResBlock(64, 128, 128, temporal_ksize=3, spatial_ksize=3).cuda()
+    n, t = 2, 6
+    x0 = torch.randn(t * n, 128, 9, 16, device='cuda').contiguous(memory_format=torch.channels_last)
+    lat = torch.randn(n, 64, t, device='cuda')
+
+    def run(flag, dtype):
+        monkeypatch.setattr(lres, 'HAND_CONV', flag)
+        x = x0.clone().requires_grad_(True)
+        for p in blk.parameters():
+            p.grad = None
+        y = blk.forward_frames(x, lat, magnitude_ema_beta=0.999, dtype=dtype)
+        (y.float() * torch.linspace(-1, 1, y.numel(), device='cuda').reshape(y.shape)).sum().backward()
+        return [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in blk.parameters()]
+
+    truth = run(False, torch.float32)
+    hand = run(True, torch.bfloat16)
+    miopen = run(False, torch.bfloat16)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    for i, (h, m, tr) in enumerate(zip(hand, miopen, truth)):
+        eh, em = rel(h, tr), rel(m, tr)
+        assert eh < 4e-2 and eh <= 1.25 * em + 2e-3, (i, eh, em)
+        assert rel(h, m) < 5e-2, (i, rel(h, m))
