@@ -53,6 +53,7 @@ struct ConvArgs
     int          reach;        // (kh/2) * W + kw/2: pixels of halo on each side of a tile
     int          bandRows;     // 128 + 2 * reach, rounded up to a multiple of 8
     int          nABuf;        // 2 when there is more than one band per tile
+    int          nBBuf;        // weight-tile ring: 2 (prefetch one K-step ahead) or 3 (two)
     int          nTiles;       // Co / BN
     float        slopeNeg;     // activation as max-free form: u > 0 ? u : u * slopeNeg (linear 1, relu 0, lrelu alpha)
     float        gain, clamp;
@@ -84,7 +85,12 @@ template <> struct Mma<f16_t>
     }
 };
 
-constexpr int kBM = 128;      // pixels per workgroup
+// Measurement builds only (-DLVG_CONV_ABL=bits): 1 no staging in the K loop, 2 no MFMA, 4 no fragment reads, 8 no masks,
+// 16 no wait / barrier, 32 weight tiles always from the first (cache-resident) tile, 64 no band staging, 128 no weight staging. The shipped library is built with 0.
+#ifndef LVG_CONV_ABL
+#define LVG_CONV_ABL 0
+#endif
+constexpr int kAbl = LVG_CONV_ABL;
 constexpr int kBK = 64;       // input channels per K-step (one 128-byte LDS row)
 constexpr int kRowBytes = kBK * 2;
 
@@ -114,12 +120,33 @@ __device__ __forceinline__ void stage16(const unsigned char* src, uint32_t ldsPi
         reg = *reinterpret_cast<const uint4*>(src);
 }
 
-template <class T, int BN, bool GLDS>
-__global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
+__device__ __forceinline__ void wait_vm(int n)
+{
+    // s_waitcnt takes an immediate: the (wave-uniform) number of LDS-DMA pieces that may stay in flight
+    switch (n)
+    {
+    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6:  asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7:  asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+template <class T, int BM, int BN, bool GLDS>
+__global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW  = BM / 32;                 // waves: BM/64 along the pixels x 2 along the output channels
     constexpr int NCB = BN / 64;                 // 32-channel MFMA blocks per wave
-    constexpr int NBI = BN / 32;                 // weight pieces per wave and K-step
+    constexpr int NWA = BM / 128;                // band-loading waves (the last NWA) when the staging is split by operand
+    constexpr int NWB = NW - NWA;                // weight-loading waves then
+    constexpr int NBP = BN / 8;                  // weight pieces per K-step
+    constexpr int NBI = (NBP + NWB - 1) / NWB;   // ... per wave, at most
     constexpr int MAXAI = 4;                     // band pieces per wave and K-step (host guarantees)
     constexpr int bBytes = BN * kRowBytes;
 
@@ -134,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
     const int q = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
     const int mt = tile / p.nTiles, nt = tile - mt * p.nTiles;
-    const int64_t m0 = (int64_t)mt * kBM;
+    const int64_t m0 = (int64_t)mt * BM;
     const int co0 = nt * BN;
 
     const int aBytes = p.bandRows * kRowBytes;
@@ -146,7 +173,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
     const int nMacro = p.kt * nchunk;
     const int nSteps = nMacro * ntap;
     const int nAI = p.bandRows >> 3;                                   // band pieces in total
-    const int aPerStep = (nAI + 4 * ntap - 1) / (4 * ntap);           // per wave and K-step (<= MAXAI)
+    // Prefetch distance of the weight tiles: nBBuf - 1 K-steps. With distance 2 only the pieces issued in the current
+    // K-step may still be in flight at its closing barrier (counted vmcnt), so a band must be complete one K-step
+    // before it is used: its pieces are spread over the first aSlots taps of the previous band only.
+    const int dist = p.nBBuf - 1;
+    // Who stages what. The two operands have different latencies: weight tiles are shared by every workgroup and come
+    // out of L2 / Infinity Cache, a band is first-touch HBM data. vmcnt retires in order, so a wave that issued a band
+    // piece cannot wait for a later weight piece without waiting for the band piece too -- with both on the same waves
+    // every K-step paid an HBM round trip. With a spatial kernel (ntap > 1) the last NWA waves therefore stage ONLY
+    // bands (waited for once, at the last tap of the previous band) and the others ONLY weight tiles (counted vmcnt
+    // per K-step). Without spatial taps (one K-step per band) everything is staged by all waves one K-step ahead.
+    const bool split = ntap > 1;
+    const int bWaves = split ? NWB : NW, aWaves = split ? NWA : NW, aWave0 = split ? NWB : 0;
+    const bool isB = wave < bWaves;
+    const int aPerStep = (nAI + aWaves * ntap - 1) / (aWaves * ntap);  // per band wave and K-step (<= MAXAI)
+    const int aPerStep0 = (nAI + NW * ntap - 1) / (NW * ntap);         // prologue: all waves
     const int pt = p.kt >> 1;
 
     const unsigned char* const xb = static_cast<const unsigned char*>(p.x);
@@ -160,33 +201,46 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
     #pragma unroll
     for (int i = 0; i < NBI; i++)
     {
-        const int piece = wave * NBI + i;
+        const int piece = wave + i * bWaves;
         bLaneOff[i] = (piece * 8 + (lane >> 3)) * (int)rowStrideX + piece_chunk(piece, lane) * 16;
     }
-    // weight tile of (temporal tap dt, chunk kc, spatial tap) -> LDS buffer `buf`
-    auto issueB = [&](int dt, int kc, int tap, int buf)
+    // weight tile of (temporal tap dt, chunk kc, spatial tap) -> LDS buffer `buf`; returns the pieces this wave issued
+    auto issueB = [&](int dt, int kc, int tap, int buf) -> int
     {
         const unsigned char* base = wb + ((int64_t)(dt * ntap + tap) * p.Co + co0) * rowStrideX + kc * kRowBytes;
+        int issued = 0;
         #pragma unroll
         for (int i = 0; i < NBI; i++)
-            stage16<GLDS>(base + bLaneOff[i], ldsBase + bOff + buf * bBytes + (wave * NBI + i) * 1024, regB[i]);
+        {
+            const int piece = wave + i * bWaves;
+            if (isB && piece < NBP)
+            {
+                stage16<GLDS>(base + bLaneOff[i], ldsBase + bOff + buf * bBytes + piece * 1024, regB[i]);
+                issued++;
+            }
+        }
+        return issued;
     };
-    // band pieces of (dt, kc) that this wave brings in during K-step `tapSlot` of the previous band
-    auto issueA = [&](int dt, int kc, int tapSlot, int buf)
+    // band pieces of (dt, kc) that this wave brings in during K-step `tapSlot` of the previous band (waves w0 .. w0 + nw - 1
+    // share the band, `per` pieces per wave and K-step); returns their number
+    auto issueA = [&](int dt, int kc, int tapSlot, int buf, int per, int nw, int w0) -> int
     {
         const int64_t g0 = m0 - p.reach + (int64_t)(dt - pt) * p.tShift;
+        int issued = 0;
         #pragma unroll
         for (int i = 0; i < MAXAI; i++)
         {
-            const int piece = (tapSlot * aPerStep + i) * 4 + wave;
-            if (i < aPerStep && piece < nAI)
+            const int piece = (tapSlot * per + i) * nw + (wave - w0);
+            if (i < per && wave >= w0 && piece < nAI)
             {
                 int64_t g = g0 + piece * 8 + (lane >> 3);
                 g = g < 0 ? 0 : (g >= p.M ? p.M - 1 : g);            // clamped rows are only ever read masked
                 const unsigned char* src = xb + g * rowStrideX + kc * kRowBytes + piece_chunk(piece, lane) * 16;
                 stage16<GLDS>(src, ldsBase + aOff + buf * aBytes + piece * 1024, regA[i]);
+                issued++;
             }
         }
+        return issued;
     };
     auto commitB = [&](int buf)
     {
@@ -194,18 +248,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
         {
             #pragma unroll
             for (int i = 0; i < NBI; i++)
-                *reinterpret_cast<uint4*>(smem + bOff + buf * bBytes + (wave * NBI + i) * 1024 + lane * 16) = regB[i];
+            {
+                const int piece = wave + i * bWaves;
+                if (isB && piece < NBP)
+                    *reinterpret_cast<uint4*>(smem + bOff + buf * bBytes + piece * 1024 + lane * 16) = regB[i];
+            }
         }
     };
-    auto commitA = [&](int tapSlot, int buf)
+    auto commitA = [&](int tapSlot, int buf, int per, int nw, int w0)
     {
         if (!GLDS)
         {
             #pragma unroll
             for (int i = 0; i < MAXAI; i++)
             {
-                const int piece = (tapSlot * aPerStep + i) * 4 + wave;
-                if (i < aPerStep && piece < nAI)
+                const int piece = (tapSlot * per + i) * nw + (wave - w0);
+                if (i < per && wave >= w0 && piece < nAI)
                     *reinterpret_cast<uint4*>(smem + aOff + buf * aBytes + piece * 1024 + lane * 16) = regA[i];
             }
         }
@@ -260,32 +318,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
         wKey[cb] = (row >> 1) & 7;
     }
 
-    // ---- prologue: first band, first weight tile ----------------------------------------------------------------
-    for (int t = 0; t < ntap; t++)
-    {
-        issueA(0, 0, t, 0);
-        commitA(t, 0);
-    }
-    issueB(0, 0, 0, 0);
-    commitB(0);
-    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- K loop: (dt, kc) = band, (dh, dw) = spatial tap inside it; n* = the same counters one K-step ahead ------
+    // ---- K-step counters: (dt, kc) = band, tap = spatial tap inside it; n* = the same, `dist` K-steps ahead ------
     int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
     int ndt = 0, nkc = 0, ntp = 0;
+    auto advanceNext = [&]() { if (++ntp == ntap) { ntp = 0; if (++nkc == nchunk) { nkc = 0; ndt++; } } };
+
+    // ---- prologue: first band, first `dist` weight tiles ---------------------------------------------------------
+    for (int t = 0; t < ntap; t++)
+    {
+        issueA(0, 0, t, 0, aPerStep0, NW, 0);
+        commitA(t, 0, aPerStep0, NW, 0);
+    }
+    for (int d = 0; d < dist; d++)
+    {
+        if (d < nSteps) { issueB(ndt, nkc, ntp, d); commitB(d); }
+        advanceNext();
+    }
+    if (GLDS) wait_vm(0);
+    __syncthreads();
+
+    int bufCur = 0, bufNext = dist;                                   // weight-tile ring positions (mod nBBuf)
     for (int step = 0; step < nSteps; step++)
     {
-        if (++ntp == ntap) { ntp = 0; if (++nkc == nchunk) { nkc = 0; ndt++; } }
-        const bool moreB = step + 1 < nSteps;
+        const bool moreB = step + dist < nSteps;
         const bool moreA = macro + 1 < nMacro;
         const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;               // the band after this one
         const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
-        if (moreB) issueB(ndt, nkc, ntp, (step + 1) & 1);
-        if (moreA) issueA(mdt, mkc, tap, (macro + 1) & 1);
+        int inflight = 0;
+        if (moreB && !(kAbl & (1 | 128))) inflight += (kAbl & 32) ? issueB(0, 0, 0, bufNext) : issueB(ndt, nkc, ntp, bufNext);
+        if (moreA && !(kAbl & (1 | 64))) inflight += issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
+        advanceNext();
 
         const unsigned char* aBuf = smem + aOff + (macro & 1) * aBytes;   // nABuf == 1 only when there is one band
-        const unsigned char* bBuf = smem + bOff + (step & 1) * bBytes;
+        const unsigned char* bBuf = smem + bOff + bufCur * bBytes;
         const int shift = dh * p.W + dw;
         const int bit = dt * ntap + tap;
         int xRowOff[2], xKey[2];
@@ -296,33 +361,66 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
             const int rb = jrow[pb] + shift;
             xRowOff[pb] = rb * kRowBytes;
             xKey[pb] = (rb >> 1) & 7;
-            sel[pb] = ((vmask[pb] >> bit) & 1u) ? 0xffffffffu : 0u;
+            sel[pb] = (((vmask[pb] >> bit) & 1u) | ((kAbl >> 3) & 1u)) ? 0xffffffffu : 0u;
         }
         #pragma unroll
         for (int ks = 0; ks < kBK / 16; ks++)
         {
             const int c = 2 * ks + hi;
             uint4 wf[NCB], xf[2];
-            #pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-                wf[cb] = *reinterpret_cast<const uint4*>(bBuf + wRowOff[cb] + ((c ^ wKey[cb]) << 4));
+            if constexpr (!(kAbl & 4))
+            {
+                #pragma unroll
+                for (int cb = 0; cb < NCB; cb++)
+                    wf[cb] = *reinterpret_cast<const uint4*>(bBuf + wRowOff[cb] + ((c ^ wKey[cb]) << 4));
+                #pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+                    xf[pb] = *reinterpret_cast<const uint4*>(aBuf + xRowOff[pb] + ((c ^ xKey[pb]) << 4));
+            }
+            else
+            {
+                #pragma unroll
+                for (int cb = 0; cb < NCB; cb++) wf[cb] = make_uint4(c, step, cb, 1);
+                #pragma unroll
+                for (int pb = 0; pb < 2; pb++) xf[pb] = make_uint4(c, step, pb, 2);
+            }
             #pragma unroll
             for (int pb = 0; pb < 2; pb++)
             {
-                xf[pb] = *reinterpret_cast<const uint4*>(aBuf + xRowOff[pb] + ((c ^ xKey[pb]) << 4));
                 xf[pb].x &= sel[pb]; xf[pb].y &= sel[pb]; xf[pb].z &= sel[pb]; xf[pb].w &= sel[pb];
             }
-            #pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
+            if constexpr (!(kAbl & 2))
+            {
                 #pragma unroll
-                for (int pb = 0; pb < 2; pb++)
-                    acc[cb][pb] = Mma<T>::run(wf[cb], xf[pb], acc[cb][pb]);
+                for (int cb = 0; cb < NCB; cb++)
+                    #pragma unroll
+                    for (int pb = 0; pb < 2; pb++)
+                        acc[cb][pb] = Mma<T>::run(wf[cb], xf[pb], acc[cb][pb]);
+            }
+            else
+            {
+                #pragma unroll
+                for (int cb = 0; cb < NCB; cb++)
+                    #pragma unroll
+                    for (int pb = 0; pb < 2; pb++)
+                        acc[cb][pb][ks] += __uint_as_float(wf[cb].x ^ xf[pb].y ^ wf[cb].w ^ xf[pb].z);
+            }
         }
 
-        if (moreB) commitB((step + 1) & 1);
-        if (moreA) commitA(tap, (macro + 1) & 1);
-        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (moreB) commitB(bufNext);
+        if (moreA) commitA(tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
+        if constexpr (!(kAbl & 16))
+        {
+            if (GLDS)
+            {
+                if (!split) wait_vm(0);
+                else if (isB) wait_vm(dist > 1 ? inflight : 0);       // weight waves: the tile of the NEXT K-step has landed
+                else if (tap == ntap - 1) wait_vm(0);                 // band waves: the next band is complete
+            }
+            __syncthreads();
+        }
+        if (++bufCur == p.nBBuf) bufCur = 0;
+        if (++bufNext == p.nBBuf) bufNext = 0;
         if (++dw == p.kw) { dw = 0; dh++; }
         if (++tap == ntap) { tap = 0; dh = 0; dw = 0; macro++; kc = mkc; dt = mdt; }
     }
@@ -390,38 +488,62 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_kernel(ConvArgs p)
         float* red = reinterpret_cast<float*>(smem);        // the K loop ended with a barrier: LDS is free
         if (lane == 0) red[wave] = sq;
         __syncthreads();
-        if (tid == 0) p.msqPartial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0)
+        {
+            float tot = 0.f;
+            for (int i = 0; i < NW; i++) tot += red[i];
+            p.msqPartial[tile] = tot;
+        }
     }
 }
 
 struct Plan
 {
-    int bn, bandRows, nABuf, ldsBytes;
+    int bm, bn, bandRows, nABuf, nBBuf, ldsBytes;
     int64_t mTiles;
 };
 
-// Tile choice: 128 output channels per workgroup when two workgroups still fit the 160 KiB of a CU, else 64.
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// Tile choice. 256 pixels x 128 channels on 8 waves with the weight tiles prefetched two K-steps ahead when the
+// problem still gives every CU a workgroup; 128-pixel tiles (4 waves, two workgroups per CU) otherwise.
 int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl)
 {
     const int reach = (kh / 2) * W + kw / 2;
-    pl.bandRows = (int)lvg_ceil_div(kBM + 2 * reach, 8) * 8;
-    pl.nABuf = (kt * (Ci / kBK) > 1) ? 2 : 1;
-    pl.mTiles = lvg_ceil_div(M, kBM);
-    const int aBytes = pl.nABuf * pl.bandRows * kRowBytes;
-    const char* force = getenv("LVG_CONV_BN");
-    int bn = (Co % 128 == 0 && aBytes + 2 * 128 * kRowBytes <= 80 * 1024) ? 128 : 64;
-    if (force && atoi(force) == 64) bn = 64;
-    if (force && atoi(force) == 128 && Co % 128 == 0) bn = 128;
-    pl.bn = bn;
-    pl.ldsBytes = aBytes + 2 * bn * kRowBytes;
+    const int ntap = kh * kw;
+    auto fill = [&](int bm, int bn, int nb)
+    {
+        pl.bm = bm; pl.bn = bn;
+        pl.bandRows = (int)lvg_ceil_div(bm + 2 * reach, 8) * 8;
+        pl.nABuf = (kt * (Ci / kBK) > 1) ? 2 : 1;
+        pl.nBBuf = ntap > 1 ? nb : 2;                                  // no spatial taps: everything one K-step ahead
+        pl.mTiles = lvg_ceil_div(M, bm);
+        pl.ldsBytes = pl.nABuf * pl.bandRows * kRowBytes + pl.nBBuf * bn * kRowBytes;
+    };
+    const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);
+    int bn = (Co % 128 == 0) ? 128 : 64;
+    if (fbn == 64 || (fbn == 128 && Co % 128 == 0)) bn = fbn;
+    int bm = (lvg_ceil_div(M, 256) * (Co / bn) >= 256) ? 256 : 128;
+    if (fbm == 128 || fbm == 256) bm = fbm;
+    int nb = bm == 256 ? 3 : 2;
+    if (fnb == 2 || fnb == 3) nb = fnb;
+    fill(bm, bn, nb);
+    if (pl.ldsBytes > 160 * 1024 && nb == 3) fill(bm, bn, 2);
+    if (pl.ldsBytes > 160 * 1024 && bm == 256) fill(128, bn, 2);
     if (pl.ldsBytes > 160 * 1024) return -1;
+    const int aw = ntap > 1 ? pl.bm / 128 : pl.bm / 32;                // band-staging waves (see `split` in the kernel)
+    if (lvg_ceil_div(pl.bandRows / 8, aw * ntap) > 4) return -1;       // MAXAI band pieces per wave and K-step
     return 0;
 }
 
-template <class T, int BN, bool GLDS>
+template <class T, int BM, int BN, bool GLDS>
 int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BN, GLDS>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, GLDS>;
     if (pl.ldsBytes > 64 * 1024)
     {
         // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
@@ -433,8 +555,15 @@ int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
         }
     }
     const int64_t blocks = pl.mTiles * a.nTiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), pl.ldsBytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM * 2), pl.ldsBytes, stream, a);
     return lvg_check_launch("conv3d_frames");
+}
+
+template <class T, bool GLDS>
+int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
+{
+    if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, GLDS>(a, pl, s) : launch<T, 256, 64, GLDS>(a, pl, s);
+    return pl.bn == 128 ? launch<T, 128, 128, GLDS>(a, pl, s) : launch<T, 128, 64, GLDS>(a, pl, s);
 }
 
 } // namespace
@@ -442,7 +571,7 @@ int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
 {
     Plan pl;
-    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0) return 0;
+    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32 || frames * h * w >= (int64_t)1 << 31) return 0;
     if (make_plan(frames * h * w, w, ci, co, kt, kh, kw, pl) != 0) return 0;
     return pl.mTiles * (co / pl.bn);
 }
@@ -464,9 +593,9 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
         return LVG_ERR_UNSUPPORTED;
     }
     Plan pl;
-    if (make_plan(frames * h * wd, wd, ci, co, kt, kh, kw, pl) != 0 || lvg_ceil_div(pl.bandRows / 8, 4 * kh * kw) > 4)
+    if (make_plan(frames * h * wd, wd, ci, co, kt, kh, kw, pl) != 0)
     {
-        lvg_set_error("conv3d_frames: frame width %d needs a %d-row band: no kernel", wd, pl.bandRows);
+        lvg_set_error("conv3d_frames: frame width %d needs a band the tile cannot hold: no kernel", wd);
         return LVG_ERR_UNSUPPORTED;
     }
     ConvArgs a;
@@ -479,6 +608,7 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     a.reach = (kh / 2) * wd + kw / 2;
     a.bandRows = pl.bandRows;
     a.nABuf = pl.nABuf;
+    a.nBBuf = pl.nBBuf;
     a.nTiles = co / pl.bn;
     a.slopeNeg = act == LVG_ACT_LINEAR ? 1.f : (act == LVG_ACT_RELU ? 0.f : alpha);
     a.gain = gain;
@@ -486,11 +616,6 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     const char* st = getenv("LVG_CONV_STAGE");
     const bool glds = !(st && strcmp(st, "reg") == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == LVG_BF16)
-    {
-        if (pl.bn == 128) return glds ? launch<bf16_t, 128, true>(a, pl, s) : launch<bf16_t, 128, false>(a, pl, s);
-        return glds ? launch<bf16_t, 64, true>(a, pl, s) : launch<bf16_t, 64, false>(a, pl, s);
-    }
-    if (pl.bn == 128) return glds ? launch<f16_t, 128, true>(a, pl, s) : launch<f16_t, 128, false>(a, pl, s);
-    return glds ? launch<f16_t, 64, true>(a, pl, s) : launch<f16_t, 64, false>(a, pl, s);
+    if (dtype == LVG_BF16) return glds ? launch_tile<bf16_t, true>(a, pl, s) : launch_tile<bf16_t, false>(a, pl, s);
+    return glds ? launch_tile<f16_t, true>(a, pl, s) : launch_tile<f16_t, false>(a, pl, s);
 }
