@@ -12,23 +12,31 @@
 //               (terms whose source pixel leaves the frame -- rows, columns or time -- are zero: 'same' padding)
 //   out[m][co] = clamp(act(acc * pre[f][co] + b[co] + res[m][co]) * gain) * post[f][co]      ysum = acc (saved)
 //
-// GEMM view: D[co][pixel] = W[co][k] * X[k][pixel], k = (dt, dh, dw, ci). One workgroup (4 waves) owns 128
-// consecutive pixels x BN output channels; a wave owns 64 pixels x BN/2 channels as 2 x (BN/64) MFMA blocks
-// (v_mfma_f32_32x32x16, weights = A operand, pixels = B operand: a lane of the result holds ONE pixel and 4
+// GEMM view: D[co][pixel] = W[co][k] * X[k][pixel], k = (dt, dh, dw, ci). One workgroup owns BM (128 / 256)
+// consecutive pixels x BN (64 / 128) output channels; a wave owns 64 pixels x BN/2 channels as 2 x (BN/64) MFMA
+// blocks (v_mfma_f32_32x32x16, weights = A operand, pixels = B operand: a lane of the result holds ONE pixel and 4
 // consecutive output channels per register quad -> 8-byte channels-last stores).
 //
-// What makes it implicit: in channels-last memory the pixels a 128-pixel tile needs for ALL kh x kw spatial taps
-// are one contiguous band of 128 + 2 * (kh/2 * W + kw/2) pixel rows (a tap is a constant shift of the flattened
-// pixel index; what wraps around a row / frame edge is masked at fragment-read time). The band of one
+// What makes it implicit: in channels-last memory the pixels a tile needs for ALL kh x kw spatial taps are one
+// contiguous band of BM + 2 * (kh/2 * W + kw/2) pixel rows (a tap is a constant shift of the flattened pixel index;
+// lanes whose source pixel wraps around a row / frame edge read a zero row of LDS instead). The band of one
 // (temporal tap, 64-channel chunk) is brought into LDS ONCE and feeds kh*kw K-steps; only the weight tile
 // (BN x 64) is loaded per K-step. Staging is LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no
 // ds_write pass): the LDS image is lane-linear, so the bank swizzle (16-byte chunk c of row r lives at chunk
 // c ^ ((r >> 1) & 7): conflict-free `ds_read_b128` for any tap shift, since the 16-lane read groups cover 16
-// rows that are distinct modulo 16) is applied to the per-lane SOURCE address. Weight tiles are double-buffered
-// per K-step, bands per (temporal tap, chunk), their loads spread over the taps of the previous band.
+// rows that are distinct modulo 16 -- SQ_LDS_BANK_CONFLICT = 0 measured) is applied to the per-lane SOURCE address.
 //
-// A register-staged variant of the same schedule (global_load_dwordx4 -> ds_write_b128) is kept behind
-// LVG_CONV_STAGE=reg for A/B measurements.
+// Measured facts the schedule is built on (profiles/r02_conv3d_igemm_*.csv, tools/gpu_conv_abl.sh):
+//  * the K loop is bound by INSTRUCTION ISSUE, not by the matrix pipe or by bytes: the first version spent 160
+//    scalar + 90 vector instructions per K-step and wave next to its 16 MFMAs (31 % MFMA busy). Everything per-step
+//    is therefore strength-reduced: running 64-bit tile pointers in SGPRs with the SGPR-base form of the LDS-DMA
+//    instruction (no 64-bit lane addresses), masks through ONE address select per pixel block, fragment addresses
+//    as (e ^ const) + base;
+//  * vmcnt retires in order and the two operands have different latencies (weight tiles are shared by every
+//    workgroup and come out of L2 / Infinity Cache, a band is first-touch HBM data): with both on the same waves
+//    every K-step paid an HBM round trip. The last BM/128 waves therefore stage ONLY bands (waited for once per
+//    band), the others ONLY weight tiles (counted vmcnt per K-step, ring of 2 or 3 tiles);
+//  * a register-staged variant of the same schedule (global_load -> ds_write) ran at half the rate and was dropped.
 
 #include "epilogue_common.h"
 #include <stdlib.h>
@@ -51,7 +59,7 @@ struct ConvArgs
     int64_t      tShift;       // pixels between consecutive time steps (= clips * H * W)
     int          H, W, Ci, Co, kt, kh, kw;
     int          reach;        // (kh/2) * W + kw/2: pixels of halo on each side of a tile
-    int          bandRows;     // 128 + 2 * reach, rounded up to a multiple of 8
+    int          bandRows;     // BM + 2 * reach, rounded up to a multiple of 8
     int          nABuf;        // 2 when there is more than one band per tile
     int          nBBuf;        // weight-tile ring: 2 (prefetch one K-step ahead) or 3 (two)
     int          nTiles;       // Co / BN
@@ -85,14 +93,15 @@ template <> struct Mma<f16_t>
     }
 };
 
-// Measurement builds only (-DLVG_CONV_ABL=bits): 1 no staging in the K loop, 2 no MFMA, 4 no fragment reads, 8 no masks,
-// 16 no wait / barrier, 32 weight tiles always from the first (cache-resident) tile, 64 no band staging, 128 no weight staging. The shipped library is built with 0.
+// Measurement builds only (-DLVG_CONV_ABL=bits): 1 no staging in the K loop, 2 no MFMA, 4 no fragment reads,
+// 16 no wait / barrier, 64 no band staging, 128 no weight staging. The shipped library is built with 0.
 #ifndef LVG_CONV_ABL
 #define LVG_CONV_ABL 0
 #endif
 constexpr int kAbl = LVG_CONV_ABL;
 constexpr int kBK = 64;       // input channels per K-step (one 128-byte LDS row)
 constexpr int kRowBytes = kBK * 2;
+constexpr int kZeroBytes = 1024;   // LDS [0, 1024): zeros (what masked lanes read); the tiles follow
 
 // One 1-KiB piece (8 LDS rows x 128 B) per wave instruction: lane -> (row in piece, physical chunk).
 // Returns the LOGICAL 16-byte chunk this lane must fetch so that the lane-linear LDS image is the swizzled one.
@@ -102,53 +111,40 @@ __device__ __forceinline__ int piece_chunk(int piece, int lane)
     return (lane & 7) ^ ((row >> 1) & 7);
 }
 
-// LDS-DMA of 16 bytes per lane: LDS address = ldsPiece (wave-uniform, via M0) + lane * 16. Issued as inline assembly
-// on purpose: hipcc orders every later ds_read behind a `__builtin_amdgcn_global_load_lds` it has seen (s_waitcnt
-// vmcnt(0) before the first fragment read of the K-step, i.e. no overlap of the prefetch with the MFMAs of the
-// same wave); an asm statement is outside its bookkeeping, the kernel waits (vmcnt) itself before the barrier
-// that publishes the tile.
-template <bool GLDS>
-__device__ __forceinline__ void stage16(const unsigned char* src, uint32_t ldsPiece, uint4& reg)
+// LDS-DMA of 16 bytes per lane: LDS address = ldsPiece (wave-uniform, via M0) + lane * 16; source = base (SGPR pair)
+// + 32-bit lane offset. Inline assembly on purpose: hipcc orders every later ds_read behind a
+// `__builtin_amdgcn_global_load_lds` it has seen (s_waitcnt vmcnt(0) before the first fragment read of the K-step,
+// i.e. no overlap of the prefetch with the MFMAs of the same wave); an asm statement is outside its bookkeeping, the
+// kernel waits (vmcnt) itself before the barrier that publishes the tile. M0 is not used by anything else here.
+__device__ __forceinline__ void dma16(const unsigned char* base, uint32_t laneOff, uint32_t ldsPiece)
 {
-    if (GLDS)
-    {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(ldsPiece) : "memory");
-    }
-    else
-        reg = *reinterpret_cast<const uint4*>(src);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(laneOff), "s"(base), "s"(ldsPiece) : "memory");
 }
 
-__device__ __forceinline__ void wait_vm(int n)
+template <int N> __device__ __forceinline__ void wait_vm_const()
 {
-    // s_waitcnt takes an immediate: the (wave-uniform) number of LDS-DMA pieces that may stay in flight
-    switch (n)
-    {
-    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1:  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6:  asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7:  asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    }
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
-template <class T, int BM, int BN, bool GLDS>
-__global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
+template <class T, int BM, int BN, int PB>
+__global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW  = BM / 32;                 // waves: BM/64 along the pixels x 2 along the output channels
+    constexpr int NW  = BM / (32 * PB) * 2;      // waves: BM / (32 PB) along the pixels x 2 along the output channels
     constexpr int NCB = BN / 64;                 // 32-channel MFMA blocks per wave
-    constexpr int NWA = BM / 128;                // band-loading waves (the last NWA) when the staging is split by operand
-    constexpr int NWB = NW - NWA;                // weight-loading waves then
+    constexpr int NWA = NW / 4;                  // band-staging waves (the last NWA) when the kernel has spatial taps
+    constexpr int NWB = NW - NWA;                // weight-staging waves then
     constexpr int NBP = BN / 8;                  // weight pieces per K-step
     constexpr int NBI = (NBP + NWB - 1) / NWB;   // ... per wave, at most
-    constexpr int MAXAI = 4;                     // band pieces per wave and K-step (host guarantees)
+    constexpr int MAXAI = 6;                     // band pieces per wave and K-step (host guarantees)
     constexpr int bBytes = BN * kRowBytes;
+    static_assert(NBI <= 6, "wait_vm_const covers up to 6 pieces in flight");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,25 +160,18 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
     const int64_t m0 = (int64_t)mt * BM;
     const int co0 = nt * BN;
 
+    // LDS: [zero page | nBBuf weight tiles | nABuf bands]
     const int aBytes = p.bandRows * kRowBytes;
     const uint32_t ldsBase = (uint32_t)(uintptr_t)smem;                 // generic -> LDS byte address (low 32 bits)
-    const int aOff = 0, bOff = p.nABuf * aBytes;
+    const int bOff = kZeroBytes, aOff = kZeroBytes + p.nBBuf * bBytes;
 
     const int ntap = p.kh * p.kw;
     const int nchunk = p.Ci / kBK;
     const int nMacro = p.kt * nchunk;
     const int nSteps = nMacro * ntap;
     const int nAI = p.bandRows >> 3;                                   // band pieces in total
-    // Prefetch distance of the weight tiles: nBBuf - 1 K-steps. With distance 2 only the pieces issued in the current
-    // K-step may still be in flight at its closing barrier (counted vmcnt), so a band must be complete one K-step
-    // before it is used: its pieces are spread over the first aSlots taps of the previous band only.
-    const int dist = p.nBBuf - 1;
-    // Who stages what. The two operands have different latencies: weight tiles are shared by every workgroup and come
-    // out of L2 / Infinity Cache, a band is first-touch HBM data. vmcnt retires in order, so a wave that issued a band
-    // piece cannot wait for a later weight piece without waiting for the band piece too -- with both on the same waves
-    // every K-step paid an HBM round trip. With a spatial kernel (ntap > 1) the last NWA waves therefore stage ONLY
-    // bands (waited for once, at the last tap of the previous band) and the others ONLY weight tiles (counted vmcnt
-    // per K-step). Without spatial taps (one K-step per band) everything is staged by all waves one K-step ahead.
+    const int dist = p.nBBuf - 1;                                      // weight tiles are staged `dist` K-steps ahead
+    // Without spatial taps (one K-step per band) everything is staged by all waves one K-step ahead (host: nBBuf = 2).
     const bool split = ntap > 1;
     const int bWaves = split ? NWB : NW, aWaves = split ? NWA : NW, aWave0 = split ? NWB : 0;
     const bool isB = wave < bWaves;
@@ -192,22 +181,29 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
 
     const unsigned char* const xb = static_cast<const unsigned char*>(p.x);
     const unsigned char* const wb = static_cast<const unsigned char*>(p.w);
-    const int64_t rowStrideX = (int64_t)p.Ci * 2;
+    const uint32_t rowStride = (uint32_t)p.Ci * 2;                     // bytes per pixel / per weight row
+
+    if (tid < kZeroBytes / 16) reinterpret_cast<uint4*>(smem)[tid] = make_uint4(0, 0, 0, 0);
 
     // ---- staging -----------------------------------------------------------------------------------------------
-    // Per lane and piece the source offset inside a tile is fixed: (row in tile) * row stride + swizzled chunk.
-    uint4 regB[NBI], regA[MAXAI];
-    int bLaneOff[NBI];
+    // Weight tiles: per lane and piece the source offset inside a tile is fixed; the tile base is a running pointer.
+    uint32_t bLaneOff[NBI];
+    int bPiece[NBI];                                                   // LDS piece of each; a wave with fewer pieces repeats its last
     #pragma unroll
     for (int i = 0; i < NBI; i++)
     {
-        const int piece = wave + i * bWaves;
-        bLaneOff[i] = (piece * 8 + (lane >> 3)) * (int)rowStrideX + piece_chunk(piece, lane) * 16;
+        int piece = wave + i * bWaves;
+        if (piece >= NBP) piece -= bWaves;                             // NBI - 1 pieces exist for every weight wave
+        bPiece[i] = piece;
+        bLaneOff[i] = (uint32_t)(piece * 8 + (lane >> 3)) * rowStride + piece_chunk(piece, lane) * 16;
     }
-    // weight tile of (temporal tap dt, chunk kc, spatial tap) -> LDS buffer `buf`; returns the pieces this wave issued
-    auto issueB = [&](int dt, int kc, int tap, int buf) -> int
+    const uint64_t tapStride = (uint64_t)p.Co * rowStride;             // bytes between the tiles of consecutive taps
+    const uint64_t macroJump = (uint64_t)ntap * tapStride - (uint64_t)(nchunk - 1) * kRowBytes;   // last chunk -> next temporal tap
+    const unsigned char* wMacro = wb + (uint64_t)co0 * rowStride;      // tap 0 of the band the NEXT staged tile belongs to
+    const unsigned char* wNext = wMacro;                               // the next tile to stage
+    int nTap = 0, nKc = 0;                                             // its (spatial tap, chunk)
+    auto issueB = [&](int buf) -> int
     {
-        const unsigned char* base = wb + ((int64_t)(dt * ntap + tap) * p.Co + co0) * rowStrideX + kc * kRowBytes;
         int issued = 0;
         #pragma unroll
         for (int i = 0; i < NBI; i++)
@@ -215,67 +211,51 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
             const int piece = wave + i * bWaves;
             if (isB && piece < NBP)
             {
-                stage16<GLDS>(base + bLaneOff[i], ldsBase + bOff + buf * bBytes + piece * 1024, regB[i]);
+                dma16(wNext, bLaneOff[i], ldsBase + bOff + buf * bBytes + piece * 1024);
                 issued++;
             }
         }
+        // advance to the tile of the next K-step: next tap; then next chunk of the same temporal tap; then next temporal tap
+        if (++nTap == ntap)
+        {
+            nTap = 0;
+            if (++nKc == nchunk) { nKc = 0; wMacro += macroJump; }
+            else wMacro += kRowBytes;
+            wNext = wMacro;
+        }
+        else wNext += tapStride;
         return issued;
     };
-    // band pieces of (dt, kc) that this wave brings in during K-step `tapSlot` of the previous band (waves w0 .. w0 + nw - 1
-    // share the band, `per` pieces per wave and K-step); returns their number
-    auto issueA = [&](int dt, int kc, int tapSlot, int buf, int per, int nw, int w0) -> int
+    // Band pieces of (dt, kc) that this wave brings in during K-step `tapSlot` of the previous band (waves w0 .. w0 + nw - 1
+    // share the band, `per` pieces per wave and K-step). Source rows are clamped into the tensor: clamped rows are only
+    // ever read by masked lanes.
+    const uint32_t aChunkOff = (uint32_t)(lane & 7);
+    auto issueA = [&](int dt, int kc, int tapSlot, int buf, int per, int nw, int w0)
     {
-        const int64_t g0 = m0 - p.reach + (int64_t)(dt - pt) * p.tShift;
-        int issued = 0;
+        const int g0 = (int)(m0 - p.reach + (int64_t)(dt - pt) * p.tShift);     // |.| < 2^31 (host check)
+        const int last = (int)p.M - 1;
         #pragma unroll
         for (int i = 0; i < MAXAI; i++)
         {
             const int piece = (tapSlot * per + i) * nw + (wave - w0);
             if (i < per && wave >= w0 && piece < nAI)
             {
-                int64_t g = g0 + piece * 8 + (lane >> 3);
-                g = g < 0 ? 0 : (g >= p.M ? p.M - 1 : g);            // clamped rows are only ever read masked
-                const unsigned char* src = xb + g * rowStrideX + kc * kRowBytes + piece_chunk(piece, lane) * 16;
-                stage16<GLDS>(src, ldsBase + aOff + buf * aBytes + piece * 1024, regA[i]);
-                issued++;
-            }
-        }
-        return issued;
-    };
-    auto commitB = [&](int buf)
-    {
-        if (!GLDS)
-        {
-            #pragma unroll
-            for (int i = 0; i < NBI; i++)
-            {
-                const int piece = wave + i * bWaves;
-                if (isB && piece < NBP)
-                    *reinterpret_cast<uint4*>(smem + bOff + buf * bBytes + piece * 1024 + lane * 16) = regB[i];
-            }
-        }
-    };
-    auto commitA = [&](int tapSlot, int buf, int per, int nw, int w0)
-    {
-        if (!GLDS)
-        {
-            #pragma unroll
-            for (int i = 0; i < MAXAI; i++)
-            {
-                const int piece = (tapSlot * per + i) * nw + (wave - w0);
-                if (i < per && wave >= w0 && piece < nAI)
-                    *reinterpret_cast<uint4*>(smem + aOff + buf * aBytes + piece * 1024 + lane * 16) = regA[i];
+                int g = g0 + piece * 8 + (lane >> 3);
+                g = g < 0 ? 0 : (g > last ? last : g);
+                const uint32_t chunk = aChunkOff ^ (uint32_t)(((piece * 8 + (lane >> 3)) >> 1) & 7);
+                const uint32_t off = (uint32_t)g * rowStride + (uint32_t)kc * kRowBytes + chunk * 16;   // < 2^32 (host check)
+                dma16(xb, off, ldsBase + aOff + buf * aBytes + piece * 1024);
             }
         }
     };
 
     // ---- which (temporal tap, spatial tap) pairs read a real pixel, per lane and pixel block -------------------
-    uint32_t vmask[2];
-    int jrow[2];
+    uint32_t vmask[PB];
+    int jrow[PB];
     #pragma unroll
-    for (int pb = 0; pb < 2; pb++)
+    for (int pb = 0; pb < PB; pb++)
     {
-        const int j = wr * 64 + pb * 32 + l31;
+        const int j = wr * (32 * PB) + pb * 32 + l31;
         jrow[pb] = j;
         const int64_t m = m0 + j;
         uint32_t mask = 0;
@@ -300,129 +280,176 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
         vmask[pb] = mask;
     }
 
-    f32x16 acc[NCB][2];
+    f32x16 acc[NCB][PB];
     #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
         #pragma unroll
-        for (int pb = 0; pb < 2; pb++)
+        for (int pb = 0; pb < PB; pb++)
             #pragma unroll
             for (int r = 0; r < 16; r++) acc[cb][pb][r] = 0.f;
 
-    // LDS offsets of the weight fragments (fixed): row = wc * BN/2 + cb * 32 + l31
-    int wRowOff[NCB], wKey[NCB];
+    // Fragment addresses. Row r, logical chunk c = 2 ks + hi lives at byte r * 128 + ((c ^ key(r)) << 4), key = (r >> 1) & 7,
+    // and (2 ks + hi) ^ key = (hi ^ key) ^ 2 ks: address = rowBase + (e ^ (ks << 5)) with e = (hi ^ key) << 4.
+    uint32_t wAddr[NCB][4];                                           // weight fragments: fixed per lane (+ ring position)
     #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
     {
         const int row = wc * (BN / 2) + cb * 32 + l31;
-        wRowOff[cb] = row * kRowBytes;
-        wKey[cb] = (row >> 1) & 7;
+        const uint32_t e = (uint32_t)(hi ^ ((row >> 1) & 7)) << 4;
+        #pragma unroll
+        for (int ks = 0; ks < 4; ks++) wAddr[cb][ks] = (uint32_t)(bOff + row * kRowBytes) + (e ^ (uint32_t)(ks << 5));
     }
 
-    // ---- K-step counters: (dt, kc) = band, tap = spatial tap inside it; n* = the same, `dist` K-steps ahead ------
-    int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
-    int ndt = 0, nkc = 0, ntp = 0;
-    auto advanceNext = [&]() { if (++ntp == ntap) { ntp = 0; if (++nkc == nchunk) { nkc = 0; ndt++; } } };
-
-    // ---- prologue: first band, first `dist` weight tiles ---------------------------------------------------------
-    for (int t = 0; t < ntap; t++)
-    {
-        issueA(0, 0, t, 0, aPerStep0, NW, 0);
-        commitA(t, 0, aPerStep0, NW, 0);
-    }
+    // ---- prologue: first band (all waves), first `dist` weight tiles ------------------------------------------------
+    for (int t = 0; t < ntap; t++) issueA(0, 0, t, 0, aPerStep0, NW, 0);
     for (int d = 0; d < dist; d++)
-    {
-        if (d < nSteps) { issueB(ndt, nkc, ntp, d); commitB(d); }
-        advanceNext();
-    }
-    if (GLDS) wait_vm(0);
+        if (d < nSteps) issueB(d);
+    wait_vm_const<0>();
     __syncthreads();
 
-    int bufCur = 0, bufNext = dist;                                   // weight-tile ring positions (mod nBBuf)
-    for (int step = 0; step < nSteps; step++)
-    {
-        const bool moreB = step + dist < nSteps;
-        const bool moreA = macro + 1 < nMacro;
-        const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;               // the band after this one
-        const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
-        int inflight = 0;
-        if (moreB && !(kAbl & (1 | 128))) inflight += (kAbl & 32) ? issueB(0, 0, 0, bufNext) : issueB(ndt, nkc, ntp, bufNext);
-        if (moreA && !(kAbl & (1 | 64))) inflight += issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
-        advanceNext();
+    // ---- K loop: (dt, kc) = band, tap = spatial tap inside it --------------------------------------------------------
+    int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
+    int bufNext = dist;                                               // ring slot the next staged weight tile goes to
+    uint32_t curB = 0;                                                // byte offset of the current weight tile in the ring
+    uint32_t curA = (uint32_t)aOff;                                   // byte offset of the current band
+    const uint32_t ringBytes = (uint32_t)(p.nBBuf * bBytes);
 
-        const unsigned char* aBuf = smem + aOff + (macro & 1) * aBytes;   // nABuf == 1 only when there is one band
-        const unsigned char* bBuf = smem + bOff + bufCur * bBytes;
+    // One K-step of arithmetic: fragment addresses of this tap, then 4 x (fragment reads, MFMAs) with the reads of
+    // sub-step ks + 1 issued ahead of the MFMAs of sub-step ks (two fragment register sets).
+    auto compute = [&]() __attribute__((always_inline))
+    {
         const int shift = dh * p.W + dw;
         const int bit = dt * ntap + tap;
-        int xRowOff[2], xKey[2];
-        uint32_t sel[2];
+        uint32_t xBase[PB], xE[PB];
         #pragma unroll
-        for (int pb = 0; pb < 2; pb++)
+        for (int pb = 0; pb < PB; pb++)
         {
-            const int rb = jrow[pb] + shift;
-            xRowOff[pb] = rb * kRowBytes;
-            xKey[pb] = (rb >> 1) & 7;
-            sel[pb] = (((vmask[pb] >> bit) & 1u) | ((kAbl >> 3) & 1u)) ? 0xffffffffu : 0u;
+            const uint32_t rb = (uint32_t)(jrow[pb] + shift);
+            const bool ok = (vmask[pb] >> bit) & 1u;
+            xE[pb] = ((uint32_t)hi ^ ((rb >> 1) & 7u)) << 4;
+            // masked lanes read zeros from the 256-byte zero page at the SAME bank position (row parity kept): the
+            // conflict-free bank pattern of the group survives
+            xBase[pb] = ok ? curA + (rb << 7) : ((rb & 1u) << 7);
         }
-        #pragma unroll
-        for (int ks = 0; ks < kBK / 16; ks++)
+        uint4 wf[2][NCB], xf[2][PB];
+        auto fetch = [&](int ks, int set) __attribute__((always_inline))
         {
-            const int c = 2 * ks + hi;
-            uint4 wf[NCB], xf[2];
             if constexpr (!(kAbl & 4))
             {
                 #pragma unroll
                 for (int cb = 0; cb < NCB; cb++)
-                    wf[cb] = *reinterpret_cast<const uint4*>(bBuf + wRowOff[cb] + ((c ^ wKey[cb]) << 4));
+                    wf[set][cb] = *reinterpret_cast<const uint4*>(smem + (wAddr[cb][ks] + curB));
                 #pragma unroll
-                for (int pb = 0; pb < 2; pb++)
-                    xf[pb] = *reinterpret_cast<const uint4*>(aBuf + xRowOff[pb] + ((c ^ xKey[pb]) << 4));
+                for (int pb = 0; pb < PB; pb++)
+                    xf[set][pb] = *reinterpret_cast<const uint4*>(smem + (xBase[pb] + (xE[pb] ^ (uint32_t)(ks << 5))));
             }
             else
             {
                 #pragma unroll
-                for (int cb = 0; cb < NCB; cb++) wf[cb] = make_uint4(c, step, cb, 1);
+                for (int cb = 0; cb < NCB; cb++) wf[set][cb] = make_uint4(ks, tap, cb, 1);
                 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) xf[pb] = make_uint4(c, step, pb, 2);
+                for (int pb = 0; pb < PB; pb++) xf[set][pb] = make_uint4(ks, tap, pb, xBase[pb]);
             }
-            #pragma unroll
-            for (int pb = 0; pb < 2; pb++)
-            {
-                xf[pb].x &= sel[pb]; xf[pb].y &= sel[pb]; xf[pb].z &= sel[pb]; xf[pb].w &= sel[pb];
-            }
+        };
+        fetch(0, 0);
+        #pragma unroll
+        for (int ks = 0; ks < kBK / 16; ks++)
+        {
+            if (ks + 1 < kBK / 16) fetch(ks + 1, (ks + 1) & 1);
             if constexpr (!(kAbl & 2))
             {
                 #pragma unroll
-                for (int cb = 0; cb < NCB; cb++)
+                for (int pb = 0; pb < PB; pb++)
                     #pragma unroll
-                    for (int pb = 0; pb < 2; pb++)
-                        acc[cb][pb] = Mma<T>::run(wf[cb], xf[pb], acc[cb][pb]);
+                    for (int cb = 0; cb < NCB; cb++)
+                        acc[cb][pb] = Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
             }
             else
             {
                 #pragma unroll
                 for (int cb = 0; cb < NCB; cb++)
                     #pragma unroll
-                    for (int pb = 0; pb < 2; pb++)
-                        acc[cb][pb][ks] += __uint_as_float(wf[cb].x ^ xf[pb].y ^ wf[cb].w ^ xf[pb].z);
+                    for (int pb = 0; pb < PB; pb++)
+                        acc[cb][pb][ks] += __uint_as_float(wf[ks & 1][cb].x ^ xf[ks & 1][pb].y ^ wf[ks & 1][cb].w ^ xf[ks & 1][pb].z);
             }
         }
-
-        if (moreB) commitB(bufNext);
-        if (moreA) commitA(tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
-        if constexpr (!(kAbl & 16))
-        {
-            if (GLDS)
-            {
-                if (!split) wait_vm(0);
-                else if (isB) wait_vm(dist > 1 ? inflight : 0);       // weight waves: the tile of the NEXT K-step has landed
-                else if (tap == ntap - 1) wait_vm(0);                 // band waves: the next band is complete
-            }
-            __syncthreads();
-        }
-        if (++bufCur == p.nBBuf) bufCur = 0;
+    };
+    // counters of the next K-step
+    auto advance = [&]() __attribute__((always_inline))
+    {
+        curB += bBytes;
+        if (curB == ringBytes) curB = 0;
         if (++bufNext == p.nBBuf) bufNext = 0;
         if (++dw == p.kw) { dw = 0; dh++; }
-        if (++tap == ntap) { tap = 0; dh = 0; dw = 0; macro++; kc = mkc; dt = mdt; }
+        if (++tap == ntap)
+        {
+            tap = 0; dh = 0; dw = 0; macro++;
+            if (++kc == nchunk) { kc = 0; dt++; }
+            curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);  // nABuf == 1 only when there is one band
+        }
+    };
+
+    if (!split)
+    {
+        // no spatial taps: every wave stages its share of both operands one K-step ahead
+        for (int step = 0; step < nSteps; step++)
+        {
+            const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;
+            const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
+            if (step + dist < nSteps && !(kAbl & (1 | 128))) issueB(bufNext);
+            if (macro + 1 < nMacro && !(kAbl & (1 | 64))) issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
+            compute();
+            if constexpr (!(kAbl & 16)) { wait_vm_const<0>(); __syncthreads(); }
+            advance();
+        }
+    }
+    else if (isB)
+    {
+        // weight waves: NBI pieces per K-step, always (past the last tile the same tile is staged again into a ring slot
+        // nobody reads any more) -- no branches between the staging and the MFMAs, counted wait
+        for (int step = 0; step < nSteps; step++)
+        {
+            if constexpr (!(kAbl & (1 | 128)))
+            {
+                #pragma unroll
+                for (int i = 0; i < NBI; i++)
+                    dma16(wNext, bLaneOff[i], ldsBase + bOff + bufNext * bBytes + bPiece[i] * 1024);
+                const bool more = step + dist + 1 < nSteps;            // another tile after this one
+                const bool wrapT = nTap + 1 == ntap;
+                const bool wrapK = wrapT && (nKc + 1 == nchunk);
+                const uint64_t jump = wrapK ? macroJump : (uint64_t)kRowBytes;
+                const unsigned char* nm = wMacro + (wrapT ? jump : 0);
+                const unsigned char* nn = wrapT ? nm : wNext + tapStride;
+                wMacro = more ? nm : wMacro;
+                wNext = more ? nn : wNext;
+                nTap = wrapT ? 0 : nTap + 1;
+                nKc = wrapK ? 0 : (wrapT ? nKc + 1 : nKc);
+            }
+            compute();
+            if constexpr (!(kAbl & 16))
+            {
+                if (dist > 1) wait_vm_const<NBI>(); else wait_vm_const<0>();
+                __syncthreads();
+            }
+            advance();
+        }
+    }
+    else
+    {
+        // band waves: the pieces of the next band, spread over the taps of this one; waited for at its last tap
+        for (int step = 0; step < nSteps; step++)
+        {
+            const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;
+            const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
+            if (macro + 1 < nMacro && !(kAbl & (1 | 64))) issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
+            compute();
+            if constexpr (!(kAbl & 16))
+            {
+                if (tap == ntap - 1) wait_vm_const<0>();
+                __syncthreads();
+            }
+            advance();
+        }
     }
 
     // ---- epilogue: registers -> out / ysum (8-byte channels-last stores), per-workgroup sum of squares ----------
@@ -433,7 +460,7 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
     const uint32_t hw = (uint32_t)(p.H * p.W);
     float sq = 0.f;
     #pragma unroll
-    for (int pb = 0; pb < 2; pb++)
+    for (int pb = 0; pb < PB; pb++)
     {
         const int64_t m = m0 + jrow[pb];
         if (m >= p.M) continue;
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
     if (p.msqPartial)
     {
         sq = wave_sum(sq);
-        float* red = reinterpret_cast<float*>(smem);        // the K loop ended with a barrier: LDS is free
+        float* red = reinterpret_cast<float*>(smem) + 64;   // the K loop ended with a barrier; LDS past the zero rows in use
         if (lane == 0) red[wave] = sq;
         __syncthreads();
         if (tid == 0)
@@ -499,7 +526,7 @@ __global__ __launch_bounds__(BM * 2) void conv3d_igemm_kernel(ConvArgs p)
 
 struct Plan
 {
-    int bm, bn, bandRows, nABuf, nBBuf, ldsBytes;
+    int bm, bn, pb, bandRows, nABuf, nBBuf, ldsBytes;
     int64_t mTiles;
 };
 
@@ -509,41 +536,53 @@ int env_int(const char* name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-// Tile choice. 256 pixels x 128 channels on 8 waves with the weight tiles prefetched two K-steps ahead when the
-// problem still gives every CU a workgroup; 128-pixel tiles (4 waves, two workgroups per CU) otherwise.
+// Tile choice (measured on MI355X, tools/conv_bench.py, profiles/r02_conv_variants.log): 128 pixels x 128 channels on
+// 4 waves with two independent workgroups per CU is the fastest form on every 512- / 256-channel layer (two
+// workgroups de-synchronise their barriers; 256-pixel tiles on 8 waves ran 20 % slower there). Wide frames
+// (W >= 32: the halo is half a 128-pixel tile) with >= 128 output channels take 256-pixel tiles.
+// LVG_CONV_BM / _BN / _NB override (A/B measurements).
 int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl)
 {
     const int reach = (kh / 2) * W + kw / 2;
     const int ntap = kh * kw;
     auto fill = [&](int bm, int bn, int nb)
     {
-        pl.bm = bm; pl.bn = bn;
+        pl.bm = bm; pl.bn = bn; pl.pb = 2;
         pl.bandRows = (int)lvg_ceil_div(bm + 2 * reach, 8) * 8;
         pl.nABuf = (kt * (Ci / kBK) > 1) ? 2 : 1;
         pl.nBBuf = ntap > 1 ? nb : 2;                                  // no spatial taps: everything one K-step ahead
         pl.mTiles = lvg_ceil_div(M, bm);
-        pl.ldsBytes = pl.nABuf * pl.bandRows * kRowBytes + pl.nBBuf * bn * kRowBytes;
+        pl.ldsBytes = kZeroBytes + pl.nABuf * pl.bandRows * kRowBytes + pl.nBBuf * bn * kRowBytes;
     };
     const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);
     int bn = (Co % 128 == 0) ? 128 : 64;
     if (fbn == 64 || (fbn == 128 && Co % 128 == 0)) bn = fbn;
-    int bm = (lvg_ceil_div(M, 256) * (Co / bn) >= 256) ? 256 : 128;
+    int bm = (2 * reach >= 64 && bn == 128 && lvg_ceil_div(M, 256) * (Co / bn) >= 512) ? 256 : 128;
     if (fbm == 128 || fbm == 256) bm = fbm;
-    int nb = bm == 256 ? 3 : 2;
+    int nb = 2;
     if (fnb == 2 || fnb == 3) nb = fnb;
     fill(bm, bn, nb);
     if (pl.ldsBytes > 160 * 1024 && nb == 3) fill(bm, bn, 2);
     if (pl.ldsBytes > 160 * 1024 && bm == 256) fill(128, bn, 2);
     if (pl.ldsBytes > 160 * 1024) return -1;
-    const int aw = ntap > 1 ? pl.bm / 128 : pl.bm / 32;                // band-staging waves (see `split` in the kernel)
-    if (lvg_ceil_div(pl.bandRows / 8, aw * ntap) > 4) return -1;       // MAXAI band pieces per wave and K-step
+    const int nw = pl.bm / (32 * pl.pb) * 2;
+    const int aw = ntap > 1 ? nw / 4 : nw;                             // band-staging waves (see `split` in the kernel)
+    if (lvg_ceil_div(pl.bandRows / 8, aw * ntap) > 6) return -1;       // MAXAI band pieces per wave and K-step
     return 0;
 }
 
-template <class T, int BM, int BN, bool GLDS>
+bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
+{
+    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32) return false;
+    const int64_t M = frames * h * w;
+    // 32-bit pixel indices (incl. the temporal halo) and 32-bit byte offsets into x
+    return (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * ci * 2 < ((int64_t)1 << 32);
+}
+
+template <class T, int BM, int BN, int PB>
 int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, GLDS>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, PB>;
     if (pl.ldsBytes > 64 * 1024)
     {
         // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
@@ -555,15 +594,15 @@ int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
         }
     }
     const int64_t blocks = pl.mTiles * a.nTiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM * 2), pl.ldsBytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM / (32 * PB) * 128), pl.ldsBytes, stream, a);
     return lvg_check_launch("conv3d_frames");
 }
 
-template <class T, bool GLDS>
+template <class T>
 int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
 {
-    if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, GLDS>(a, pl, s) : launch<T, 256, 64, GLDS>(a, pl, s);
-    return pl.bn == 128 ? launch<T, 128, 128, GLDS>(a, pl, s) : launch<T, 128, 64, GLDS>(a, pl, s);
+    if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, 2>(a, pl, s) : launch<T, 256, 64, 2>(a, pl, s);
+    return pl.bn == 128 ? launch<T, 128, 128, 2>(a, pl, s) : launch<T, 128, 64, 2>(a, pl, s);
 }
 
 } // namespace
@@ -571,7 +610,7 @@ int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
 extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
 {
     Plan pl;
-    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32 || frames * h * w >= (int64_t)1 << 31) return 0;
+    if (frames <= 0 || h <= 0 || w <= 0 || !shape_ok(frames, h, w, ci, co, kt, kh, kw)) return 0;
     if (make_plan(frames * h * w, w, ci, co, kt, kh, kw, pl) != 0) return 0;
     return pl.mTiles * (co / pl.bn);
 }
@@ -587,9 +626,11 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     LVG_REQUIRE(act == LVG_ACT_LINEAR || act == LVG_ACT_RELU || act == LVG_ACT_LRELU, "conv3d_frames: linear / relu / lrelu only");
     LVG_REQUIRE(lvg_aligned16(x) && lvg_aligned16(w) && lvg_aligned16(out) && lvg_aligned16(ysum) && lvg_aligned16(res)
                 && lvg_aligned16(pre) && lvg_aligned16(post) && lvg_aligned16(b), "conv3d_frames: pointers must be 16-byte aligned");
-    if (ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32 || frames * h * wd >= (int64_t)1 << 31)
+    LVG_REQUIRE(frame_shift > 0 && frames % frame_shift == 0, "conv3d_frames: frames must be a multiple of frame_shift");
+    if (!shape_ok(frames, h, wd, ci, co, kt, kh, kw))
     {
-        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d (Ci %% 64, Co %% 64, <= 32 taps)", ci, co, kt, kh, kw);
+        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d on %lld pixels (Ci %% 64, Co %% 64, <= 32 taps, 32-bit offsets)",
+                      ci, co, kt, kh, kw, (long long)(frames * h * wd));
         return LVG_ERR_UNSUPPORTED;
     }
     Plan pl;
@@ -613,9 +654,6 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     a.slopeNeg = act == LVG_ACT_LINEAR ? 1.f : (act == LVG_ACT_RELU ? 0.f : alpha);
     a.gain = gain;
     a.clamp = clamp;
-    const char* st = getenv("LVG_CONV_STAGE");
-    const bool glds = !(st && strcmp(st, "reg") == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == LVG_BF16) return glds ? launch_tile<bf16_t, true>(a, pl, s) : launch_tile<bf16_t, false>(a, pl, s);
-    return glds ? launch_tile<f16_t, true>(a, pl, s) : launch_tile<f16_t, false>(a, pl, s);
+    return dtype == LVG_BF16 ? launch_tile<bf16_t>(a, pl, s) : launch_tile<f16_t>(a, pl, s);
 }

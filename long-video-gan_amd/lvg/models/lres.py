@@ -362,6 +362,7 @@ SIDE_STREAM_TERMS = os.environ.get('LVG_SIDE_STREAM_TERMS', '1') == '1'
 # tap-stacked output channels + the tap-gather epilogue kernel. LVG_HAND_CONV=0 restores the MIOpen route; shapes the
 # kernel does not cover (float32, Ci or Co not a multiple of 64) take it anyway.
 HAND_CONV = os.environ.get('LVG_HAND_CONV', '1') == '1'
+HAND_CONV_MIN_TILES = int(os.environ.get('LVG_HAND_CONV_MIN_TILES', '128'))
 
 
 def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) -> bool:
@@ -369,7 +370,10 @@ def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) -> bool:
         return False
     if tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
         return False
-    return conv3d_frames.supported(_cl(x), weight)
+    if not conv3d_frames.supported(_cl(x), weight):
+        return False
+    # tiny layers (the 3x4 frames: 72 tiles on 256 CUs) stay on MIOpen: 173 us vs 138 us measured
+    return conv3d_frames.workgroups(x.shape[0], x.shape[2], x.shape[3], x.shape[1], weight.shape[0], *weight.shape[2:]) >= HAND_CONV_MIN_TILES
 
 
 SECOND_ORDER = False      # True inside `second_order()`: layers must build a graph that can be differentiated twice

