@@ -183,7 +183,8 @@ int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const v
  * store (16-bit channels-last frames; csrc/conv3d_igemm.hip). Replaces F.conv3d of the reference's
  * temporal_modulated_conv3d (model/generator_lres.py:119, padding = k // 2: :544-548) together with
  * lvg_tapconv_epilogue / lvg_modconv_epilogue:
- *   x [frames, H, W, ci]; w [kt, kh, kw, co, ci] (tap-major, input channel fastest)
+ *   x [frames, H, W, ci] with x_pixel_stride elements between pixels (0 = ci; larger when x is a channel slice of a
+ *   wider channels-last tensor); w [kt, kh, kw, co, ci] (tap-major, input channel fastest)
  *   acc[f,h,v,o] = sum_{dt,dh,dw,c} x[f + (dt-kt/2)*frame_shift, h+dh-kh/2, v+dw-kw/2, c] * w[dt,dh,dw,o,c]   (zero outside)
  *   out = clamp(act(acc * pre[f,o] + b[o] + res[f,h,v,o]) * gain, +-clamp) * post[f,o];  ysum = acc (may be NULL)
  *   msq_partial[i] = sum over workgroup i of (value before post)^2, i < lvg_conv3d_frames_workgroups(...)
@@ -194,7 +195,7 @@ int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const v
 int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
                       void* out, void* ysum, float* msq_partial,
                       int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
-                      int dtype, int act, float alpha, float gain, float clamp, void* stream);
+                      int64_t x_pixel_stride, int dtype, int act, float alpha, float gain, float clamp, void* stream);
 
 /* Workgroups lvg_conv3d_frames launches for this shape (= length of msq_partial); 0 = unsupported shape. */
 int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw);

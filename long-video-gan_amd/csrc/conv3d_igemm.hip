@@ -58,6 +58,7 @@ struct ConvArgs
     int64_t      M;            // frames * H * W
     int64_t      tShift;       // pixels between consecutive time steps (= clips * H * W)
     int          H, W, Ci, Co, kt, kh, kw;
+    int          xStride;      // elements between consecutive pixels of x (>= Ci: x may be a channel slice of a wider tensor)
     int          reach;        // (kh/2) * W + kw/2: pixels of halo on each side of a tile
     int          bandRows;     // BM + 2 * reach, rounded up to a multiple of 8
     int          nABuf;        // 2 when there is more than one band per tile
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
 
     const unsigned char* const xb = static_cast<const unsigned char*>(p.x);
     const unsigned char* const wb = static_cast<const unsigned char*>(p.w);
-    const uint32_t rowStride = (uint32_t)p.Ci * 2;                     // bytes per pixel / per weight row
+    const uint32_t rowStride = (uint32_t)p.Ci * 2;                     // bytes per weight row
+    const uint32_t xRowStride = (uint32_t)p.xStride * 2;               // bytes per pixel of x
 
     if (tid < kZeroBytes / 16) reinterpret_cast<uint4*>(smem)[tid] = make_uint4(0, 0, 0, 0);
 
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
                 int g = g0 + piece * 8 + (lane >> 3);
                 g = g < 0 ? 0 : (g > last ? last : g);
                 const uint32_t chunk = aChunkOff ^ (uint32_t)(((piece * 8 + (lane >> 3)) >> 1) & 7);
-                const uint32_t off = (uint32_t)g * rowStride + (uint32_t)kc * kRowBytes + chunk * 16;   // < 2^32 (host check)
+                const uint32_t off = (uint32_t)g * xRowStride + (uint32_t)kc * kRowBytes + chunk * 16;  // < 2^32 (host check)
                 dma16(xb, off, ldsBase + aOff + buf * aBytes + piece * 1024);
             }
         }
@@ -571,12 +573,12 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
     return 0;
 }
 
-bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
+bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw, int64_t xstride)
 {
     if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32) return false;
     const int64_t M = frames * h * w;
     // 32-bit pixel indices (incl. the temporal halo) and 32-bit byte offsets into x
-    return (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * ci * 2 < ((int64_t)1 << 32);
+    return xstride >= ci && xstride % 8 == 0 && (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * xstride * 2 < ((int64_t)1 << 32);
 }
 
 template <class T, int BM, int BN, int PB>
@@ -610,7 +612,7 @@ int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
 extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
 {
     Plan pl;
-    if (frames <= 0 || h <= 0 || w <= 0 || !shape_ok(frames, h, w, ci, co, kt, kh, kw)) return 0;
+    if (frames <= 0 || h <= 0 || w <= 0 || !shape_ok(frames, h, w, ci, co, kt, kh, kw, ci)) return 0;
     if (make_plan(frames * h * w, w, ci, co, kt, kh, kw, pl) != 0) return 0;
     return pl.mTiles * (co / pl.bn);
 }
@@ -618,7 +620,7 @@ extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, in
 extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
                                  void* out, void* ysum, float* msq_partial,
                                  int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
-                                 int dtype, int act, float alpha, float gain, float clamp, void* stream)
+                                 int64_t x_pixel_stride, int dtype, int act, float alpha, float gain, float clamp, void* stream)
 {
     LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv3d_frames: float16 / bfloat16 only (dtype %d)", dtype);
     LVG_REQUIRE(frames > 0 && h > 0 && wd > 0, "conv3d_frames: empty input");
@@ -627,9 +629,10 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     LVG_REQUIRE(lvg_aligned16(x) && lvg_aligned16(w) && lvg_aligned16(out) && lvg_aligned16(ysum) && lvg_aligned16(res)
                 && lvg_aligned16(pre) && lvg_aligned16(post) && lvg_aligned16(b), "conv3d_frames: pointers must be 16-byte aligned");
     LVG_REQUIRE(frame_shift > 0 && frames % frame_shift == 0, "conv3d_frames: frames must be a multiple of frame_shift");
-    if (!shape_ok(frames, h, wd, ci, co, kt, kh, kw))
+    if (x_pixel_stride == 0) x_pixel_stride = ci;
+    if (!shape_ok(frames, h, wd, ci, co, kt, kh, kw, x_pixel_stride))
     {
-        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d on %lld pixels (Ci %% 64, Co %% 64, <= 32 taps, 32-bit offsets)",
+        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d on %lld pixels (Ci %% 64, Co %% 64, <= 32 taps, pixel stride %% 8, 32-bit offsets)",
                       ci, co, kt, kh, kw, (long long)(frames * h * wd));
         return LVG_ERR_UNSUPPORTED;
     }
@@ -646,6 +649,7 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     a.M = frames * h * wd;
     a.tShift = frame_shift * h * wd;
     a.H = h; a.W = wd; a.Ci = ci; a.Co = co; a.kt = kt; a.kh = kh; a.kw = kw;
+    a.xStride = (int)x_pixel_stride;
     a.reach = (kh / 2) * wd + kw / 2;
     a.bandRows = pl.bandRows;
     a.nABuf = pl.nABuf;

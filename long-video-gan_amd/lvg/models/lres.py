@@ -362,15 +362,16 @@ SIDE_STREAM_TERMS = os.environ.get('LVG_SIDE_STREAM_TERMS', '1') == '1'
 # tap-stacked output channels + the tap-gather epilogue kernel. LVG_HAND_CONV=0 restores the MIOpen route; shapes the
 # kernel does not cover (float32, Ci or Co not a multiple of 64) take it anyway.
 HAND_CONV = os.environ.get('LVG_HAND_CONV', '1') == '1'
+HAND_CONV_DGRAD = os.environ.get('LVG_HAND_CONV_DGRAD', '1') == '1'      # data gradients on the same kernel
 HAND_CONV_MIN_TILES = int(os.environ.get('LVG_HAND_CONV_MIN_TILES', '128'))
 
 
-def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) -> bool:
+def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw, cl: bool = True) -> bool:
     if not (HAND_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)):
         return False
     if tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
         return False
-    if not conv3d_frames.supported(_cl(x), weight):
+    if not conv3d_frames.supported(_cl(x) if cl else x, weight):
         return False
     # tiny layers (the 3x4 frames: 72 tiles on 256 CUs) stay on MIOpen: 173 us vs 138 us measured
     return conv3d_frames.workgroups(x.shape[0], x.shape[2], x.shape[3], x.shape[1], weight.shape[0], *weight.shape[2:]) >= HAND_CONV_MIN_TILES
@@ -442,8 +443,16 @@ class _TapConvEpilogue(torch.autograd.Function):
         co, ci, kt, kh, kw = weight.shape
         need = ctx.needs_input_grad
         dz, d_pre, d_post, d_sum = tap_gather_backward(dout, ysum, pre, b, res, post, kt, n, act=act, clamp=clamp)
-        gx, gwst, _ = torch.ops.aten.convolution_backward(
-            _cl(dz), _cl(x), _cl(stack_taps(weight)), None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need[0], need[1], False])
+        dy = dz[:, (kt // 2) * co:(kt // 2 + 1) * co]          # the centre tap of the scattered gradient IS the gradient of the sum
+        hand = need[0] and HAND_CONV_DGRAD and _hand_conv_takes(dy, weight.transpose(0, 1), pad, cl=False)
+        if hand:
+            # data gradient on the hand-written kernel: the same convolution with the taps mirrored and the channel roles
+            # swapped, reading dy straight out of dz (pixel stride kt * Co); the weight gradient stays ONE MIOpen call
+            gx = conv3d_frames.conv3d_frames_forward(dy, weight.flip(2, 3, 4).transpose(0, 1), n, keep_sum=False)[0]
+        gxm, gwst, _ = torch.ops.aten.convolution_backward(
+            _cl(dz), _cl(x), _cl(stack_taps(weight)), None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need[0] and not hand, need[1], False])
+        if not hand:
+            gx = gxm
         gw = gwst.reshape(kt, co, ci, kh, kw).permute(1, 2, 0, 3, 4) if need[1] else None
         d_b = d_sum.sum(dim=0).to(b.dtype) if (b is not None and need[3]) else None
         d_res = None

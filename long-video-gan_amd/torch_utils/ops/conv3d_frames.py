@@ -30,11 +30,29 @@ def workgroups(frames, h, w, ci, co, kt, kh, kw):
     return int(_hip.lib().lvg_conv3d_frames_workgroups(frames, h, w, ci, co, kt, kh, kw))
 
 
+def _pixel_stride(x):
+    """Elements between consecutive pixels when x [(T N), C, H, W] is channels-last or a channel slice of a channels-last
+    tensor (what the kernel can walk), else None."""
+    if x.dim() != 4:
+        return None
+    f, c, h, w = x.shape
+    s = x.stride(3) if w > 1 else (x.stride(2) if h > 1 else x.stride(0))
+    if c > 1 and x.stride(1) != 1:
+        return None
+    if s < c or (w > 1 and x.stride(3) != s) or (h > 1 and x.stride(2) != w * s) or (f > 1 and x.stride(0) != h * w * s):
+        return None
+    return s
+
+
 def supported(x, weight):
-    """True when the hand-written kernel takes (x [(T N), Ci, H, W] channels-last, weight [Co, Ci, kt, kh, kw])."""
+    """True when the hand-written kernel takes (x [(T N), Ci, H, W] channels-last -- or a channel slice of a
+    channels-last tensor --, weight [Co, Ci, kt, kh, kw])."""
     if x.device.type != 'cuda' or x.dtype not in (torch.float16, torch.bfloat16) or weight.dtype != x.dtype:
         return False
-    if x.dim() != 4 or weight.dim() != 5 or not x.is_contiguous(memory_format=torch.channels_last):
+    if x.dim() != 4 or weight.dim() != 5:
+        return False
+    s = _pixel_stride(x)
+    if s is None or s % 8 != 0 or x.data_ptr() % 16 != 0 or x.shape[0] * x.shape[2] * x.shape[3] * s * 2 >= 2 ** 32:
         return False
     f, ci, h, w = x.shape
     co, ci2, kt, kh, kw = weight.shape
@@ -56,7 +74,7 @@ def conv3d_frames_forward(x, weight, shift, pre=None, b=None, res=None, post=Non
                           clamp=None, want_msq=False, keep_sum=True, packed=None):
     """-> (out, ysum | None, mean_square | None); out / ysum [(T N), Co, H, W] in x's dtype, channels-last.
 
-    x [(T N), Ci, H, W] channels-last (frame f = t * shift + n); weight [Co, Ci, kt, kh, kw] in x's dtype (`packed`:
+    x [(T N), Ci, H, W] channels-last or a channel slice of a channels-last tensor (frame f = t * shift + n); weight [Co, Ci, kt, kh, kw] in x's dtype (`packed`:
     the same weight already through `pack_weight`); pre / post float32 [(T N), Co]; b [Co]; res like out."""
     spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
     f, ci, h, w = x.shape
@@ -75,7 +93,7 @@ def conv3d_frames_forward(x, weight, shift, pre=None, b=None, res=None, post=Non
             rc = _hip.lib().lvg_conv3d_frames(
                 x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(res), _hip.ptr(post),
                 out.data_ptr(), _hip.ptr(ysum), _hip.ptr(part),
-                f, h, w, ci, co, kt, kh, kw, shift, _hip.dtype_code(x.dtype), spec.cuda_idx, alpha, gain, clamp, _hip.stream(x.device))
+                f, h, w, ci, co, kt, kh, kw, shift, _pixel_stride(x), _hip.dtype_code(x.dtype), spec.cuda_idx, alpha, gain, clamp, _hip.stream(x.device))
         _hip.check(rc, 'conv3d_frames')
         return out, ysum, (part.sum() / float(out.numel()) if want_msq else None)
     acc = _conv_ref(x, weight, shift)

@@ -118,6 +118,26 @@ def test_hip_matches_oracle_gpu(oracle, case, dtype):
 
 
 @pytest.mark.gpu
+def test_channel_slice_input_and_mirrored_weight_is_the_data_gradient_gpu():
+    """x may be a channel slice of a wider channels-last tensor (what the backward pass hands over: the centre tap of the
+    tap-stacked gradient), and conv(dy, mirrored + transposed weight) is the data gradient of the convolution."""
+    t, n, ci, co, h, w, kt = 4, 2, 64, 128, 9, 16, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(t * n, ci, h, w, generator=g).cuda().requires_grad_(True)
+    weight = (torch.randn(co, ci, kt, 3, 3, generator=g) / math.sqrt(ci * kt * 9)).cuda()
+    dz = torch.randn(t * n, kt * co, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    dy = dz[:, co:2 * co]
+    assert not dy.is_contiguous(memory_format=torch.channels_last) and cf.supported(dy, weight.transpose(0, 1).to(torch.bfloat16))
+    wt = weight.to(torch.bfloat16).flip(2, 3, 4).transpose(0, 1)
+    gx = cf.conv3d_frames_forward(dy, wt, n, keep_sum=False)[0]
+    gx_copy = cf.conv3d_frames_forward(dy.contiguous(memory_format=torch.channels_last), wt, n, keep_sum=False)[0]
+    assert torch.equal(gx, gx_copy)
+    y = cf._conv_ref(x, weight.to(torch.bfloat16).float(), n)
+    ref, = torch.autograd.grad(y, x, dy.float())
+    np.testing.assert_allclose(_np(gx), _np(ref), rtol=1.5 * 2.0 ** -8, atol=2e-3)
+
+
+@pytest.mark.gpu
 def test_tile_variants_agree_bitwise_gpu(monkeypatch):
     """Every tile shape / weight-ring depth runs the same arithmetic in the same order."""
     x, weight, pre, b, res, post = _case(3, 4, 2, 128, 128, 9, 16, 3, 3, 3, torch.bfloat16, 'cuda')
