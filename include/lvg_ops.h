@@ -189,7 +189,7 @@ int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const v
  *   out = clamp(act(acc * pre[f,o] + b[o] + res[f,h,v,o]) * gain, +-clamp) * post[f,o];  ysum = acc (may be NULL)
  *   msq_partial[i] = sum over workgroup i of (value before post)^2, i < lvg_conv3d_frames_workgroups(...)
  *                    (fixed summation order: reproducible; the caller adds them up; may be NULL)
- * Returns LVG_ERR_UNSUPPORTED when no kernel exists for the shape (ci % 64, co % 64, <= 32 taps, odd kernel
+ * Returns LVG_ERR_UNSUPPORTED when no kernel exists for the shape (ci % 64, co % 64, kt <= 7, kh * kw <= 25, odd kernel
  * sizes, frames*h*w < 2^31): the caller then takes the library convolution + lvg_tapconv_epilogue.
  */
 int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
         }
     };
 
-    // ---- which (temporal tap, spatial tap) pairs read a real pixel, per lane and pixel block -------------------
+    // ---- which temporal taps and which spatial taps read a real pixel, per lane and pixel block ------------------
     uint32_t vmask[PB];
     int jrow[PB];
     #pragma unroll
@@ -273,10 +273,11 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
                     const int y = hh + dh - (p.kh >> 1), x = ww + dw - (p.kw >> 1);
                     if (y >= 0 && y < p.H && x >= 0 && x < p.W) sp |= 1u << (dh * p.kw + dw);
                 }
+            mask = sp;                                                // bits 0 .. 24: spatial taps; bits 25 .. 31: temporal taps
             for (int dt = 0; dt < p.kt; dt++)
             {
                 const int64_t ms = m + (int64_t)(dt - pt) * p.tShift;
-                if (ms >= 0 && ms < p.M) mask |= sp << (dt * ntap);
+                if (ms >= 0 && ms < p.M) mask |= 1u << (25 + dt);
             }
         }
         vmask[pb] = mask;
@@ -321,13 +322,13 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
     auto compute = [&]() __attribute__((always_inline))
     {
         const int shift = dh * p.W + dw;
-        const int bit = dt * ntap + tap;
+        const int tbit = 25 + dt;
         uint32_t xBase[PB], xE[PB];
         #pragma unroll
         for (int pb = 0; pb < PB; pb++)
         {
             const uint32_t rb = (uint32_t)(jrow[pb] + shift);
-            const bool ok = (vmask[pb] >> bit) & 1u;
+            const bool ok = (vmask[pb] >> tap) & (vmask[pb] >> tbit) & 1u;
             xE[pb] = ((uint32_t)hi ^ ((rb >> 1) & 7u)) << 4;
             // masked lanes read zeros from the 256-byte zero page at the SAME bank position (row parity kept): the
             // conflict-free bank pattern of the group survives
@@ -575,7 +576,7 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
 
 bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw, int64_t xstride)
 {
-    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0 || kt * kh * kw > 32) return false;
+    if (ci <= 0 || co <= 0 || ci % kBK != 0 || co % 64 != 0 || kh * kw > 25 || kt > 7) return false;
     const int64_t M = frames * h * w;
     // 32-bit pixel indices (incl. the temporal halo) and 32-bit byte offsets into x
     return xstride >= ci && xstride % 8 == 0 && (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * xstride * 2 < ((int64_t)1 << 32);
@@ -632,7 +633,7 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     if (x_pixel_stride == 0) x_pixel_stride = ci;
     if (!shape_ok(frames, h, wd, ci, co, kt, kh, kw, x_pixel_stride))
     {
-        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d on %lld pixels (Ci %% 64, Co %% 64, <= 32 taps, pixel stride %% 8, 32-bit offsets)",
+        lvg_set_error("conv3d_frames: no kernel for Ci=%d Co=%d taps=%dx%dx%d on %lld pixels (Ci %% 64, Co %% 64, <= 7 x 25 taps, pixel stride %% 8, 32-bit offsets)",
                       ci, co, kt, kh, kw, (long long)(frames * h * wd));
         return LVG_ERR_UNSUPPORTED;
     }

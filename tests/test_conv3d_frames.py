@@ -95,6 +95,7 @@ GPU_CASES = [
     (2, 2, 64, 64, 18, 32, 1, 3, 3, False),          # W = 32: band of 194 rows
     (1, 2, 64, 64, 36, 64, 1, 3, 3, True),           # W = 64: band of 258 rows, single band
     (7, 1, 256, 128, 5, 8, 3, 3, 3, False),          # four chunks
+    (6, 2, 64, 128, 8, 8, 5, 3, 3, False),           # discriminator kernel: 5 temporal taps (45 taps in all)
 ]
 
 
@@ -176,6 +177,7 @@ FULL_SHAPES = [
     (80 * 8, 512, 512, 9, 16, 3, 3, 3, 8),
     (128 * 8, 128, 128, 18, 32, 1, 3, 3, 8),
     (128 * 8, 64, 64, 36, 64, 1, 3, 3, 8),
+    (128 * 8, 64, 64, 32, 32, 5, 3, 3, 8),           # discriminator block at 32 x 32
 ]
 
 

@@ -29,6 +29,8 @@ SHAPES = [
     (24, 512, 512, 3, 4, 3), (32, 512, 512, 5, 8, 3), (48, 512, 512, 5, 8, 3), (80, 512, 512, 9, 16, 3), (80, 512, 256, 9, 16, 3),
     (144, 256, 256, 9, 16, 3), (128, 256, 256, 9, 16, 1), (128, 256, 128, 9, 16, 1), (128, 128, 128, 18, 32, 1), (128, 128, 64, 18, 32, 1),
     (128, 64, 64, 36, 64, 1),
+    # discriminator (5 x 3 x 3)
+    (128, 64, 64, 32, 32, 5), (128, 64, 128, 32, 32, 5), (64, 128, 128, 16, 16, 5), (64, 128, 256, 16, 16, 5), (32, 256, 256, 8, 8, 5), (32, 256, 512, 8, 8, 5),
 ]
 
 
