@@ -20,6 +20,9 @@ from . import _hip
 from .modconv_epilogue import _init, _ref, _resolve
 
 
+stats = {'flops': 0, 'launches': 0}     # algorithmic work handed to the hand-written kernel (read by bench.py's FLOP tally)
+
+
 def pack_weight(weight):
     """[Co, Ci, kt, kh, kw] -> [kt, kh, kw, Co, Ci] contiguous (tap-major, input channel fastest)."""
     return weight.permute(2, 3, 4, 0, 1).contiguous()
@@ -95,6 +98,8 @@ def conv3d_frames_forward(x, weight, shift, pre=None, b=None, res=None, post=Non
                 out.data_ptr(), _hip.ptr(ysum), _hip.ptr(part),
                 f, h, w, ci, co, kt, kh, kw, shift, _pixel_stride(x), _hip.dtype_code(x.dtype), spec.cuda_idx, alpha, gain, clamp, _hip.stream(x.device))
         _hip.check(rc, 'conv3d_frames')
+        stats['flops'] += 2 * f * h * w * co * ci * kt * kh * kw
+        stats['launches'] += 1
         return out, ysum, (part.sum() / float(out.numel()) if want_msq else None)
     acc = _conv_ref(x, weight, shift)
     ysum = acc.to(x.dtype)
