@@ -100,6 +100,10 @@ template <> struct Mma<f16_t>
 #define LVG_CONV_ABL 0
 #endif
 constexpr int kAbl = LVG_CONV_ABL;
+#ifndef LVG_CONV_PIN
+#define LVG_CONV_PIN 1
+#endif
+constexpr bool kPinOrder = LVG_CONV_PIN != 0;
 constexpr int kBK = 64;       // input channels per K-step (one 128-byte LDS row)
 constexpr int kRowBytes = kBK * 2;
 constexpr int kZeroBytes = 1024;   // LDS [0, 1024): zeros (what masked lanes read); the tiles follow
@@ -133,7 +137,7 @@ template <int N> __device__ __forceinline__ void wait_vm_const()
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
-template <class T, int BM, int BN, int PB>
+template <class T, int BM, int BN, int PB, int NB>
 __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -171,7 +175,8 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
     const int nMacro = p.kt * nchunk;
     const int nSteps = nMacro * ntap;
     const int nAI = p.bandRows >> 3;                                   // band pieces in total
-    const int dist = p.nBBuf - 1;                                      // weight tiles are staged `dist` K-steps ahead
+    // weight-tile ring: NB slots with spatial taps (tiles staged NB - 1 K-steps ahead), 2 without (host sets nBBuf)
+    const int dist = p.nBBuf - 1;
     // Without spatial taps (one K-step per band) everything is staged by all waves one K-step ahead (host: nBBuf = 2).
     const bool split = ntap > 1;
     const int bWaves = split ? NWB : NW, aWaves = split ? NWA : NW, aWave0 = split ? NWB : 0;
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
 
     // ---- K loop: (dt, kc) = band, tap = spatial tap inside it --------------------------------------------------------
     int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
+    (void)dh;
     int bufNext = dist;                                               // ring slot the next staged weight tile goes to
     uint32_t curB = 0;                                                // byte offset of the current weight tile in the ring
     uint32_t curA = (uint32_t)aOff;                                   // byte offset of the current band
@@ -319,10 +325,9 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
 
     // One K-step of arithmetic: fragment addresses of this tap, then 4 x (fragment reads, MFMAs) with the reads of
     // sub-step ks + 1 issued ahead of the MFMAs of sub-step ks (two fragment register sets).
+    int shift = 0, tbit = 25;                                         // dh * W + dw and 25 + dt of the current K-step
     auto compute = [&]() __attribute__((always_inline))
     {
-        const int shift = dh * p.W + dw;
-        const int tbit = 25 + dt;
         uint32_t xBase[PB], xE[PB];
         #pragma unroll
         for (int pb = 0; pb < PB; pb++)
@@ -376,6 +381,20 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
                         acc[cb][pb][ks] += __uint_as_float(wf[ks & 1][cb].x ^ xf[ks & 1][pb].y ^ wf[ks & 1][cb].w ^ xf[ks & 1][pb].z);
             }
         }
+        // Pin the order the source states (hipcc otherwise re-uses ONE fragment register set and issues the reads of sub-step
+        // ks + 1 behind the MFMAs of sub-step ks, exposing the LDS latency four times per K-step): reads(0), then
+        // 3 x [reads(ks + 1), MFMAs(ks)], MFMAs(3).   masks: 0x100 = DS read, 0x8 = MFMA
+        if constexpr (kAbl == 0 && kPinOrder)
+        {
+            __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
+            #pragma unroll
+            for (int ks = 0; ks < kBK / 16 - 1; ks++)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
+        }
     };
     // counters of the next K-step
     auto advance = [&]() __attribute__((always_inline))
@@ -383,11 +402,12 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
         curB += bBytes;
         if (curB == ringBytes) curB = 0;
         if (++bufNext == p.nBBuf) bufNext = 0;
-        if (++dw == p.kw) { dw = 0; dh++; }
+        shift++;
+        if (++dw == p.kw) { dw = 0; dh++; shift += p.W - p.kw; }
         if (++tap == ntap)
         {
-            tap = 0; dh = 0; dw = 0; macro++;
-            if (++kc == nchunk) { kc = 0; dt++; }
+            tap = 0; dh = 0; dw = 0; shift = 0; macro++;
+            if (++kc == nchunk) { kc = 0; dt++; tbit++; }
             curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);  // nABuf == 1 only when there is one band
         }
     };
@@ -408,33 +428,47 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
     }
     else if (isB)
     {
-        // weight waves: NBI pieces per K-step, always (past the last tile the same tile is staged again into a ring slot
-        // nobody reads any more) -- no branches between the staging and the MFMAs, counted wait
-        for (int step = 0; step < nSteps; step++)
+        // Weight waves: NBI pieces per K-step, always (where no tile is left to stage an earlier one is staged again into a ring
+        // slot nobody reads any more): no branches between the staging and the MFMAs, counted wait. The taps of a band are two
+        // plain loops -- while the staged tile (NB - 1 K-steps ahead) still belongs to this band, and after it moved on to the
+        // next band -- so the per-step scalar work is the staging itself and a handful of counters.
+        constexpr int D = NB - 1;
+        const uint32_t ldsB0 = ldsBase + bOff;
+        uint32_t stageOff = (uint32_t)(D * bBytes);                    // ring offset of the slot being staged
+        auto kstep = [&]() __attribute__((always_inline))
         {
             if constexpr (!(kAbl & (1 | 128)))
             {
                 #pragma unroll
                 for (int i = 0; i < NBI; i++)
-                    dma16(wNext, bLaneOff[i], ldsBase + bOff + bufNext * bBytes + bPiece[i] * 1024);
-                const bool more = step + dist + 1 < nSteps;            // another tile after this one
-                const bool wrapT = nTap + 1 == ntap;
-                const bool wrapK = wrapT && (nKc + 1 == nchunk);
-                const uint64_t jump = wrapK ? macroJump : (uint64_t)kRowBytes;
-                const unsigned char* nm = wMacro + (wrapT ? jump : 0);
-                const unsigned char* nn = wrapT ? nm : wNext + tapStride;
-                wMacro = more ? nm : wMacro;
-                wNext = more ? nn : wNext;
-                nTap = wrapT ? 0 : nTap + 1;
-                nKc = wrapK ? 0 : (wrapT ? nKc + 1 : nKc);
+                    dma16(wNext, bLaneOff[i], ldsB0 + stageOff + bPiece[i] * 1024);
+                wNext += tapStride;
             }
             compute();
             if constexpr (!(kAbl & 16))
             {
-                if (dist > 1) wait_vm_const<NBI>(); else wait_vm_const<0>();
+                wait_vm_const<(D > 1 ? NBI : 0)>();
                 __syncthreads();
             }
-            advance();
+            stageOff += bBytes;
+            if (stageOff == ringBytes) stageOff = 0;
+            curB += bBytes;
+            if (curB == ringBytes) curB = 0;
+            tap++;
+            shift++;
+            if (++dw == p.kw) { dw = 0; dh++; shift += p.W - p.kw; }
+        };
+        // the prologue staged the first D tiles of band 0 through the generic path: wNext already points D taps in
+        for (macro = 0; macro < nMacro; macro++)
+        {
+            tap = 0; dh = 0; dw = 0; shift = 0;
+            curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
+            for (int t = 0; t < ntap - D; t++) kstep();
+            // the staged tile moves on to the next band (on the last band: back to this band's first tile, never read)
+            if (macro + 1 < nMacro) wMacro += (kc + 1 == nchunk) ? macroJump : (uint64_t)kRowBytes;
+            wNext = wMacro;
+            for (int t = 0; t < D; t++) kstep();
+            if (++kc == nchunk) { kc = 0; dt++; tbit++; }
         }
     }
     else
@@ -582,10 +616,10 @@ bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int 
     return xstride >= ci && xstride % 8 == 0 && (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * xstride * 2 < ((int64_t)1 << 32);
 }
 
-template <class T, int BM, int BN, int PB>
+template <class T, int BM, int BN, int PB, int NB>
 int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, PB>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB>;
     if (pl.ldsBytes > 64 * 1024)
     {
         // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
@@ -601,11 +635,18 @@ int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
     return lvg_check_launch("conv3d_frames");
 }
 
+template <class T, int NB>
+int launch_ring(const ConvArgs& a, const Plan& pl, hipStream_t s)
+{
+    if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, 2, NB>(a, pl, s) : launch<T, 256, 64, 2, NB>(a, pl, s);
+    return pl.bn == 128 ? launch<T, 128, 128, 2, NB>(a, pl, s) : launch<T, 128, 64, 2, NB>(a, pl, s);
+}
+
 template <class T>
 int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
 {
-    if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, 2>(a, pl, s) : launch<T, 256, 64, 2>(a, pl, s);
-    return pl.bn == 128 ? launch<T, 128, 128, 2>(a, pl, s) : launch<T, 128, 64, 2>(a, pl, s);
+    // kernels without spatial taps run the generic loop, which reads the ring depth (2) from the arguments
+    return pl.nBBuf == 3 ? launch_ring<T, 3>(a, pl, s) : launch_ring<T, 2>(a, pl, s);
 }
 
 } // namespace
