@@ -13,6 +13,8 @@
  *   lvg_conv3d_frames       (the dense contraction itself + the two epilogues above: F.conv3d of
  *                           temporal_modulated_conv3d, model/generator_lres.py:119, which the reference
  *                           hands to cuDNN)
+ *   lvg_video_to_uint8 / lvg_video_from_uint8  (utils.py:163 write_video_grid, dataset.py:81 read_frame: tensor code
+ *                           in the reference, no plugin)
  *   lvg_modconv_epilogue[_backward]  (no pybind counterpart: fuses the modulated-conv epilogue the
  *                           reference spells in Python, model/generator_lres.py:101-123,570-574)
  *
@@ -245,6 +247,19 @@ int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, const void* 
  */
 int lvg_adam_step(float* p, const float* g, float* m, float* v, float* p_ema, int64_t n,
                   float lr, float beta1, float beta2, float eps, int64_t step, float ema_weight, void* stream);
+
+/*
+ * The two ends of the pixel path, one HBM pass each (csrc/video_io.hip).
+ *   lvg_video_to_uint8:   video [n, c, t, h, w] (dtype) -> bytes [n, t, h, w, c] uint8 = (x * 127.5 + 128).clamp(0, 255)
+ *                         truncated: utils.py:163 / :203 (write_video_grid / save_image_grid) + the channel-last
+ *                         rearrangement of :171 / :209, bit-identical for float32 input.
+ *   lvg_video_from_uint8: bytes [n, t, h, w, c] uint8 -> video [n, c, t, h, w] (dtype) = 2 * float(x) / 255 - 1
+ *                         (dataset.py:81-83 read_frame), mirrored in x for samples with flip[i] != 0 (:93-94 x_flip;
+ *                         flip = device pointer to n bytes, or NULL).
+ * 1 <= c <= 4, w a multiple of 4; dense tensors.
+ */
+int lvg_video_to_uint8(const void* video, void* bytes, int64_t n, int c, int t, int h, int w, int dtype, void* stream);
+int lvg_video_from_uint8(const void* bytes, void* video, const uint8_t* flip, int64_t n, int c, int t, int h, int w, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,74 @@
+"""Checkpoint I/O of the training-step bodies (reference train_lres.py:165-178, video_gan_lres.py:218-233 `ckpt()`):
+the generator EMA alone (what `generate` loads) and the full training state -- G, D, both optimizers, step.
+
+The reference pickles module OBJECTS through `torch_utils.persistence` (the pickle embeds the model source). This
+repo's networks are state-dict compatible re-implementations, so a checkpoint here is (constructor kwargs, state dict)
+per network + the flat Adam moments, written with torch.save; reference-written pickles still load through
+`torch_utils.persistence` (tests/test_persistence.py) and their state dicts load into these networks."""
+
+from typing import Optional
+
+import torch
+
+
+def _module_state(module) -> Optional[dict]:
+    if module is None:
+        return None
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+def trainer_state(trainer, step: int) -> dict:
+    """Everything `load_trainer_state` needs to resume `trainer` bit-exactly (single rank; ranks hold identical copies)."""
+    return dict(format='lvg-train-1', step=int(step),
+                G=_module_state(trainer.G), D=_module_state(trainer.D), G_ema=_module_state(getattr(trainer, 'G_ema', None)),
+                G_opt=_cpu(trainer.G_opt.state_dict()), D_opt=_cpu(trainer.D_opt.state_dict()),
+                rng=dict(cpu=torch.get_rng_state()))
+
+
+def _cpu(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu().clone()
+    if isinstance(obj, dict):
+        return {k: _cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_cpu(v) for v in obj)
+    return obj
+
+
+def save_checkpoint(path, trainer, step: int) -> None:
+    torch.save(trainer_state(trainer, step), path)
+
+
+def save_G_ema(path, trainer, init_kwargs: Optional[dict] = None) -> None:
+    """The inference artefact: generator EMA weights + the constructor arguments to rebuild the network."""
+    net = trainer.G_ema if getattr(trainer, 'G_ema', None) is not None else trainer.G
+    torch.save(dict(format='lvg-G-1', init_kwargs=dict(init_kwargs or {}), state=_module_state(net)), path)
+
+
+def load_trainer_state(trainer, state: dict) -> int:
+    """Restore `trainer` in place from `trainer_state` / `save_checkpoint` output; returns the step to continue from."""
+    assert state.get('format') == 'lvg-train-1', 'not a training checkpoint of this repo'
+    with torch.no_grad():
+        trainer.G.load_state_dict(state['G'])
+        trainer.D.load_state_dict(state['D'])
+        if state.get('G_ema') is not None and getattr(trainer, 'G_ema', None) is not None:
+            trainer.G_ema.load_state_dict(state['G_ema'])
+    trainer.G_opt.load_state_dict(state['G_opt'])
+    trainer.D_opt.load_state_dict(state['D_opt'])
+    if 'rng' in state and 'cpu' in state['rng']:
+        torch.set_rng_state(state['rng']['cpu'])
+    return int(state['step'])
+
+
+def load_checkpoint(path, trainer) -> int:
+    return load_trainer_state(trainer, torch.load(path, map_location='cpu', weights_only=False))
+
+
+def load_G(path, factory):
+    """Rebuild a generator saved by `save_G_ema`: `factory(**init_kwargs)` -> module, weights loaded, eval mode, no grads
+    (reference utils.load_G, utils.py:53-56)."""
+    blob = torch.load(path, map_location='cpu', weights_only=False)
+    assert blob.get('format') == 'lvg-G-1'
+    net = factory(**blob['init_kwargs'])
+    net.load_state_dict(blob['state'])
+    return net.requires_grad_(False).eval()

@@ -151,6 +151,16 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
     keep_y = ('y' in spec.ref) or (act == 'linear' and clamp >= 0)
     empty = torch.empty([0])
 
+    def bias_grad(dx):
+        """dx summed over every dim but `dim`. Channels-last tensors with a handful of channels (ToRGB: 3) are summed as
+        a [rows, 64 * C] matrix first: the direct strided reduction of [1024, 3, 36, 64] bf16 took 793 us per step."""
+        c = dx.shape[dim] if dx.ndim > dim else 0
+        if dx.ndim == 4 and dim == 1 and 1 < c < 32 and dx.is_cuda and dx.is_contiguous(memory_format=torch.channels_last) \
+                and (dx.numel() // c) % 64 == 0:
+            rows = dx.permute(0, 2, 3, 1).reshape(-1, 64 * c)          # a view: channels-last memory order
+            return rows.sum(0, dtype=torch.float32).reshape(64, c).sum(0).to(dx.dtype)
+        return dx.sum([i for i in range(dx.ndim) if i != dim])
+
     class BiasActCuda(torch.autograd.Function):
         @staticmethod
         def forward(ctx, x, b): # pylint: disable=arguments-differ
@@ -171,7 +181,7 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx = dy if is_identity else BiasActCudaGrad.apply(dy, x, b, y)
             if ctx.needs_input_grad[1]:
-                db = dx.sum([i for i in range(dx.ndim) if i != dim])
+                db = bias_grad(dx)
             return dx, db
 
     class BiasActCudaGrad(torch.autograd.Function):
@@ -192,7 +202,7 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
             if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
                 d_x = _launch(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
             if spec.has_2nd_grad and ctx.needs_input_grad[2]:
-                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+                d_b = bias_grad(d_x)
             return d_dy, d_x, d_b, None
 
     _bias_act_cuda_cache[key] = BiasActCuda

@@ -255,3 +255,25 @@ def modconv2d_epilogue(y, demod, c_out):
     rc = lib().orc_modconv2d_epilogue(_dp(y), _dp(d), _dp(out), ctypes.c_int64(n), c_pad, c_out, ctypes.c_int64(h * w))
     assert rc == 0, rc
     return out
+
+
+def video_to_uint8(video):
+    """[N, C, T, H, W] float32 -> [N, T, H, W, C] uint8, (x * 127.5 + 128).clamp(0, 255) truncated (orc_video_to_uint8)."""
+    v = np.ascontiguousarray(video, dtype=np.float32)
+    n, c, t, h, w = v.shape
+    out = np.empty((n, t, h, w, c), dtype=np.uint8)
+    rc = lib().orc_video_to_uint8(v.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), c, t, h, w)
+    assert rc == 0
+    return out
+
+
+def video_from_uint8(frames, flip=None):
+    """[N, T, H, W, C] uint8 -> [N, C, T, H, W] float32, 2 * x / 255 - 1; samples with flip[i] != 0 mirrored in x."""
+    b = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, t, h, w, c = b.shape
+    out = np.empty((n, c, t, h, w), dtype=np.float32)
+    fl = None if flip is None else np.ascontiguousarray(flip, dtype=np.uint8)
+    rc = lib().orc_video_from_uint8(b.ctypes.data_as(ctypes.c_void_p), None if fl is None else fl.ctypes.data_as(ctypes.c_void_p),
+                                    out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), c, t, h, w)
+    assert rc == 0
+    return out

@@ -1,0 +1,176 @@
+"""Pixel path around the networks: display-byte conversion, dataset -> device float conversion,
+the sampling pipeline with streaming low-resolution generation, checkpoint round trip.
+
+CPU: oracle (C) vs the reference's tensor expressions (utils.py:163, dataset.py:81-83) -- bit-exact; this repo's dataset
+vs what the REFERENCE's VideoDataset returned for the committed tiny dataset (tests/golden/make_golden_dataset.py);
+streaming generation == one-shot generation; checkpoint resume. GPU: the HIP kernels vs the oracle, bit-exact, at small
+ragged sizes and at the BASELINE frame sizes (36x64, 144x256)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from lvg import checkpoint, generate, video_io
+from lvg.dataset import VideoDataset, VideoDatasetTwoRes
+
+
+def _video(seed, n, c, t, h, w, spread=1.3):
+    g = torch.Generator().manual_seed(seed)
+    v = (torch.rand(n, c, t, h, w, generator=g) * 2 - 1) * spread
+    v.view(-1)[:7] = torch.tensor([-1.0, 1.0, 0.0, -0.0, 1.0 - 2 ** -24, -1.0039216, 0.99607843])     # edge values of the formula
+    return v
+
+
+def test_oracle_bytes_equal_reference_expression_cpu(oracle):
+    v = _video(0, 2, 3, 3, 6, 8)
+    ref = (v * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 4, 1)                   # utils.py:163 + :171 layout
+    assert np.array_equal(oracle.video_to_uint8(v.numpy()), ref.numpy())
+    assert np.array_equal(video_io.video_to_uint8(v).numpy(), ref.numpy())
+
+
+def test_oracle_floats_equal_reference_expression_cpu(oracle):
+    g = torch.Generator().manual_seed(1)
+    fr = torch.randint(0, 256, (3, 2, 5, 8, 3), generator=g, dtype=torch.uint8)
+    fr.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)                                         # every byte value
+    flip = torch.tensor([0, 1, 1], dtype=torch.uint8)
+    ref = torch.stack([(2 * f.permute(3, 0, 1, 2).to(torch.float32) / 255 - 1) for f in fr])          # dataset.py:81-83 per frame, stacked :91
+    ref = torch.where(flip.bool().reshape(3, 1, 1, 1, 1), ref.flip(dims=(-1,)), ref)                # :93-94
+    got = oracle.video_from_uint8(fr.numpy(), flip.numpy())
+    assert got.dtype == np.float32 and np.array_equal(got, ref.numpy())
+    assert torch.equal(video_io.video_from_uint8(fr, flip), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 3, 3, 6, 8), (1, 1, 2, 5, 4), (1, 4, 1, 3, 12), (2, 3, 16, 36, 64), (1, 3, 8, 144, 256)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_hip_video_to_uint8_bit_exact_gpu(oracle, shape, dtype):
+    v = _video(2, *shape).to(dtype)
+    got = video_io.video_to_uint8(v.cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.video_to_uint8(v.float().numpy()))          # 16-bit inputs are widened first, on both sides
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 2, 5, 8, 3), (1, 2, 3, 4, 1), (2, 16, 36, 64, 3), (1, 8, 144, 256, 3)])
+def test_hip_video_from_uint8_bit_exact_gpu(oracle, shape):
+    g = torch.Generator().manual_seed(3)
+    fr = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    flip = (torch.arange(shape[0]) % 2).to(torch.uint8)
+    ref = oracle.video_from_uint8(fr.numpy(), flip.numpy())
+    assert np.array_equal(video_io.video_from_uint8(fr.cuda(), flip.cuda()).cpu().numpy(), ref)
+    assert np.array_equal(video_io.video_from_uint8(fr.cuda()).cpu().numpy(), oracle.video_from_uint8(fr.numpy()))
+    got16 = video_io.video_from_uint8(fr.cuda(), flip.cuda(), dtype=torch.bfloat16).float().cpu()
+    assert torch.equal(got16, torch.tensor(ref).to(torch.bfloat16).float())       # one rounding of the float32 value
+    # bytes -> floats -> bytes is the identity
+    assert torch.equal(video_io.video_to_uint8(video_io.video_from_uint8(fr.cuda())).cpu(), fr)
+
+
+def test_dataset_matches_reference_golden_cpu():
+    """Same files, same seeds, same torch random-number order as the reference's loader -> the same clips, bit for bit."""
+    g = load_golden('dataset')
+    root = os.path.join(GOLDEN, 'tiny_dataset')
+    ds = VideoDataset(root, seq_length=4, height=8, width=12, min_spacing=1, max_spacing=3, x_flip=True)
+    assert len(ds) == int(g['n_clips'])
+    torch.manual_seed(123)
+    for k in range(6):
+        item = ds.reference_item(k % len(ds))
+        assert item['spacing'] == int(g[f'one_{k}_spacing'])
+        assert np.array_equal(item['video'].numpy(), g[f'one_{k}_video'])
+    two = VideoDatasetTwoRes(root, seq_length=3, lr_height=8, lr_width=12, hr_height=16, hr_width=24, max_spacing=2, x_flip=True)
+    torch.manual_seed(7)
+    items = [two[k % len(two)] for k in range(4)]
+    batch = torch.utils.data.default_collate(items)
+    lr, hr = VideoDatasetTwoRes.to_videos(batch)
+    for k in range(4):
+        assert int(batch['spacing'][k]) == int(g[f'two_{k}_spacing'])
+        assert np.array_equal(lr[k].numpy(), g[f'two_{k}_lr']) and np.array_equal(hr[k].numpy(), g[f'two_{k}_hr'])
+
+
+@pytest.mark.gpu
+def test_dataset_batch_to_device_gpu():
+    g = load_golden('dataset')
+    ds = VideoDataset(os.path.join(GOLDEN, 'tiny_dataset'), seq_length=4, height=8, width=12, min_spacing=1, max_spacing=3, x_flip=True)
+    torch.manual_seed(123)
+    batch = torch.utils.data.default_collate([ds[k % len(ds)] for k in range(6)])
+    video = VideoDataset.to_video(batch, device='cuda')
+    for k in range(6):
+        assert np.array_equal(video[k].cpu().numpy(), g[f'one_{k}_video'])
+
+
+def _tiny_lres():
+    from lvg.models import lres
+    torch.manual_seed(0)
+    return lres.VideoGenerator().eval().requires_grad_(False)
+
+
+def test_streaming_lres_generation_equals_one_shot_cpu():
+    G = _tiny_lres()
+    with torch.no_grad():
+        emb = G.sample_temporal_emb(1, 64, torch.Generator().manual_seed(1))
+        full = G.forward_from_emb(emb, 64)
+        chunks = torch.cat(list(generate.lres_video_chunks(G, emb, 64, chunk=32)), dim=2)
+    assert chunks.shape == full.shape
+    assert float((chunks - full).abs().max()) < 1e-5
+
+
+def test_generate_video_lengths_and_bytes_cpu():
+    G = _tiny_lres()
+    segs = list(generate.generate_video(G, None, seq_length=40, seed=3, lres_chunk=32))
+    video = torch.cat(segs, dim=1)
+    assert video.dtype == torch.uint8 and video.shape == (1, 40, 36, 64, 3)
+    # the same frames as the reference's flow: G(1, ceil(40/16)*16) from ONE seeded generator, cropped, converted
+    with torch.no_grad():
+        ref = G(1, 48, generator_emb=torch.Generator().manual_seed(3))[:, :, :40]
+    assert torch.equal(video, video_io.video_to_uint8(ref))
+
+
+@pytest.mark.gpu
+def test_generate_video_with_super_resolution_gpu():
+    from lvg.models import lres, sres
+    torch.manual_seed(0)
+    G = lres.VideoGenerator().eval().requires_grad_(False).cuda()
+    S = sres.VideoGenerator().eval().requires_grad_(False).cuda()
+    ctx = S.temporal_context
+    items = list(generate.generate_video(G, S, seq_length=20, seed=5, segment_length=16, return_lres=True))
+    hr = torch.cat([h for h, _ in items], dim=1)
+    lr = torch.cat([l for _, l in items], dim=1)
+    assert hr.dtype == torch.uint8 and hr.shape == (1, 20, 144, 256, 3) and lr.shape == (1, 20, 36, 64, 3)
+    # reference flow (generate.py:56-88): one generator -> lres clip of 32 + 2 ctx frames -> sres segments -> crop
+    gen = torch.Generator('cuda').manual_seed(5)
+    with torch.no_grad():
+        lr_video = G(1, 32 + 2 * ctx, generator_emb=gen)
+        segs = torch.cat(list(S.sample_video_segments(lr_video, 16, generator_z=gen)), dim=2)[:, :, :20]
+    ref = video_io.video_to_uint8(segs)
+    assert (hr.int() - ref.int()).abs().max() <= 1 and (hr != ref).float().mean() < 1e-3          # same path twice: kernel-order noise only
+    assert torch.equal(lr, video_io.video_to_uint8(lr_video[:, :, ctx:ctx + 20]))
+
+
+def test_checkpoint_round_trip_resumes_cpu(tmp_path):
+    from lvg.train_lres import LowResTrainer
+    kw = dict(seq_length=16, device='cpu', G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=False)
+    torch.manual_seed(0)
+    a = LowResTrainer(**kw)
+    real = torch.rand(1, 3, 16, 36, 64) * 2 - 1
+    torch.manual_seed(1)
+    a.train_step(1, real)                                     # (steps 1, 2: no R1 pass -- keeps the CPU suite short)
+    path = tmp_path / 'ckpt.pt'
+    checkpoint.save_checkpoint(path, a, step=2)
+    checkpoint.save_G_ema(tmp_path / 'g.pt', a)
+    ema_at_save = [v.clone() for v in a.G_ema.state_dict().values()]
+    torch.manual_seed(5)
+    b = LowResTrainer(**kw)                                   # different init
+    assert checkpoint.load_checkpoint(path, b) == 2
+    for net in ('G', 'D', 'G_ema'):
+        for (k, x), (_, y) in zip(getattr(a, net).state_dict().items(), getattr(b, net).state_dict().items()):
+            assert torch.equal(x, y), (net, k)
+    torch.manual_seed(2)
+    a.train_step(2, real)
+    torch.manual_seed(2)
+    b.train_step(2, real)
+    for (k, x), (_, y) in zip(a.G.state_dict().items(), b.G.state_dict().items()):
+        assert torch.equal(x, y), k                           # same weights AND same optimizer moments -> same next step
+    from lvg.models import lres
+    G = checkpoint.load_G(tmp_path / 'g.pt', lres.VideoGenerator)
+    assert all(torch.equal(x, y) for x, y in zip(G.state_dict().values(), ema_at_save))
