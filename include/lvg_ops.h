@@ -199,6 +199,20 @@ int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void
                       int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
                       int64_t x_pixel_stride, int dtype, int act, float alpha, float gain, float clamp, void* stream);
 
+/*
+ * Weight gradient of lvg_conv3d_frames (csrc/conv3d_wgrad.hip; what autograd derives for the reference's F.conv3d,
+ * model/generator_lres.py:119, discriminator_lres.py:169): 3 x 3 spatial taps, kt <= 7 temporal taps, 16-bit
+ * channels-last frames whose width is 8 / 16 / 32 / 64, ci and co multiples of 64.
+ *   part[s, dt, dh*3+dw, o, c] = sum over the pixels of range s of dy[f,h,v,o] * x[f + (dt-kt/2)*frame_shift, h+dh-1, v+dw-1, c]
+ * part: float32 [splits, kt, 9, co, ci] with splits = lvg_conv3d_frames_wgrad_splits(...) (0 = no kernel for the
+ * shape); the caller adds the ranges (fixed order: reproducible). zeros: >= 128 zero bytes in device memory.
+ * x / dy may be channel slices of wider channels-last tensors (pixel strides in elements, 0 = dense).
+ */
+int lvg_conv3d_frames_wgrad(const void* x, const void* dy, float* part, const void* zeros,
+                            int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
+                            int64_t x_pixel_stride, int64_t dy_pixel_stride, int splits, int dtype, void* stream);
+int lvg_conv3d_frames_wgrad_splits(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw);
+
 /* Workgroups lvg_conv3d_frames launches for this shape (= length of msq_partial); 0 = unsupported shape. */
 int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw);
 

@@ -363,7 +363,28 @@ SIDE_STREAM_TERMS = os.environ.get('LVG_SIDE_STREAM_TERMS', '1') == '1'
 # kernel does not cover (float32, Ci or Co not a multiple of 64) take it anyway.
 HAND_CONV = os.environ.get('LVG_HAND_CONV', '1') == '1'
 HAND_CONV_DGRAD = os.environ.get('LVG_HAND_CONV_DGRAD', '1') == '1'      # data gradients on the same kernel
+HAND_CONV_WGRAD = os.environ.get('LVG_HAND_CONV_WGRAD', '1') == '1'      # weight gradients on csrc/conv3d_wgrad.hip
 HAND_CONV_MIN_TILES = int(os.environ.get('LVG_HAND_CONV_MIN_TILES', '128'))
+
+
+def _hand_conv_shape_ok(x: torch.Tensor, co: int, ci: int, weight: torch.Tensor, padding_hw) -> bool:
+    """Would the hand-written kernel take the DATA GRADIENT of conv(x, weight): a convolution of a [frames, Co, H, W] gradient
+    with the mirrored [Ci, Co, ...] weight (decided on shapes: the gradient tensor does not exist yet)."""
+    if not (HAND_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)) or tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
+        return False
+    f, _, h, w = x.shape
+    kt, kh, kw = weight.shape[2:]
+    if (f * h * w) * co * kt * 2 >= 2 ** 32:
+        return False
+    return conv3d_frames.workgroups(f, h, w, co, ci, kt, kh, kw) >= HAND_CONV_MIN_TILES
+
+
+def _hand_wgrad_shape_ok(x: torch.Tensor, co: int, weight: torch.Tensor, padding_hw) -> bool:
+    if not (HAND_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)) or tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
+        return False
+    f, ci, h, w = x.shape
+    kt, kh, kw = weight.shape[2:]
+    return conv3d_frames._pixel_stride(x) == ci and conv3d_frames.wgrad_splits(f, h, w, ci, co, kt, kh, kw) > 0
 
 
 def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw, cl: bool = True) -> bool:
@@ -442,18 +463,25 @@ class _TapConvEpilogue(torch.autograd.Function):
         n, pad, act, clamp = ctx.cfg
         co, ci, kt, kh, kw = weight.shape
         need = ctx.needs_input_grad
-        dz, d_pre, d_post, d_sum = tap_gather_backward(dout, ysum, pre, b, res, post, kt, n, act=act, clamp=clamp)
-        dy = dz[:, (kt // 2) * co:(kt // 2 + 1) * co]          # the centre tap of the scattered gradient IS the gradient of the sum
-        hand = need[0] and HAND_CONV_DGRAD and _hand_conv_takes(dy, weight.transpose(0, 1), pad, cl=False)
-        if hand:
-            # data gradient on the hand-written kernel: the same convolution with the taps mirrored and the channel roles
-            # swapped, reading dy straight out of dz (pixel stride kt * Co); the weight gradient stays ONE MIOpen call
+        xc = _cl(x)
+        hand_d = need[0] and HAND_CONV_DGRAD and _hand_conv_shape_ok(xc, co, ci, weight, pad)
+        hand_w = need[1] and HAND_CONV_WGRAD and _hand_wgrad_shape_ok(xc, co, weight, pad)
+        stacked = (need[0] and not hand_d) or (need[1] and not hand_w)      # MIOpen needs the gradient scattered over the taps
+        dz, d_pre, d_post, d_sum = tap_gather_backward(dout, ysum, pre, b, res, post, kt if stacked else 1, n, act=act, clamp=clamp)
+        dy = dz[:, (kt // 2) * co:(kt // 2 + 1) * co] if stacked else dz     # the centre tap of the scattered gradient IS the gradient of the sum
+        gx = gw = None
+        if hand_d:
+            # data gradient on the hand-written kernel: the same convolution with the taps mirrored and the channel roles swapped
             gx = conv3d_frames.conv3d_frames_forward(dy, weight.flip(2, 3, 4).transpose(0, 1), n, keep_sum=False)[0]
-        gxm, gwst, _ = torch.ops.aten.convolution_backward(
-            _cl(dz), _cl(x), _cl(stack_taps(weight)), None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need[0] and not hand, need[1], False])
-        if not hand:
-            gx = gxm
-        gw = gwst.reshape(kt, co, ci, kh, kw).permute(1, 2, 0, 3, 4) if need[1] else None
+        if hand_w:
+            gw = conv3d_frames.conv3d_frames_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
+        if stacked:
+            gxm, gwst, _ = torch.ops.aten.convolution_backward(
+                _cl(dz), xc, _cl(stack_taps(weight)), None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need[0] and not hand_d, need[1] and not hand_w, False])
+            if need[0] and not hand_d:
+                gx = gxm
+            if need[1] and not hand_w:
+                gw = gwst.reshape(kt, co, ci, kh, kw).permute(1, 2, 0, 3, 4)
         d_b = d_sum.sum(dim=0).to(b.dtype) if (b is not None and need[3]) else None
         d_res = None
         if res is not None and need[4]:

@@ -105,3 +105,60 @@ def conv3d_frames_forward(x, weight, shift, pre=None, b=None, res=None, post=Non
     ysum = acc.to(x.dtype)
     out, msq = _ref(acc, pre, b, post, act, alpha, gain, clamp, want_msq, res=res)
     return out.to(x.dtype), (ysum if keep_sum else None), msq
+
+
+# ----------------------------------------------------------------------------------------------------
+# Weight gradient (csrc/conv3d_wgrad.hip).
+
+_zero_pages = {}
+
+
+def _zeros(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return z
+
+
+def wgrad_splits(frames, h, w, ci, co, kt, kh, kw):
+    """Pixel ranges `lvg_conv3d_frames_wgrad` splits this shape into; 0 when there is no kernel for it."""
+    return int(_hip.lib().lvg_conv3d_frames_wgrad_splits(frames, h, w, ci, co, kt, kh, kw))
+
+
+def wgrad_supported(x, dy, kt, kh, kw):
+    if x.device.type != 'cuda' or x.dtype not in (torch.float16, torch.bfloat16) or dy.dtype != x.dtype:
+        return False
+    sx, sd = _pixel_stride(x), _pixel_stride(dy)
+    if sx is None or sd is None or sx % 8 or sd % 8 or x.data_ptr() % 16 or dy.data_ptr() % 16 or x.shape[2:] != dy.shape[2:] or x.shape[0] != dy.shape[0]:
+        return False
+    return _init() and wgrad_splits(x.shape[0], x.shape[2], x.shape[3], x.shape[1], dy.shape[1], kt, kh, kw) > 0
+
+
+def _wgrad_ref(x, dy, kt, kh, kw, shift):
+    """float32 weight gradient through autograd of the plain definition."""
+    co, ci = dy.shape[1], x.shape[1]
+    w = torch.zeros(co, ci, kt, kh, kw, dtype=torch.float32, device=x.device, requires_grad=True)
+    with torch.enable_grad():
+        y = _conv_ref(x, w, shift)
+    return torch.autograd.grad(y, w, dy.float())[0]
+
+
+def conv3d_frames_wgrad(x, dy, kt, kh, kw, shift):
+    """Weight gradient [Co, Ci, kt, kh, kw] (float32) of `conv3d_frames_forward`'s contraction:
+    x [(T N), Ci, H, W], dy [(T N), Co, H, W], both channels-last (or channel slices of channels-last tensors)."""
+    f, ci, h, w = x.shape
+    co = dy.shape[1]
+    if x.device.type == 'cuda' and _init():
+        assert wgrad_supported(x, dy, kt, kh, kw), 'conv3d_frames_wgrad: no hand-written kernel for this shape / dtype / layout'
+        splits = wgrad_splits(f, h, w, ci, co, kt, kh, kw)
+        part = torch.empty((splits, kt, kh * kw, co, ci), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _hip.lib().lvg_conv3d_frames_wgrad(
+                x.data_ptr(), dy.data_ptr(), part.data_ptr(), _zeros(x.device).data_ptr(),
+                f, h, w, ci, co, kt, kh, kw, shift, _pixel_stride(x), _pixel_stride(dy), splits, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+        _hip.check(rc, 'conv3d_frames_wgrad')
+        stats['flops'] += 2 * f * h * w * co * ci * kt * kh * kw
+        stats['launches'] += 1
+        gw = part.sum(0) if splits > 1 else part[0]                  # fixed summation order: reproducible
+        return gw.reshape(kt, kh, kw, co, ci).permute(3, 4, 0, 1, 2)
+    return _wgrad_ref(x, dy, kt, kh, kw, shift)

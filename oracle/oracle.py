@@ -233,6 +233,19 @@ def conv3d_frames(x, w, shift=1):
     return y
 
 
+def conv3d_frames_wgrad(x, dy, kt, kh, kw, shift=1):
+    """Weight gradient of `conv3d_frames` (orc_conv3d_frames_wgrad): x [frames, Ci, H, W], dy [frames, Co, H, W]
+    -> gw [Co, Ci, kt, kh, kw]."""
+    x, dy = _f64(x), _f64(dy)
+    f, ci, h, wd = x.shape
+    co = dy.shape[1]
+    gw = np.empty((co, ci, kt, kh, kw), dtype=np.float64)
+    rc = lib().orc_conv3d_frames_wgrad(_dp(x), _dp(dy), _dp(gw), ctypes.c_int64(f), ctypes.c_int(ci), ctypes.c_int(co), ctypes.c_int(h),
+                                       ctypes.c_int(wd), ctypes.c_int(kt), ctypes.c_int(kh), ctypes.c_int(kw), ctypes.c_int64(shift))
+    assert rc == 0, rc
+    return gw
+
+
 def modconv2d_prologue(x, cond, mod, c_pad):
     """cat(x, cond) * mod with zero channels up to c_pad. x may be None. NCHW in, NCHW out."""
     cond = _f64(cond)

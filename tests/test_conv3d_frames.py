@@ -138,6 +138,47 @@ def test_channel_slice_input_and_mirrored_weight_is_the_data_gradient_gpu():
     np.testing.assert_allclose(_np(gx), _np(ref), rtol=1.5 * 2.0 ** -8, atol=2e-3)
 
 
+def test_wgrad_definition_matches_oracle_cpu(oracle):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 3, 4, 8, generator=g)
+    dy = torch.randn(6, 5, 4, 8, generator=g)
+    gw = cf.conv3d_frames_wgrad(x, dy, 3, 3, 3, 2)
+    np.testing.assert_allclose(gw.numpy(), oracle.conv3d_frames_wgrad(x.numpy(), dy.numpy(), 3, 3, 3, shift=2), rtol=1e-4, atol=1e-5)
+
+
+WGRAD_CASES = [
+    # t, n, ci, co,  h,  w, kt     (K-step = 64 pixels = 64 / w image rows: frame changes inside a step for h % (64 / w) != 0)
+    (4, 2, 64, 64, 9, 16, 3),        # 4 rows per step, 9-row frames: steps straddle frames
+    (3, 2, 64, 128, 5, 8, 3),        # 8 rows per step, 5-row frames: up to two frame changes per step
+    (2, 2, 128, 64, 18, 32, 1),      # 2 rows per step
+    (1, 3, 64, 64, 36, 64, 1),       # 1 row per step, single band slot triple
+    (6, 2, 64, 64, 8, 8, 5),         # discriminator kernel, whole frame per step
+    (5, 1, 128, 192, 3, 16, 3),      # ragged: 15 rows -> partial last step
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_hip_wgrad_matches_oracle_gpu(oracle, case, dtype, monkeypatch):
+    t, n, ci, co, h, w, kt = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(t * n, ci, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    dz = torch.randn(t * n, 2 * co, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    dy = dz[:, co:]                                                     # a channel slice: pixel stride 2 * co
+    assert cf.wgrad_supported(x, dy, kt, 3, 3)
+    ref = oracle.conv3d_frames_wgrad(_np(x), _np(dy), kt, 3, 3, shift=n)
+    scale = np.abs(ref).max()
+    for splits in (None, 1, 3):
+        if splits is not None:
+            monkeypatch.setenv('LVG_WGRAD_SPLITS', str(splits))
+        gw = cf.conv3d_frames_wgrad(x, dy, kt, 3, 3, n)
+        assert gw.shape == (co, ci, kt, 3, 3) and gw.dtype == torch.float32
+        np.testing.assert_allclose(_np(gw), ref, rtol=1e-4, atol=2e-5 * scale)      # exact products, float32 accumulation
+    again = cf.conv3d_frames_wgrad(x, dy, kt, 3, 3, n)
+    assert torch.equal(gw, again)                                                   # no atomics: reproducible
+
+
 @pytest.mark.gpu
 def test_tile_variants_agree_bitwise_gpu(monkeypatch):
     """Every tile shape / weight-ring depth runs the same arithmetic in the same order."""
