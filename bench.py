@@ -122,7 +122,10 @@ class OpTimer:
             x, w = args[0], args[1]
             return 2 * x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3] * w.shape[4]
         wrap(conv3d_frames, 'conv3d_frames_forward', lambda a: 'conv3d_igemm', conv_flops)
-        self.flop_ops = {'conv3d_igemm'}
+        # conv3d_frames_wgrad(x, dy, kt, kh, kw, shift): the hand-written weight gradient (its own kernel, csrc/conv3d_wgrad.hip)
+        wrap(conv3d_frames, 'conv3d_frames_wgrad', lambda a: 'conv3d_wgrad',
+             lambda args, out: 2 * args[0].shape[0] * args[0].shape[2] * args[0].shape[3] * args[0].shape[1] * args[1].shape[1] * args[2] * args[3] * args[4])
+        self.flop_ops = {'conv3d_igemm', 'conv3d_wgrad'}
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step
