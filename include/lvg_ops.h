@@ -263,6 +263,20 @@ int lvg_adam_step(float* p, const float* g, float* m, float* v, float* p_ema, in
                   float lr, float beta1, float beta2, float eps, int64_t step, float ema_weight, void* stream);
 
 /*
+ * Weight side of a modulated convolution in one pass per direction (csrc/weight_prep.hip): the per-output-channel max
+ * normalisation, the 1 / sqrt(fan_in) scale, the sum of squares over the taps (demodulation term) and the cast to the
+ * compute dtype of model/generator_lres.py:97-119, written in the [taps, co, ci] layout lvg_conv3d_frames consumes.
+ *   forward:  w [co, ci, taps] f32 -> wp [taps, co, ci] (dtype), w2 [co, ci] f32 (may be NULL), amax [co] f32
+ *   backward: g = gradient of wp's elements addressed as g[co*s0 + ci*s1 + tap*s2] (dtype; g_strides = {s0, s1, s2} in
+ *             elements), g_w2 [co, ci] f32 or NULL -> dw [co, ci, taps] f32. Ties in max|w| share the gradient.
+ * ci * taps * 8 bytes must fit in LDS (150 KiB) and ci <= 1024.
+ */
+int lvg_weight_prep(const float* w, void* wp, float* w2, float* amax, int co, int ci, int taps, float scale, int normalize,
+                    int dtype, void* stream);
+int lvg_weight_prep_backward(const float* w, const float* amax, const void* g, const int64_t* g_strides, const float* g_w2,
+                             float* dw, int co, int ci, int taps, float scale, int normalize, int dtype, void* stream);
+
+/*
  * The two ends of the pixel path, one HBM pass each (csrc/video_io.hip).
  *   lvg_video_to_uint8:   video [n, c, t, h, w] (dtype) -> bytes [n, t, h, w, c] uint8 = (x * 127.5 + 128).clamp(0, 255)
  *                         truncated: utils.py:163 / :203 (write_video_grid / save_image_grid) + the channel-last

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 import torch_utils.distributed as dist_utils
 import contextlib
 
-from torch_utils.ops import bias_act, conv3d_frames, upfirdn2d
+from torch_utils.ops import bias_act, conv3d_frames, upfirdn2d, weight_prep
 from torch_utils.ops.modconv_epilogue import modconv_epilogue, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
@@ -584,20 +584,34 @@ def modulated_conv_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Te
     return y
 
 
-def modulation_terms(weight: torch.Tensor, style: torch.Tensor, demodulate: bool):
+# The weight side of `modulation_terms` (max normalisation, 1 / sqrt(fan_in), sum of squares over the taps, cast to the compute
+# dtype in the hand-written convolution's layout) as ONE HIP pass per direction (torch_utils/ops/weight_prep.py) instead of eight
+# tensor passes forward and about twice that backward per layer and step. LVG_WEIGHT_PREP=0 restores the tensor expressions.
+WEIGHT_PREP = os.environ.get('LVG_WEIGHT_PREP', '1') == '1'
+
+
+def modulation_terms(weight: torch.Tensor, style: torch.Tensor, demodulate: bool, dtype: Optional[torch.dtype] = None):
     """Small-tensor side of a modulated convolution in frames layout.
 
     weight [Co, Ci, kt, kh, kw], style [T, N, Ci] float32 -> (scaled weight, per-frame modulation
     [(T N), Ci], per-frame demodulation [(T N), Co] or None); same normalisations as
-    `modulated_conv_frames`, so conv(x * modulation, weight) * demodulation is the modulated conv."""
+    `modulated_conv_frames`, so conv(x * modulation, weight) * demodulation is the modulated conv.
+    With a 16-bit `dtype` the weight comes back already in that dtype."""
     t, n, ci = style.shape
+    scale = 1.0 / math.sqrt(weight[0].numel())
     if demodulate:
-        weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
         style = style / style.abs().amax(dim=(0, 2), keepdim=True)
-    weight = weight * (1.0 / math.sqrt(weight[0].numel()))
+    if WEIGHT_PREP and dtype is not None and demodulate and weight_prep.supported(weight, dtype):
+        weight, w2 = weight_prep.weight_prep(weight, scale, True, dtype, want_w2=True)
+    else:
+        if demodulate:
+            weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
+        weight = weight * scale
+        w2 = weight.square().sum(dim=(2, 3, 4)) if demodulate else None
+        if dtype is not None:
+            weight = weight.to(dtype)
     demod = None
     if demodulate:
-        w2 = weight.square().sum(dim=(2, 3, 4))
         demod = torch.matmul(style.square(), w2.t()).add(1e-8).rsqrt().reshape(t * n, -1)
     return weight, style.reshape(t * n, ci), demod
 
@@ -741,9 +755,9 @@ class Synthesis3dResBlock(nn.Module):
         convolutions, weights already in the compute dtype."""
         n, c, t = latent.shape
         lat = latent.permute(2, 0, 1).reshape(t * n, c)                         # rows ordered (t n), like the frames
-        w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True)
-        w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True)
-        return w0.to(dtype), mod_0, demod_0, w1.to(dtype), mod_1, demod_1
+        w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True, dtype)
+        w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True, dtype)
+        return w0, mod_0, demod_0, w1, mod_1, demod_1
 
     def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
                        out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None, terms=None) -> torch.Tensor:
@@ -1039,7 +1053,10 @@ class Conv3dLayer(nn.Module):
 
     def forward_frames(self, x: torch.Tensor, n: int) -> torch.Tensor:
         """Time-major frames layout: x [(T N), C, H, W]."""
-        w = (self.weight * self.weight_gain).to(x.dtype)
+        if WEIGHT_PREP and not SECOND_ORDER and weight_prep.supported(self.weight, x.dtype):
+            w = weight_prep.weight_prep(self.weight, self.weight_gain, False, x.dtype, want_w2=False)[0]     # scale + cast + layout: one pass
+        else:
+            w = (self.weight * self.weight_gain).to(x.dtype)
         b = self._bias.to(x.dtype) if self._bias is not None else None
         if not self.has_down:                   # conv -> bias / activation / clamp in one epilogue pass
             return temporal_conv_epilogue(x, w, n, self.padding[1:], b=b, act=self.activation, clamp=self.conv_clamp)
