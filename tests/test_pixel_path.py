@@ -146,7 +146,8 @@ def test_generate_video_with_super_resolution_gpu():
     # the same computation twice; an untrained network's output sits at 128.0 +- float16 noise, right on a truncation
     # boundary, so a byte may differ by one between two runs
     assert (hr.int() - ref.int()).abs().max() <= 1
-    assert torch.equal(lr, video_io.video_to_uint8(lr_video[:, :, ctx:ctx + 20]))
+    lr_ref = video_io.video_to_uint8(lr_video[:, :, ctx:ctx + 20])
+    assert (lr.int() - lr_ref.int()).abs().max() <= 1 and (lr != lr_ref).float().mean() < 0.02        # two runs of the float32 generator (library convolutions are not bit-reproducible)
 
 
 def test_checkpoint_round_trip_resumes_cpu(tmp_path):
