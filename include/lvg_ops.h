@@ -139,10 +139,12 @@ int lvg_filtered_lrelu_act(void* x, uint8_t* s, const int64_t xshape[4], const i
 /*
  * Epilogue of a style-modulated convolution fused with the prologue of the next one, one pass:
  *   out[f,c,p] = clamp(act(y[f,c,p] * pre[f,c] + b[c]) * gain, +-clamp) * post[f,c]
- *   msq[f]    += sum_{c,p} (value before `post`)^2        (optional input-magnitude statistic)
+ *   msq[s, f]  = partial sum of (value before `post`)^2   (optional input-magnitude statistic; see "slots")
  * y/out: dense [frames, channels, pixels] (channels_last = 0) or [frames, pixels, channels]
  * (channels_last = 1) in `dtype` (f32/f16/bf16); pre/post: float32 [frames, channels] or NULL (= 1);
- * b: [channels] in `dtype` or NULL; msq: float32 [frames], zero-initialised by the caller, or NULL.
+ * b: [channels] in `dtype` or NULL; msq: float32 [slots, frames] or NULL.
+ * Reductions are written as PARTIAL sums in `slots` = lvg_modconv_epilogue_slots(...) slices that the caller adds in a
+ * fixed order (no atomics: results are reproducible run to run; every element of every slice is written, no zero-fill).
  * act: LVG_ACT_LINEAR / RELU / LRELU (others: LVG_ERR_UNSUPPORTED). clamp < 0 disables clamping.
  * Replaces the reference's Python-level sequence  output * demodulation  (model/generator_lres.py:122),
  * bias_act (:570, torch_utils/ops/bias_act.cpp:32), input * style (:101) and the magnitude
@@ -156,13 +158,14 @@ int lvg_modconv_epilogue(const void* y, const float* pre, const void* b, const f
  * Backward of lvg_modconv_epilogue with the activation recomputed from y:
  *   du = dout * post * [|g| < clamp] * gain * act'(y*pre + b);   dy = du * pre
  *   d_pre[f,c] = sum_p du * y;  d_post[f,c] = sum_p dout * g;  d_sum[f,c] = sum_p du  (db = sum_f d_sum)
- * d_pre / d_post / d_sum: float32 [frames, channels], zero-initialised by the caller (d_pre / d_post
- * may be NULL when pre / post are).
+ * d_pre / d_post / d_sum: float32 [slots, frames, channels] partial sums (slots as above with backward = 1; d_pre /
+ * d_post may be NULL when pre / post are).
  */
 int lvg_modconv_epilogue_backward(const void* dout, const void* y, const float* pre, const void* b, const float* post,
                                   void* dy, float* d_pre, float* d_post, float* d_sum,
                                   int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
                                   float alpha, float gain, float clamp, void* stream);
+int lvg_modconv_epilogue_slots(int64_t frames, int channels, int pixels, int channels_last, int dtype, int backward);
 
 /*
  * Temporal-tap gather fused with the epilogue above (channels-last only). A kt x kh x kw convolution over
@@ -170,7 +173,8 @@ int lvg_modconv_epilogue_backward(const void* dout, const void* y, const float* 
  * z [frames, pixels, taps*channels] (tap-major); this entry point performs the temporal sum while applying
  * the epilogue:
  *   ysum[f,p,c] = sum_k z[f + (k - taps/2) * tap_shift, p, k*channels + c]     (frames outside -> 0)
- *   out[f,p,c]  = clamp(act(ysum * pre[f,c] + b[c] + res[f,p,c]) * gain, +-clamp) * post[f,c];  msq[f] as above
+ *   out[f,p,c]  = clamp(act(ysum * pre[f,c] + b[c] + res[f,p,c]) * gain, +-clamp) * post[f,c];  msq[s, f] as above with
+ *                 slots = lvg_tapconv_epilogue_slots(...) (also for d_pre / d_post / d_sum of the backward entry point)
  * res (layout of out) and ysum (saved for the backward pass) may be NULL. tap_shift = frames per time step.
  * Replaces, next to the sequence cited for lvg_modconv_epilogue, the accumulation of the per-tap
  * convolution outputs (the reference's conv3d does it inside cuDNN: model/generator_lres.py:119).
@@ -179,6 +183,7 @@ int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const v
                          void* out, void* ysum, float* msq,
                          int64_t frames, int channels, int pixels, int taps, int64_t tap_shift,
                          int dtype, int act, float alpha, float gain, float clamp, void* stream);
+int lvg_tapconv_epilogue_slots(int64_t frames, int channels, int pixels, int dtype);
 
 /*
  * Implicit-GEMM convolution on the matrix cores with the temporal-tap sum and the epilogue above fused on

@@ -95,7 +95,7 @@ template <> struct Mma<f16_t>
 };
 
 // Measurement builds only (-DLVG_CONV_ABL=bits): 1 no staging in the K loop, 2 no MFMA, 4 no fragment reads,
-// 16 no wait / barrier, 64 no band staging, 128 no weight staging. The shipped library is built with 0.
+// 16 no wait / barrier, 64 no band staging, 128 no weight staging, 256 no output stores. The shipped library is built with 0.
 #ifndef LVG_CONV_ABL
 #define LVG_CONV_ABL 0
 #endif
@@ -542,8 +542,11 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
                 uint2 ov, yv;
                 __builtin_memcpy(&ov, o4, 8);
                 __builtin_memcpy(&yv, y4, 8);
-                *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
-                if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
+                if (!(kAbl & 256) || sq == 12345.f)                      // (ablation 256: no output stores)
+                {
+                    *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
+                    if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
+                }
             }
     }
     if (p.msqPartial)

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_fwd_kernel(EpilogueArgs 
         sq = wave_sum(sq);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.msq + f, part[0] + part[1] + part[2] + part[3]);
+        if (threadIdx.x == 0) p.msq[(int64_t)blockIdx.x * p.frames + f] = (part[0] + part[1]) + (part[2] + part[3]);   // slot = chunk: no atomics
     }
 }
 
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_bwd_kernel(EpilogueArgs 
             s1 += red[1][e][c + r * cv];
             s2 += red[2][e][c + r * cv];
         }
-        const int64_t o = f * p.channels + c * V + e;
-        if (p.pre)  atomicAdd(p.d_pre + o, s0);
-        if (p.post) atomicAdd(p.d_post + o, s1);
-        atomicAdd(p.d_sum + o, s2);
+        const int64_t o = ((int64_t)blockIdx.x * p.frames + f) * p.channels + c * V + e;      // slot = chunk: the caller adds the chunks
+        if (p.pre)  p.d_pre[o] = s0;
+        if (p.post) p.d_post[o] = s1;
+        p.d_sum[o] = s2;
     }
 }
 
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void epilogue_plane_fwd_kernel(EpilogueAr
     if (p.msq)
     {
         sq = wave_sum(sq);
-        if (lane == 0 && sq != 0.f) atomicAdd(p.msq + f, sq);
+        if (lane == 0 && plane < p.frames * p.channels) p.msq[(plane - f * p.channels) * p.frames + f] = sq;   // slot = channel
     }
 }
 
@@ -297,6 +297,22 @@ int run(EpilogueArgs& p, int dtype, int act, bool backward, int channels_last, v
 }
 
 } // namespace
+
+// Partial-sum slots of the reductions (see include/lvg_ops.h): the channels-last kernels write one partial per chunk of a frame, the
+// plane kernels one mean-square partial per channel and final gradient sums.
+extern "C" int lvg_modconv_epilogue_slots(int64_t frames, int channels, int pixels, int channels_last, int dtype, int backward)
+{
+    if (frames <= 0 || channels <= 0 || pixels <= 0) return 1;
+    const int V = dtype == LVG_F32 ? 4 : 8;
+    const int cv = channels / V;
+    const bool vec = channels_last && channels % V == 0 && cv <= kThreads && (cv & (cv - 1)) == 0 && frames <= 65535;
+    if (vec)
+    {
+        const int64_t frameVecs = (int64_t)pixels * cv;
+        return (int)lvg_ceil_div(frameVecs, epilogue_chunk_vecs(frameVecs, frames));
+    }
+    return backward ? 1 : channels;
+}
 
 extern "C" int lvg_modconv_epilogue(const void* y, const float* pre, const void* b, const float* post, void* out, float* msq,
                                     int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void tapconv_fwd_kernel(EpilogueArgs p)
         sq = wave_sum(sq);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.msq + f, part[0] + part[1] + part[2] + part[3]);
+        if (threadIdx.x == 0) p.msq[(int64_t)blockIdx.x * p.frames + f] = (part[0] + part[1]) + (part[2] + part[3]);   // slot = chunk: no atomics
     }
 }
 
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(kThreads) void tapconv_bwd_kernel(EpilogueArgs p)
             s1 += red[1][e][cc + r * cv];
             s2 += red[2][e][cc + r * cv];
         }
-        const int64_t o = f * p.channels + cc * V + e;
-        if (p.pre)  atomicAdd(p.d_pre + o, s0);
-        if (p.post) atomicAdd(p.d_post + o, s1);
-        atomicAdd(p.d_sum + o, s2);
+        const int64_t o = ((int64_t)blockIdx.x * p.frames + f) * p.channels + cc * V + e;     // slot = chunk: the caller adds the chunks
+        if (p.pre)  p.d_pre[o] = s0;
+        if (p.post) p.d_post[o] = s1;
+        p.d_sum[o] = s2;
     }
 }
 
@@ -297,6 +297,14 @@ int run_taps(EpilogueArgs& p, int dtype, int act, bool backward, void* stream)
 }
 
 } // namespace
+
+extern "C" int lvg_tapconv_epilogue_slots(int64_t frames, int channels, int pixels, int dtype)
+{
+    if (frames <= 0 || channels <= 0 || pixels <= 0) return 1;
+    const int V = dtype == LVG_F32 ? 4 : 8;
+    const int64_t frameVecs = (int64_t)pixels * (channels / V);
+    return (int)lvg_ceil_div(frameVecs, epilogue_chunk_vecs(frameVecs, frames));
+}
 
 extern "C" int lvg_tapconv_epilogue(const void* z, const float* pre, const void* b, const void* res, const float* post,
                                     void* out, void* ysum, float* msq,

@@ -76,12 +76,25 @@ def _layout(t):
     return t.contiguous(), 0
 
 
+def _sum_slots(red, used):
+    """[3, slots, frames, channels] partial sums -> [3, frames, channels] (fixed order; unused rows are never read)."""
+    if red.shape[1] == 1:
+        return red[:, 0]
+    out = torch.empty((3,) + tuple(red.shape[2:]), dtype=red.dtype, device=red.device)
+    for i, u in enumerate(used):
+        if u:
+            torch.sum(red[i], dim=0, out=out[i])
+    return out
+
+
 def _launch_fwd(y, pre, b, post, cl, act_id, alpha, gain, clamp, want_msq):
     """One lvg_modconv_epilogue launch on y's device and the current stream -> (out, msq per frame | None)."""
     f, c, h, w = y.shape
     out = torch.empty_like(y)
     assert out.stride() == y.stride()
-    msq = torch.zeros(f, dtype=torch.float32, device=y.device) if want_msq else None
+    # partial sums per slot (chunk of a frame / channel plane): summed below in a fixed order -- no atomics, reproducible
+    slots = _hip.lib().lvg_modconv_epilogue_slots(f, c, h * w, cl, _hip.dtype_code(y.dtype), 0) if want_msq else 0
+    msq = torch.empty((slots, f), dtype=torch.float32, device=y.device) if want_msq else None
     with torch.cuda.device(y.device):
         rc = _hip.lib().lvg_modconv_epilogue(
             y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), out.data_ptr(), _hip.ptr(msq),
@@ -94,14 +107,15 @@ def _launch_bwd(dout, y, pre, b, post, cl, act_id, alpha, gain, clamp):
     """One lvg_modconv_epilogue_backward launch -> (dy, [d_pre, d_post, d_sum] float32 [3, frames, channels])."""
     f, c, h, w = y.shape
     dy = torch.empty_like(y)
-    red = torch.zeros(3, f, c, dtype=torch.float32, device=y.device)
+    slots = _hip.lib().lvg_modconv_epilogue_slots(f, c, h * w, cl, _hip.dtype_code(y.dtype), 1)
+    red = torch.empty(3, slots, f, c, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
         rc = _hip.lib().lvg_modconv_epilogue_backward(
             dout.data_ptr(), y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), dy.data_ptr(),
             red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
             f, c, h * w, cl, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
     _hip.check(rc, 'modconv_epilogue_backward')
-    return dy, red
+    return dy, _sum_slots(red, (pre is not None, post is not None, True))
 
 
 class _Epilogue(torch.autograd.Function):
@@ -185,7 +199,8 @@ def tap_gather_forward(z, pre, b, res, post, taps, shift, act='linear', alpha=No
         assert z.is_contiguous(memory_format=torch.channels_last), 'tap gather needs channels-last z'
         out = torch.empty((f, c, h, w), dtype=z.dtype, device=z.device, memory_format=torch.channels_last)
         ysum = torch.empty_like(out) if keep_sum else None
-        msq = torch.zeros(f, dtype=torch.float32, device=z.device) if want_msq else None
+        slots = _hip.lib().lvg_tapconv_epilogue_slots(f, c, h * w, _hip.dtype_code(z.dtype))
+        msq = torch.empty((slots, f), dtype=torch.float32, device=z.device) if want_msq else None
         if res is not None:
             res = res.contiguous(memory_format=torch.channels_last)
         with torch.cuda.device(z.device):
@@ -212,7 +227,8 @@ def tap_gather_backward(dout, ysum, pre, b, res, post, taps, shift, act='linear'
         dout = dout.contiguous(memory_format=torch.channels_last)
         assert ysum.is_contiguous(memory_format=torch.channels_last) and dout.dtype == ysum.dtype
         dz = torch.empty((f, taps * c, h, w), dtype=ysum.dtype, device=ysum.device, memory_format=torch.channels_last)
-        red = torch.zeros(3, f, c, dtype=torch.float32, device=ysum.device)
+        slots = _hip.lib().lvg_tapconv_epilogue_slots(f, c, h * w, _hip.dtype_code(ysum.dtype))
+        red = torch.empty(3, slots, f, c, dtype=torch.float32, device=ysum.device)
         if res is not None:
             res = res.contiguous(memory_format=torch.channels_last)
         with torch.cuda.device(ysum.device):
@@ -221,6 +237,7 @@ def tap_gather_backward(dout, ysum, pre, b, res, post, taps, shift, act='linear'
                 red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
                 f, c, h * w, taps, shift, _hip.dtype_code(ysum.dtype), spec.cuda_idx, alpha, gain, clamp, _hip.stream(ysum.device))
         _hip.check(rc, 'tapconv_epilogue_backward')
+        red = _sum_slots(red, (pre is not None, post is not None, True))
         return dz, (red[0] if pre is not None else None), (red[1] if post is not None else None), red[2]
     y = ysum.float()
     u = y if pre is None else y * pre[:, :, None, None]

@@ -118,3 +118,28 @@ def test_unsupported_activation_raises_gpu():
     y = torch.randn(2, 8, 4, 4, device='cuda')
     with pytest.raises(AssertionError):
         modconv_epilogue(y, act='tanh')
+
+
+@pytest.mark.gpu
+def test_reductions_are_reproducible_run_to_run_gpu():
+    """Frames large enough for several chunks per frame (several workgroups contribute to one [frame, channel] sum): the
+    partial sums are written per chunk and added in a fixed order -- two runs agree bit for bit (round-1 verdict item:
+    float atomics in the backward reductions)."""
+    import torch
+    from torch_utils.ops import modconv_epilogue as me
+    from torch_utils.ops import _hip
+    g = torch.Generator().manual_seed(0)
+    f, c, h, w = 4, 64, 72, 128
+    assert _hip.lib().lvg_modconv_epilogue_slots(f, c, h * w, 1, _hip.dtype_code(torch.bfloat16), 1) > 1
+    y = torch.randn(f, c, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    dout = torch.randn(f, c, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    pre = (0.5 + torch.rand(f, c, generator=g)).cuda()
+    post = torch.randn(f, c, generator=g).cuda()
+    b = torch.randn(c, generator=g).to(torch.bfloat16).cuda()
+    runs = []
+    for _ in range(3):
+        out, msq = me._launch_fwd(y, pre, b, post, 1, 3, 0.2, 2 ** 0.5, 256.0, True)
+        dy, red = me._launch_bwd(dout, y, pre, b, post, 1, 3, 0.2, 2 ** 0.5, 256.0)
+        runs.append((msq.sum().clone(), red.clone()))
+    for m, r in runs[1:]:
+        assert torch.equal(m, runs[0][0]) and torch.equal(r, runs[0][1])
