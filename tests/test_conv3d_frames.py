@@ -277,3 +277,27 @@ def test_generator_block_hand_conv_vs_miopen_route_gpu(monkeypatch):
         eh, em = rel(h, tr), rel(m, tr)
         assert eh < 8e-2 and eh <= 1.25 * em + 2e-3, (i, eh, em)           # bf16 gradients: both routes sit at 2-5 %
         assert rel(h, m) < 8e-2, (i, rel(h, m))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(80 * 8, 512, 512, 9, 16, 3, 8), (128 * 8, 64, 64, 36, 64, 1, 8), (128 * 8, 64, 128, 32, 32, 5, 8)])
+def test_weight_gradient_is_the_adjoint_of_the_forward_full_size_gpu(shape):
+    """Size-independent property at the BASELINE.json configs[1] sizes: <dy, conv(x, w)> = <wgrad(x, dy), w> for every w --
+    checks the split-K ranges, frame changes inside K-steps and clip borders of the weight-gradient kernel against the
+    forward kernel (itself checked bit-exactly at these sizes by the one-hot test)."""
+    f, ci, co, h, w, kt, n = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(f, ci, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(f, co, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    weight = (torch.randn(co, ci, kt, 3, 3, generator=g) / math.sqrt(ci * kt * 9)).to(torch.bfloat16).cuda()
+    y = cf.conv3d_frames_forward(x, weight, n, keep_sum=False)[0]                 # one bf16 rounding per output element
+    gw = cf.conv3d_frames_wgrad(x, dy, kt, 3, 3, n)
+    lhs = float((y.double() * dy.double()).sum())
+    rhs = float((gw.double() * weight.double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(lhs - rhs) < 2e-4 * scale, (lhs, rhs, scale)
+    # and against the library's weight gradient on the same tensors (bf16 result)
+    ref = torch.ops.aten.convolution_backward(
+        dy, x, weight[:, :, kt // 2].contiguous(memory_format=torch.channels_last), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    centre = gw[:, :, kt // 2]
+    assert float((centre - ref.float()).norm() / ref.float().norm()) < 1e-2       # the centre temporal tap is a plain 2-D weight gradient
