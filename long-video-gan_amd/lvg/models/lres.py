@@ -442,6 +442,8 @@ class _TapConvEpilogue(torch.autograd.Function):
         kt = weight.shape[2]
         # a bare temporal sum (no scale / bias / activation) IS its own saved sum: nothing extra is written
         plain = pre is None and b is None and res is None and post is None and act == 'linear' and clamp is None
+        if not any(ctx.needs_input_grad):
+            plain = True                                    # inference: no backward pass will read the saved sum -- do not write it
         if _hand_conv_takes(x, weight, padding_hw):
             # contraction, temporal sum and epilogue in ONE hand-written MFMA kernel (csrc/conv3d_igemm.hip)
             out, ysum, msq = conv3d_frames.conv3d_frames_forward(_cl(x), weight, n, pre, b, res, post, act=act, clamp=clamp,
