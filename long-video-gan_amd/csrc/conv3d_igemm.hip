@@ -95,7 +95,8 @@ template <> struct Mma<f16_t>
 };
 
 // Measurement builds only (-DLVG_CONV_ABL=bits): 1 no staging in the K loop, 2 no MFMA, 4 no fragment reads,
-// 16 no wait / barrier, 64 no band staging, 128 no weight staging, 256 no output stores. The shipped library is built with 0.
+// 16 no wait / barrier, 64 no band staging, 128 no weight staging, 256 no output stores, 512 direct 8-byte stores (no LDS transpose).
+// The shipped library is built with 0.
 #ifndef LVG_CONV_ABL
 #define LVG_CONV_ABL 0
 #endif
@@ -138,7 +139,7 @@ template <int N> __device__ __forceinline__ void wait_vm_const()
 }
 
 template <class T, int BM, int BN, int PB, int NB>
-__global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(ConvArgs p)
+__global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW  = BM / (32 * PB) * 2;      // waves: BM / (32 PB) along the pixels x 2 along the output channels
@@ -489,18 +490,58 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
         }
     }
 
-    // ---- epilogue: registers -> out / ysum (8-byte channels-last stores), per-workgroup sum of squares ----------
+    // ---- epilogue: registers -> LDS (wave-private rows of this wave's 64 / 32 output channels) -> 16-byte channels-last stores -------
+    // A result lane holds ONE pixel and 4 output channels per register quad: stored directly, a wave instruction writes 16 bytes to
+    // each of 32 cache lines (measured: 36 % of the kernel time on the 128-channel layers, ablation bit 256). Through LDS a wave
+    // instruction writes whole 128-byte (64-byte for 32-channel wave tiles) pixel rows instead.
+    // Staging rows have a pitch of row bytes + 16; the two 8-byte halves of a 16-byte chunk are exchanged in rows 16 .. 31 of a pixel
+    // block, which makes the 8-byte writes of the 32 lanes of a half wave hit 64 distinct banks (exchanged back, statically, on read).
     const T* bias = static_cast<const T*>(p.b);
     const T* res  = static_cast<const T*>(p.res);
     T* out  = static_cast<T*>(p.out);
     T* ysum = static_cast<T*>(p.ysum);
     const uint32_t hw = (uint32_t)(p.H * p.W);
+    constexpr int WCO = NCB * 32;                 // output channels of a wave tile
+    constexpr int RB = WCO * 2;                   // bytes of a staged pixel row
+    constexpr int PITCH = RB + 16;
+    constexpr int ROWS = PB * 32;                 // pixels of a wave tile
+    constexpr int CPR = RB / 16;                  // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;                 // rows per wave instruction on the way out
+    constexpr int NI = ROWS / RPI;
+    constexpr bool kLdsStore = !(kAbl & 512);
+    unsigned char* const stage = smem + wave * (ROWS * PITCH);
+    if constexpr (kLdsStore)
+    {
+        wait_vm_const<0>();                       // weight waves leave the K loop with re-staged tiles still in flight towards LDS
+        __syncthreads();
+    }
+    const int flipW = (l31 >> 4) & 1;
+    // 16-byte stores of the staged wave tile to `dst` (rows = pixels m0 + wr * ROWS + ..., this wave's channel range)
+    auto flush = [&](T* dst) __attribute__((always_inline))
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        #pragma unroll
+        for (int i = 0; i < NI; i++)
+        {
+            const int R = i * RPI + lane / CPR, c = lane % CPR;
+            uint4 v = *reinterpret_cast<const uint4*>(stage + R * PITCH + c * 16);
+            if (((i * RPI) >> 4) & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+            const int64_t m = m0 + wr * ROWS + R;
+            if (m < p.M) *reinterpret_cast<uint4*>(dst + m * p.Co + (co0 + wc * WCO + c * 8)) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     float sq = 0.f;
     #pragma unroll
     for (int pb = 0; pb < PB; pb++)
     {
-        const int64_t m = m0 + jrow[pb];
-        if (m >= p.M) continue;
+        const int64_t mt_ = m0 + jrow[pb];
+        const bool valid = mt_ < p.M;
+        if constexpr (!kLdsStore) { if (!valid) continue; }
+        const int64_t m = valid ? mt_ : p.M - 1;                     // rows past the end: computed on the last pixel's terms, never stored
         const int64_t f = (uint32_t)m / hw;
         #pragma unroll
         for (int cb = 0; cb < NCB; cb++)
@@ -528,6 +569,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
                     for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
                 }
                 T o4[4], y4[4];
+                float sqq = 0.f;
                 #pragma unroll
                 for (int e = 0; e < 4; e++)
                 {
@@ -535,19 +577,48 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128) void conv3d_igemm_kernel(Conv
                     const float u = fmaf(a, pre4[e], add4[e]);
                     float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
                     if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
-                    sq = fmaf(g, g, sq);
+                    if constexpr (kLdsStore) sqq = fmaf(g, g, sqq); else sq = fmaf(g, g, sq);
                     o4[e] = from_acc<T>(g * post4[e]);
                     y4[e] = from_acc<T>(a);
                 }
+                if (kLdsStore && valid) sq += sqq;
                 uint2 ov, yv;
                 __builtin_memcpy(&ov, o4, 8);
                 __builtin_memcpy(&yv, y4, 8);
-                if (!(kAbl & 256) || sq == 12345.f)                      // (ablation 256: no output stores)
+                if constexpr (kLdsStore)
+                    *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
+                else if (!(kAbl & 256) || sq == 12345.f)                 // (ablation 256: no output stores)
                 {
                     *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
                     if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
                 }
             }
+    }
+    if constexpr (kLdsStore)
+    {
+        if (!(kAbl & 256) || sq == 12345.f)
+        {
+            flush(out);
+            if (ysum)
+            {
+                #pragma unroll
+                for (int pb = 0; pb < PB; pb++)
+                    #pragma unroll
+                    for (int cb = 0; cb < NCB; cb++)
+                        #pragma unroll
+                        for (int qd = 0; qd < 4; qd++)
+                        {
+                            T y4[4];
+                            #pragma unroll
+                            for (int e = 0; e < 4; e++) y4[e] = from_acc<T>(acc[cb][pb][qd * 4 + e]);
+                            uint2 yv;
+                            __builtin_memcpy(&yv, y4, 8);
+                            *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = yv;
+                        }
+                flush(ysum);
+            }
+        }
+        __syncthreads();                          // the statistic below re-uses the front of the LDS
     }
     if (p.msqPartial)
     {
@@ -593,6 +664,8 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
         pl.nBBuf = ntap > 1 ? nb : 2;                                  // no spatial taps: everything one K-step ahead
         pl.mTiles = lvg_ceil_div(M, bm);
         pl.ldsBytes = kZeroBytes + pl.nABuf * pl.bandRows * kRowBytes + pl.nBBuf * bn * kRowBytes;
+        const int epilogue = (bm / 64 * 2) * 64 * (bn + 16);             // the epilogue stages every wave's 64-pixel x bn/2-channel tile, pitch bn + 16 bytes
+        if (pl.ldsBytes < epilogue) pl.ldsBytes = epilogue;
     };
     const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);
     int bn = (Co % 128 == 0) ? 128 : 64;
