@@ -282,6 +282,21 @@ int lvg_weight_prep_backward(const float* w, const float* amax, const void* g, c
                              float* dw, int co, int ci, int taps, float scale, int normalize, int dtype, void* stream);
 
 /*
+ * Style side of a modulated convolution (csrc/style_prep.hip): the per-sample max normalisation of the styles and the
+ * demodulation term of model/generator_lres.py:99 and :107-108, on styles in frames order s [t, n, ci] float32 (row
+ * r = t_index * n + n_index), with w2 [co, ci] = sum over the taps of the squared scaled weight (lvg_weight_prep).
+ *   forward:  mod [t*n, ci] = s / amax[n_index],  amax [n] = max |s| over (t, ci),
+ *             demod [t*n, co] = rsqrt(sum_ci w2[co, ci] * mod[r, ci]^2 + 1e-8)
+ *   backward: g_mod [t*n, ci] (or NULL), g_demod [t*n, co] -> ds [t, n, ci], dw2 [co, ci]; gm_scratch [t*n, ci] is
+ *             work space. Ties in max|s| share the gradient (torch.amax). Reductions run in a fixed order.
+ * ci and co multiples of 4, t * n < 2^24; all tensors float32, dense, 16-byte aligned.
+ */
+int lvg_style_prep(const float* s, const float* w2, float* mod, float* demod, float* amax, int t, int n, int ci, int co, void* stream);
+int lvg_style_prep_backward(const float* s, const float* amax, const float* w2, const float* mod, const float* demod,
+                            const float* g_mod, const float* g_demod, float* gm_scratch, float* ds, float* dw2,
+                            int t, int n, int ci, int co, void* stream);
+
+/*
  * The two ends of the pixel path, one HBM pass each (csrc/video_io.hip).
  *   lvg_video_to_uint8:   video [n, c, t, h, w] (dtype) -> bytes [n, t, h, w, c] uint8 = (x * 127.5 + 128).clamp(0, 255)
  *                         truncated: utils.py:163 / :203 (write_video_grid / save_image_grid) + the channel-last

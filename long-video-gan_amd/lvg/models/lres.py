@@ -28,7 +28,7 @@ import torch.nn.functional as F
 import torch_utils.distributed as dist_utils
 import contextlib
 
-from torch_utils.ops import bias_act, conv3d_frames, upfirdn2d, weight_prep
+from torch_utils.ops import bias_act, conv3d_frames, style_prep, upfirdn2d, weight_prep
 from torch_utils.ops.modconv_epilogue import modconv_epilogue, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
@@ -590,6 +590,9 @@ def modulated_conv_frames(x: torch.Tensor, weight: torch.Tensor, style: torch.Te
 # dtype in the hand-written convolution's layout) as ONE HIP pass per direction (torch_utils/ops/weight_prep.py) instead of eight
 # tensor passes forward and about twice that backward per layer and step. LVG_WEIGHT_PREP=0 restores the tensor expressions.
 WEIGHT_PREP = os.environ.get('LVG_WEIGHT_PREP', '1') == '1'
+# The style side (per-sample max normalisation, demodulation rsqrt(w2 . s^2 + 1e-8)) likewise (torch_utils/ops/style_prep.py):
+# ~8 launches forward and ~25 backward per layer become 2 + 3. LVG_STYLE_PREP=0 restores the tensor expressions.
+STYLE_PREP = os.environ.get('LVG_STYLE_PREP', '1') == '1'
 
 
 def modulation_terms(weight: torch.Tensor, style: torch.Tensor, demodulate: bool, dtype: Optional[torch.dtype] = None):
@@ -601,12 +604,15 @@ def modulation_terms(weight: torch.Tensor, style: torch.Tensor, demodulate: bool
     With a 16-bit `dtype` the weight comes back already in that dtype."""
     t, n, ci = style.shape
     scale = 1.0 / math.sqrt(weight[0].numel())
-    if demodulate:
-        style = style / style.abs().amax(dim=(0, 2), keepdim=True)
     if WEIGHT_PREP and dtype is not None and demodulate and weight_prep.supported(weight, dtype):
         weight, w2 = weight_prep.weight_prep(weight, scale, True, dtype, want_w2=True)
+        if STYLE_PREP and style_prep.supported(style, w2):
+            mod, demod = style_prep.style_prep(style, w2)          # max normalisation + demodulation: 2 launches, 3 backward
+            return weight, mod, demod
+        style = style / style.abs().amax(dim=(0, 2), keepdim=True)
     else:
         if demodulate:
+            style = style / style.abs().amax(dim=(0, 2), keepdim=True)
             weight = weight / weight.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
         weight = weight * scale
         w2 = weight.square().sum(dim=(2, 3, 4)) if demodulate else None

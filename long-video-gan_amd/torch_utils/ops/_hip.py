@@ -38,6 +38,8 @@ _SIGNATURES = {
     'lvg_conv3d_frames_wgrad_splits': [_i64] + [_i32] * 7,
     'lvg_weight_prep': [_vp] * 4 + [_i32, _i32, _i32, _f32, _i32, _i32, _vp],
     'lvg_weight_prep_backward': [_vp, _vp, _vp, ctypes.c_int64 * 3, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
+    'lvg_style_prep': [_vp] * 5 + [_i32] * 4 + [_vp],
+    'lvg_style_prep_backward': [_vp] * 10 + [_i32] * 4 + [_vp],
     'lvg_video_to_uint8': [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_video_from_uint8': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nchw_to_nhwc': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],

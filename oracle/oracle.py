@@ -270,6 +270,19 @@ def modconv2d_epilogue(y, demod, c_out):
     return out
 
 
+def style_prep(style, w2):
+    """Style side of the modulated convolution (orc_style_prep): style [T, N, Ci] (frames order), w2 [Co, Ci]
+    -> (modulation [(T N), Ci], demodulation [(T N), Co])."""
+    s, w2 = _f64(style), _f64(w2)
+    t, n, ci = s.shape
+    co = w2.shape[0]
+    mod = np.empty((t * n, ci), dtype=np.float64)
+    demod = np.empty((t * n, co), dtype=np.float64)
+    rc = lib().orc_style_prep(_dp(s), _dp(w2), _dp(mod), _dp(demod), ctypes.c_int(t), ctypes.c_int(n), ctypes.c_int(ci), ctypes.c_int(co))
+    assert rc == 0, rc
+    return mod, demod
+
+
 def video_to_uint8(video):
     """[N, C, T, H, W] float32 -> [N, T, H, W, C] uint8, (x * 127.5 + 128).clamp(0, 255) truncated (orc_video_to_uint8)."""
     v = np.ascontiguousarray(video, dtype=np.float32)

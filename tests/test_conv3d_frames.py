@@ -45,6 +45,12 @@ def test_oracle_matches_reference_modulated_conv3d(oracle, name):
     x, weight, style, bias, gain = [t.double().numpy() for t in inputs(name)]
     n = x.shape[0]
     w, mod, demod = _modulation(weight, style, float(gain))
+    # the oracle's style side (orc_style_prep, frames order) is the same function: pinned to the reference through this test
+    omod, odemod = oracle.style_prep(style.transpose(2, 0, 1), (w ** 2).sum(axis=(2, 3, 4)))
+    t_, ci_, co_ = style.shape[2], style.shape[1], w.shape[0]
+    np.testing.assert_allclose(omod.reshape(t_, n, ci_).transpose(1, 2, 0) * float(gain), mod, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(odemod.reshape(t_, n, co_).transpose(1, 2, 0), demod, rtol=1e-10, atol=0)
+    mod, demod = omod.reshape(t_, n, ci_).transpose(1, 2, 0) * float(gain), odemod.reshape(t_, n, co_).transpose(1, 2, 0)
     xm = x * mod[:, :, :, None, None]
     y = oracle.conv3d_frames(_frames(xm), w, shift=n)
     y = _video(y, n) * demod[:, :, :, None, None]
