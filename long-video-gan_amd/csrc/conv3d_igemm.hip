@@ -36,7 +36,11 @@
 //    workgroup and come out of L2 / Infinity Cache, a band is first-touch HBM data): with both on the same waves
 //    every K-step paid an HBM round trip. The last BM/128 waves therefore stage ONLY bands (waited for once per
 //    band), the others ONLY weight tiles (counted vmcnt per K-step, ring of 2 or 3 tiles);
-//  * a register-staged variant of the same schedule (global_load -> ds_write) ran at half the rate and was dropped.
+//  * a register-staged variant of the same schedule (global_load -> ds_write) ran at half the rate and was dropped;
+//  * so was a form without the LDS weight ring (every wave loading its own MFMA A-operand fragments from L2 into registers,
+//    one barrier per band instead of per K-step, 2 or 3 register sets): bit-identical results, 0.53-0.54 PFLOP/s against 0.99
+//    on the 512-channel layers (profiles/r02_conv_direct_weights.log) -- fragment-shaped loads (32 rows x 32 bytes per
+//    instruction, every weight byte fetched by two waves) saturate the texture-address path long before the matrix pipe.
 
 #include "epilogue_common.h"
 #include <stdlib.h>
@@ -129,13 +133,8 @@ __device__ __forceinline__ void dma16(const unsigned char* base, uint32_t laneOf
 
 template <int N> __device__ __forceinline__ void wait_vm_const()
 {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
 template <class T, int BM, int BN, int PB, int NB>
@@ -150,7 +149,6 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(C
     constexpr int NBI = (NBP + NWB - 1) / NWB;   // ... per wave, at most
     constexpr int MAXAI = 6;                     // band pieces per wave and K-step (host guarantees)
     constexpr int bBytes = BN * kRowBytes;
-    static_assert(NBI <= 6, "wait_vm_const covers up to 6 pieces in flight");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -8,4 +8,4 @@ for l in open('gpurun_out/window.log'):
     if l.startswith('{'):
         d=json.loads(l); print(d['ms_per_step']*d['steps'], d['steps'])") > gpurun_out/window_stats.csv 2>&1
 rm -f gpurun_out/prof_window/win_kernel_trace.csv
-head -50 gpurun_out/window_stats.csv | cut -c1-150
+(head -3 gpurun_out/window_stats.csv; grep "^#  " gpurun_out/window_stats.csv) | cut -c1-200
