@@ -78,6 +78,18 @@ int lvg_bias_act(const void* x, const void* b, const void* xref, const void* yre
                  float alpha, float gain, float clamp, void* stream);
 
 /*
+ * grad == 1 of lvg_bias_act on a channels-last stream (element i belongs to channel i % channels) that also leaves the
+ * bias gradient: db_partial [slots, channels] float32 holds, per workgroup, the sums of the (rounded) dx over the
+ * workgroup's pixels; db = sum over the slots (the reference reduces the stored dx in a second pass: bias_act.py:183
+ * `dx.sum(...)`). lvg_bias_act_grad_bias_slots returns the number of slots, or 0 when the form does not apply
+ * (channels must be a multiple of the 16-byte vector with 256 % (channels / vector) == 0, n >= 1024 vectors, n %
+ * channels == 0): use lvg_bias_act + a reduction then. Every activation except swish.
+ */
+int64_t lvg_bias_act_grad_bias_slots(int64_t n, int channels, int dtype);
+int lvg_bias_act_grad_bias(const void* dy, const void* xref, const void* yref, void* dx, float* db_partial,
+                           int64_t n, int channels, int dtype, int act, float alpha, float gain, float clamp, void* stream);
+
+/*
  * upsample (zero insertion) -> pad/crop -> FIR -> decimate, per channel.
  * Exactly one of {f2d} or {fx, fy} describes the filter:
  *   f2d != NULL : dense 2-D taps, f2d[fy_i * fstride_y + fx_i * fstride_x], size fh x fw

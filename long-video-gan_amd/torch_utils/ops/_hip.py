@@ -22,6 +22,8 @@ _i64x2 = ctypes.c_int64 * 2
 
 _SIGNATURES = {
     'lvg_bias_act': [_vp] * 6 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
+    'lvg_bias_act_grad_bias_slots': [_i64, _i32, _i32],
+    'lvg_bias_act_grad_bias': [_vp] * 5 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_upfirdn2d': [_vp] * 5 + [_i64x4] * 4 + [_i32, _i32, _i64, _i64] + [_i32] * 4 + [_i32, _i32, _i32, _f32, _i32, _vp],
     'lvg_filtered_lrelu': [_vp] * 6 + [_i64x4] * 4 + [_i32] * 6 + [_i64x2, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _vp],
     'lvg_filtered_lrelu_supported': [_i32] * 5,
@@ -60,7 +62,7 @@ def lib():
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int64 if name == 'lvg_conv3d_frames_workgroups' else ctypes.c_int
+            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_bias_act_grad_bias_slots') else ctypes.c_int
         _lib = handle
     return _lib
 

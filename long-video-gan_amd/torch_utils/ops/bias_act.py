@@ -4,6 +4,8 @@ torch_utils/ops/bias_act.py:52). GPU tensors run the HIP kernel `lvg_bias_act`
 (grad=1 / grad=2); CPU tensors and impl='ref' run the plain-PyTorch definition."""
 
 import numpy as np
+import os
+
 import torch
 
 import dnnlib
@@ -133,6 +135,32 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     _hip.check(rc, 'bias_act')
     return y
 
+# Bias gradient of a channels-last tensor in the SAME pass as dx (lvg_bias_act_grad_bias): the tensor reduction that the
+# reference runs on the stored dx (bias_act.py:183) re-read 300 MB per block-final layer of the generator (10 x 72 us per step).
+# First-order backward passes only (under create_graph the gradient must stay a differentiable function of dy).
+# LVG_BIAS_GRAD_FUSED=0 restores dx.sum().
+FUSED_BIAS_GRAD = os.environ.get('LVG_BIAS_GRAD_FUSED', '1') == '1'
+
+
+def _grad_bias_slots(dy, dim):
+    if not (FUSED_BIAS_GRAD and dy.is_cuda and dy.ndim == 4 and dim == 1 and dy.shape[1] > 1 and not torch.is_grad_enabled()):
+        return 0
+    if not dy.is_contiguous(memory_format=torch.channels_last):
+        return 0
+    return int(_hip.lib().lvg_bias_act_grad_bias_slots(dy.numel(), dy.shape[1], _hip.dtype_code(dy.dtype)))
+
+
+def _launch_grad_bias(dy, xref, yref, slots, act_id, alpha, gain, clamp):
+    """dx and the bias gradient (summed over the per-workgroup partial sums, float32 -> dy.dtype) from one launch."""
+    dx = torch.empty_like(dy)
+    part = torch.empty((slots, dy.shape[1]), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _hip.lib().lvg_bias_act_grad_bias(dy.data_ptr(), _hip.ptr(xref), _hip.ptr(yref), dx.data_ptr(), part.data_ptr(), dy.numel(),
+                                               dy.shape[1], _hip.dtype_code(dy.dtype), act_id, alpha, gain, clamp, _hip.stream(dy.device))
+    _hip.check(rc, 'bias_act_grad_bias')
+    return dx, part.sum(0).to(dy.dtype)
+
+
 _bias_act_cuda_cache = dict()
 
 def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
@@ -178,6 +206,10 @@ def _bias_act_cuda(dim=1, act='linear', alpha=None, gain=None, clamp=None):
             dy = dy.contiguous(memory_format=ctx.memory_format)
             x, b, y = ctx.saved_tensors
             dx = db = None
+            if ctx.needs_input_grad[1] and not is_identity and act != 'swish':
+                slots = _grad_bias_slots(dy, dim)
+                if slots > 0:                                           # dx and db from one pass over dy
+                    return _launch_grad_bias(dy, x if x.numel() else None, y if y.numel() else None, slots, spec.cuda_idx, alpha, gain, clamp)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx = dy if is_identity else BiasActCudaGrad.apply(dy, x, b, y)
             if ctx.needs_input_grad[1]:

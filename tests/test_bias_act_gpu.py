@@ -106,3 +106,39 @@ def test_large_stream_linearity_and_idempotence():
     assert float(c.abs().max()) == 0.75
     ref = torch.nn.functional.leaky_relu(x + b.view(1, -1, 1, 1, 1), 0.2) * np.sqrt(2)
     assert torch.allclose(c, ref.clamp(-0.75, 0.75), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape,act,clamp', [([64, 64, 36, 64], 'lrelu', 256.0), ([16, 128, 18, 32], 'lrelu', None), ([8, 8, 64, 64], 'relu', 0.5),
+                                             ([4, 512, 9, 16], 'tanh', None), ([32, 64, 16, 16], 'linear', 1.0)])
+def test_fused_bias_gradient_channels_last(dtype, shape, act, clamp, oracle, monkeypatch):
+    """dx + bias gradient from one pass (lvg_bias_act_grad_bias): dx is bit-identical to the two-pass form, db is the sum of the STORED
+    dx over the pixels (float64 reduction as the reference value; oracle for dx)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    b = (0.3 * torch.randn(shape[1], generator=g)).to(dtype).to(DEV)
+    dy = torch.randn(shape, generator=g).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(bias_act, 'FUSED_BIAS_GRAD', fused)
+        xq, bq = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = bias_act.bias_act(xq, bq, act=act, clamp=clamp)
+        out[fused] = torch.autograd.grad(y, [xq, bq], dy)
+    (dx_f, db_f), (dx_p, db_p) = out[True], out[False]
+    assert dx_f.is_contiguous(memory_format=torch.channels_last) and torch.equal(dx_f, dx_p)
+    ref_db = host(dx_f).sum(axis=(0, 2, 3))
+    scale = np.abs(ref_db).max()
+    tol = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]        # one rounding of the result to dtype
+    assert np.abs(host(db_f) - ref_db).max() <= tol * scale + 1e-6
+    assert np.abs(host(db_p) - ref_db).max() <= 4 * tol * scale + 1e-6                    # the tensor reduction accumulates in dtype order
+    ydet = bias_act.bias_act(x, b, act=act, clamp=clamp)
+    ref_dx = oracle.bias_act(host(dy), None, dim=1, act=act, clamp=clamp, grad=1, xref=host(x), yref=host(ydet))
+    np.testing.assert_allclose(host(dx_f), ref_dx, **TOL[dtype])
+    # under create_graph the gradient stays a differentiable function of dy (two-launch form), with the same values
+    monkeypatch.setattr(bias_act, 'FUSED_BIAS_GRAD', True)
+    xq, bq = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    dyq = dy.clone().requires_grad_(True)
+    y = bias_act.bias_act(xq, bq, act=act, clamp=clamp)
+    dx_g, db_g = torch.autograd.grad(y, [xq, bq], dyq, create_graph=True)
+    assert db_g.requires_grad and torch.equal(dx_g, dx_f)
+    assert np.abs(host(db_g) - ref_db).max() <= 4 * tol * scale + 1e-6
