@@ -292,6 +292,9 @@ int lvg_weight_prep(const float* w, void* wp, float* w2, float* amax, int co, in
                     int dtype, void* stream);
 int lvg_weight_prep_backward(const float* w, const float* amax, const void* g, const int64_t* g_strides, const float* g_w2,
                              float* dw, int co, int ci, int taps, float scale, int normalize, int dtype, void* stream);
+/* wp [taps, co, ci] (16-bit elements) -> wt [taps, ci, co] with the tap order reversed: the weight of the data-gradient
+ * convolution (mirrored taps, channel roles swapped: what lvg_conv3d_frames takes as `w` when it is run on dy). */
+int lvg_weight_dgrad_pack(const void* wp, void* wt, int taps, int co, int ci, void* stream);
 
 /*
  * Style side of a modulated convolution (csrc/style_prep.hip): the per-sample max normalisation of the styles and the

@@ -161,7 +161,36 @@ __global__ __launch_bounds__(kPrepThreads) void weight_prep_backward_kernel(Prep
     }
 }
 
+// wp [taps][Co][Ci] -> wt [taps][Ci][Co] with the tap order reversed: the weight of the data-gradient convolution (mirrored taps,
+// channel roles swapped) in the layout conv3d_igemm.hip consumes. 64 x 64 tiles through LDS, 16-bit elements moved as raw words.
+__global__ __launch_bounds__(256) void weight_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t* __restrict__ wt, int taps, int Co, int Ci)
+{
+    __shared__ uint16_t tile[64][66];
+    const int t = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+    const uint16_t* src = wp + (int64_t)t * Co * Ci;
+    uint16_t* dst = wt + (int64_t)(taps - 1 - t) * Ci * Co;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256)
+    {
+        const int r = i >> 6, c = i & 63;                              // r: co, c: ci (coalesced along ci)
+        tile[r][c] = (co0 + r < Co && ci0 + c < Ci) ? src[(int64_t)(co0 + r) * Ci + ci0 + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256)
+    {
+        const int r = i >> 6, c = i & 63;                              // r: ci, c: co (coalesced along co)
+        if (ci0 + r < Ci && co0 + c < Co) dst[(int64_t)(ci0 + r) * Co + co0 + c] = tile[c][r];
+    }
+}
+
 } // namespace
+
+extern "C" int lvg_weight_dgrad_pack(const void* wp, void* wt, int taps, int co, int ci, void* stream)
+{
+    LVG_REQUIRE(wp && wt && taps > 0 && co > 0 && ci > 0 && taps <= 65535, "weight_dgrad_pack: empty input");
+    hipLaunchKernelGGL(weight_dgrad_pack_kernel, dim3((unsigned)lvg_ceil_div(ci, 64), (unsigned)lvg_ceil_div(co, 64), (unsigned)taps), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint16_t*>(wp), static_cast<uint16_t*>(wt), taps, co, ci);
+    return lvg_check_launch("weight_dgrad_pack");
+}
 
 extern "C" int lvg_weight_prep(const float* w, void* wp, float* w2, float* amax, int co, int ci, int taps, float scale, int normalize,
                                int dtype, void* stream)

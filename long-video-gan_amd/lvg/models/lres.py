@@ -454,6 +454,7 @@ class _TapConvEpilogue(torch.autograd.Function):
             out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq, keep_sum=not plain)
         ctx.save_for_backward(x, weight, out if plain else ysum, pre, b, res, post)
         ctx.cfg = (n, list(padding_hw), act, clamp)
+        ctx.wt = getattr(weight, '_lvg_dgrad', None)        # weight_prep's data-gradient packing of this weight, if it made one
         if want_msq:
             ctx.mark_non_differentiable(msq)
         return out, msq
@@ -474,7 +475,11 @@ class _TapConvEpilogue(torch.autograd.Function):
         gx = gw = None
         if hand_d:
             # data gradient on the hand-written kernel: the same convolution with the taps mirrored and the channel roles swapped
-            gx = conv3d_frames.conv3d_frames_forward(dy, weight.flip(2, 3, 4).transpose(0, 1), n, keep_sum=False)[0]
+            wt = ctx.wt
+            if wt is not None and tuple(wt.shape) == (kt, kh, kw, ci, co) and wt.dtype == dy.dtype:
+                gx = conv3d_frames.conv3d_frames_forward(dy, wt.permute(3, 4, 0, 1, 2), n, keep_sum=False, packed=wt)[0]
+            else:
+                gx = conv3d_frames.conv3d_frames_forward(dy, weight.flip(2, 3, 4).transpose(0, 1), n, keep_sum=False)[0]
         if hand_w:
             gw = conv3d_frames.conv3d_frames_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
         if stacked:

@@ -40,6 +40,7 @@ _SIGNATURES = {
     'lvg_conv3d_frames_wgrad_splits': [_i64] + [_i32] * 7,
     'lvg_weight_prep': [_vp] * 4 + [_i32, _i32, _i32, _f32, _i32, _i32, _vp],
     'lvg_weight_prep_backward': [_vp, _vp, _vp, ctypes.c_int64 * 3, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
+    'lvg_weight_dgrad_pack': [_vp, _vp, _i32, _i32, _i32, _vp],
     'lvg_style_prep': [_vp] * 5 + [_i32] * 4 + [_vp],
     'lvg_style_prep_backward': [_vp] * 10 + [_i32] * 4 + [_vp],
     'lvg_video_to_uint8': [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],

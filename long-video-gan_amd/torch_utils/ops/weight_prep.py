@@ -92,10 +92,30 @@ def supported(weight, dtype):
     return ci <= 1024 and ci * taps * 8 <= 150 * 1024 and _init()
 
 
+def dgrad_pack(w16):
+    """Weight of the data-gradient convolution (taps mirrored, channel roles swapped) of a prepared weight, already in the layout the
+    hand-written convolution consumes: [*taps, Ci, Co] contiguous. `w16` must be the tap-major view `weight_prep` returns."""
+    co, ci = w16.shape[:2]
+    taps_shape = tuple(w16.shape[2:])
+    nd = len(taps_shape)
+    wp = w16.permute(*range(2, 2 + nd), 0, 1)
+    assert wp.is_contiguous(), 'dgrad_pack: tap-major weight expected'
+    wt = torch.empty(taps_shape + (ci, co), dtype=w16.dtype, device=w16.device)
+    with torch.cuda.device(w16.device):
+        rc = _hip.lib().lvg_weight_dgrad_pack(wp.data_ptr(), wt.data_ptr(), max(1, math.prod(taps_shape)), co, ci, _hip.stream(w16.device))
+    _hip.check(rc, 'weight_dgrad_pack')
+    return wt
+
+
 def weight_prep(weight, scale, normalize, dtype, want_w2=True):
     """-> (weight in `dtype` [Co, Ci, *taps] (tap-major memory on the GPU path), w2 [Co, Ci] float32 or None).
 
-    weight [Co, Ci, *taps] float32; `normalize`: divide each output channel by its max |w| first."""
+    weight [Co, Ci, *taps] float32; `normalize`: divide each output channel by its max |w| first.
+    While gradients are recorded, the returned 5-D weight carries `_lvg_dgrad`: the same weight packed for the data-gradient
+    convolution (one small launch here, next to the other weight-side work, instead of flip + transpose + copy in the backward pass)."""
     if supported(weight, dtype):
-        return _WeightPrep.apply(weight, float(scale), bool(normalize), dtype, bool(want_w2))
+        w16, w2 = _WeightPrep.apply(weight, float(scale), bool(normalize), dtype, bool(want_w2))
+        if torch.is_grad_enabled() and w16.ndim == 5 and w16.shape[0] % 64 == 0 and w16.shape[1] % 64 == 0:
+            w16._lvg_dgrad = dgrad_pack(w16.detach())
+        return w16, w2
     return _ref(weight, scale, normalize, dtype, want_w2)

@@ -58,3 +58,21 @@ def test_hip_weight_prep_forward_backward_gpu(shape, normalize, ties, dtype):
     assert torch.equal(again, da)
     out_only, none = wp.weight_prep(wa, scale, normalize, dtype, want_w2=False)
     assert none is None and torch.equal(out_only, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(64, 128, 3, 3, 3), (192, 64, 1, 3, 3), (128, 128, 5, 3, 3), (64, 64, 1, 1, 1)])
+def test_data_gradient_packing_gpu(shape):
+    """The weight packed for the data-gradient convolution (taps mirrored, channel roles swapped) is bit-identical to flip + transpose +
+    pack of the prepared weight; weight_prep attaches it while gradients are recorded, and only then."""
+    from torch_utils.ops import conv3d_frames as cf
+    w = _weights(3, shape[0], shape[1], shape[2:]).cuda().requires_grad_(True)
+    scale = 1 / math.sqrt(np.prod(shape[1:]))
+    w16, _ = wp.weight_prep(w, scale, True, torch.bfloat16)
+    wt = getattr(w16, '_lvg_dgrad', None)
+    assert wt is not None and tuple(wt.shape) == tuple(shape[2:]) + (shape[1], shape[0]) and wt.is_contiguous()
+    ref = cf.pack_weight(w16.detach().flip(2, 3, 4).transpose(0, 1))
+    assert torch.equal(wt, ref)
+    with torch.no_grad():
+        w16n, _ = wp.weight_prep(w, scale, True, torch.bfloat16)
+    assert getattr(w16n, '_lvg_dgrad', None) is None
