@@ -75,6 +75,9 @@ class OpTimer:
             streams = 2 + sum(1 for t in args[2:5] if t is not None and t.numel() > 0)
             return out.numel() * out.element_size() * streams
         wrap(bias_act, '_launch', lambda a: 'bias_act_fwd' if a[5] == 0 else 'bias_act_bwd', ba_bytes)
+        # bias_act._launch_grad_bias(dy, xref, yref, slots, ...): the backward launch that also leaves the bias gradient (dy, yref -> dx)
+        wrap(bias_act, '_launch_grad_bias', lambda a: 'bias_act_bwd',
+             lambda args, out: out[0].numel() * out[0].element_size() * (2 + sum(1 for t in args[1:3] if t is not None and t.numel() > 0)))
         # upfirdn2d._launch(x, f, ...): (N_in + N_out) * s
         wrap(upfirdn2d, '_launch', lambda a: 'upfirdn2d', lambda args, out: (args[0].numel() + out.numel()) * out.element_size())
         # modconv_epilogue: forward y -> out (2 streams), backward dout, y -> dy (3 streams)
