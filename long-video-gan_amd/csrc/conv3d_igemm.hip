@@ -109,6 +109,10 @@ constexpr int kAbl = LVG_CONV_ABL;
 #define LVG_CONV_PIN 1
 #endif
 constexpr bool kPinOrder = LVG_CONV_PIN != 0;
+#ifndef LVG_CONV_PRIO
+#define LVG_CONV_PRIO 1
+#endif
+constexpr int kPrio = LVG_CONV_PRIO;        // 1: the arithmetic of a K-step (fragment reads + MFMAs) runs at wave priority 1, staging / waits at 0
 constexpr int kBK = 64;       // input channels per K-step (one 128-byte LDS row)
 constexpr int kRowBytes = kBK * 2;
 constexpr int kZeroBytes = 1024;   // LDS [0, 1024): zeros (what masked lanes read); the tiles follow
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(C
                 for (int pb = 0; pb < PB; pb++) xf[set][pb] = make_uint4(ks, tap, pb, xBase[pb]);
             }
         };
+        if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(1);
         fetch(0, 0);
         #pragma unroll
         for (int ks = 0; ks < kBK / 16; ks++)
@@ -394,6 +399,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(C
             }
             __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
         }
+        if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(0);
     };
     // counters of the next K-step
     auto advance = [&]() __attribute__((always_inline))

@@ -71,6 +71,10 @@ template <> struct MmaW<f16_t>
     }
 };
 
+#ifndef LVG_WGRAD_PRIO
+#define LVG_WGRAD_PRIO 1
+#endif
+constexpr bool kWgradPrio = LVG_WGRAD_PRIO != 0;
 constexpr int kRow = 128;                 // bytes per LDS row: 64 channels
 constexpr int kDyBytes = 64 * kRow;       // dy tile: 64 pixels
 
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgradArgs p)
         if (grp + 1 < g1) stage(grp + 1, f1, y1, buf ^ 1);
 
         const uint32_t dyBuf = dyBase + buf * kDyBytes, bandBuf = bandBase + buf * bandBytes;
+        if constexpr (kWgradPrio) __builtin_amdgcn_s_setprio(1);      // the arithmetic outranks the other workgroup's staging on the SIMD
         #pragma unroll
         for (int ks = 0; ks < 4; ks++)
         {
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(WgradArgs p)
                 }
             }
         }
+        if constexpr (kWgradPrio) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         y0 = y1; f0 = f1;
@@ -289,11 +295,36 @@ bool wgrad_plan(int64_t frames, int h, int w, int ci, int co, int kt, int kh, in
     return pl.ldsBytes <= 160 * 1024 && frames * h * (int64_t)w * std::max(ci, co) * 2 < ((int64_t)1 << 40);
 }
 
+int compute_units()
+{
+    static int cus = 0;
+    if (cus == 0)
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        {
+            (void)hipGetLastError();
+            n = 256;                                                   // MI355X (also what a box without a GPU plans for)
+        }
+        cus = n;
+    }
+    return cus;
+}
+
+// Split K so that the launch is ONE full round of workgroups, rounded DOWN: 184 registers allow two workgroups per CU, the LDS band
+// of 64-pixel-wide frames only one. Measured (tools/gpu_wgrad_splits.sh, profiles/r02_wgrad_splits.log): a launch of 520 workgroups on
+// 512 slots takes 1.3x the time of one of 510 (the 8 stragglers run alone), and more splits than slots only add partial-sum traffic
+// (1024 splits of the 64-channel layer wrote and re-read 151 MB). LVG_WGRAD_SPLITS / LVG_WGRAD_TARGET override (measurements).
 int wgrad_splits(const WPlan& pl, int ci, int co, int kt)
 {
     const char* f = getenv("LVG_WGRAD_SPLITS");
+    const char* tg = getenv("LVG_WGRAD_TARGET");
     const int64_t tiles = (int64_t)(ci / 64) * (co / 64) * kt;
-    int64_t s = f && *f ? atoi(f) : lvg_ceil_div(1024, tiles);      // ~4 workgroups per CU in flight
+    const int perCU = std::max(1, std::min(2, (160 * 1024) / pl.ldsBytes));
+    const int64_t slots = (int64_t)compute_units() * perCU;
+    int64_t s = slots / tiles;
+    if (tg && *tg) s = lvg_ceil_div(atoi(tg), tiles);
+    if (f && *f) s = atoi(f);
     s = std::max<int64_t>(1, std::min<int64_t>(s, lvg_ceil_div(pl.groups, 8)));   // at least 8 K-steps per workgroup
     return (int)s;
 }
