@@ -177,6 +177,21 @@ int lvg_modconv_epilogue_backward(const void* dout, const void* y, const float* 
                                   void* dy, float* d_pre, float* d_post, float* d_sum,
                                   int64_t frames, int channels, int pixels, int channels_last, int dtype, int act,
                                   float alpha, float gain, float clamp, void* stream);
+
+/*
+ * Dual form of the two functions above for channels-last tensors: the forward pass also writes `mid` = the value before
+ * `post` (the activated tensor a skip connection reads, next to the modulated one the convolution reads: the block-final
+ * bias_act of model/generator_lres.py:575 and the next block's `input * style` of :101 in ONE pass, 3 streams instead of 4),
+ * the backward pass takes the gradients of both outputs: du = (dout * post + dmid) * [inside] * gain * act'(u) (4 streams
+ * instead of the 9 of modulate-backward + gradient sum + bias_act-backward). mid / dmid may be NULL.
+ */
+int lvg_modconv_epilogue_dual(const void* y, const float* pre, const void* b, const float* post, void* out, void* mid, float* msq,
+                              int64_t frames, int channels, int pixels, int dtype, int act,
+                              float alpha, float gain, float clamp, void* stream);
+int lvg_modconv_epilogue_dual_backward(const void* dout, const void* dmid, const void* y, const float* pre, const void* b, const float* post,
+                                       void* dy, float* d_pre, float* d_post, float* d_sum,
+                                       int64_t frames, int channels, int pixels, int dtype, int act,
+                                       float alpha, float gain, float clamp, void* stream);
 int lvg_modconv_epilogue_slots(int64_t frames, int channels, int pixels, int channels_last, int dtype, int backward);
 
 /*

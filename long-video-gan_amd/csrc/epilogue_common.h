@@ -34,6 +34,10 @@ struct EpilogueArgs
     int          taps;      // temporal taps stacked along z's channels (tap-major)
     int          tapCenter; // tap that reads the frame itself
     int64_t      tapShift;  // frames between consecutive time steps (= clips per batch in time-major layout)
+    // dual form (modconv_epilogue.hip, channels-last only): the value BEFORE `post` is a second output (the activated tensor that a
+    // skip connection reads next to the modulated one), and its gradient a second input of the backward pass
+    void*        mid;       // forward: clamp(act(y * pre + b) * gain) in T, or NULL
+    const void*  dmid;      // backward: gradient with respect to `mid`, or NULL
 };
 
 constexpr int kThreads = 256;

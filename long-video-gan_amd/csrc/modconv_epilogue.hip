@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_fwd_kernel(EpilogueArgs 
     const int64_t f  = blockIdx.y;
     const T* y   = static_cast<const T*>(p.y)   + f * p.frameVecs * V;
     T*       out = static_cast<T*>(p.out)       + f * p.frameVecs * V;
+    T*       mid = p.mid ? static_cast<T*>(p.mid) + f * p.frameVecs * V : nullptr;
     ChanVec<T> k;
     load_chan<T>(p, f, (threadIdx.x & (cv - 1)) * V, k);
 
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_fwd_kernel(EpilogueArgs 
     float sq = 0.f;
     auto one = [&](const Vec16<T>& in, int64_t i)
     {
-        Vec16<T> o;
+        Vec16<T> o, m;
         #pragma unroll
         for (int e = 0; e < V; e++)
         {
@@ -54,8 +55,10 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_fwd_kernel(EpilogueArgs 
             float g = epi_value<ACT>(to_acc(in.v[e]), k.pre[e], k.b[e], p.alpha, p.gain, p.clamp, inside);
             sq = fmaf(g, g, sq);
             o.v[e] = from_acc<T>(g * k.post[e]);
+            m.v[e] = from_acc<T>(g);
         }
         store_vec16<T>(out + i * V, o);
+        if (mid) store_vec16<T>(mid + i * V, m);
     };
     // U independent 16-byte loads are issued before any of them is consumed (a per-iteration bounds
     // check would serialise them: one load in flight per lane measured 3.2 TB/s).
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_bwd_kernel(EpilogueArgs 
     const T* y    = static_cast<const T*>(p.y)    + f * p.frameVecs * V;
     const T* dout = static_cast<const T*>(p.dout) + f * p.frameVecs * V;
     T*       dy   = static_cast<T*>(p.dy)         + f * p.frameVecs * V;
+    const T* dmid = p.dmid ? static_cast<const T*>(p.dmid) + f * p.frameVecs * V : nullptr;
     ChanVec<T> k;
     load_chan<T>(p, f, (threadIdx.x & (cv - 1)) * V, k);
 
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_bwd_kernel(EpilogueArgs 
 
     const int64_t first = (int64_t)blockIdx.x * p.chunkVecs;
     const int64_t last  = min(first + p.chunkVecs, p.frameVecs);
-    auto one = [&](const Vec16<T>& in, const Vec16<T>& go, int64_t i)
+    auto one = [&](const Vec16<T>& in, const Vec16<T>& go, const Vec16<T>& gm, int64_t i)
     {
         Vec16<T> o;
         #pragma unroll
@@ -108,7 +112,9 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_bwd_kernel(EpilogueArgs 
             const float u = fmaf(yv, k.pre[e], k.b[e]);
             bool inside;
             const float g = epi_value<ACT>(yv, k.pre[e], k.b[e], p.alpha, p.gain, p.clamp, inside);
-            const float du = inside ? gv * k.post[e] * p.gain * act_slope<ACT>(u, p.alpha) : 0.f;
+            // gradient of the value before `post`: through `out` (x post) and, in the dual form, directly through `mid`
+            const float gg = dmid ? fmaf(gv, k.post[e], to_acc(gm.v[e])) : gv * k.post[e];
+            const float du = inside ? gg * p.gain * act_slope<ACT>(u, p.alpha) : 0.f;
             aPost[e] = fmaf(gv, g, aPost[e]);
             aPre[e]  = fmaf(du, yv, aPre[e]);
             aSum[e] += du;
@@ -120,17 +126,23 @@ __global__ __launch_bounds__(kThreads) void epilogue_cl_bwd_kernel(EpilogueArgs 
     int64_t i = first + threadIdx.x;
     for (; i + (U - 1) * kThreads < last; i += U * kThreads)
     {
-        Vec16<T> in[U], go[U];
+        Vec16<T> in[U], go[U], gm[U];
         #pragma unroll
         for (int u = 0; u < U; u++)
         {
             in[u] = load_vec16<T>(y + (i + u * kThreads) * V);
             go[u] = load_vec16<T>(dout + (i + u * kThreads) * V);
+            if (dmid) gm[u] = load_vec16<T>(dmid + (i + u * kThreads) * V);
         }
         #pragma unroll
-        for (int u = 0; u < U; u++) one(in[u], go[u], i + u * kThreads);
+        for (int u = 0; u < U; u++) one(in[u], go[u], gm[u], i + u * kThreads);
     }
-    for (; i < last; i += kThreads) one(load_vec16<T>(y + i * V), load_vec16<T>(dout + i * V), i);
+    for (; i < last; i += kThreads)
+    {
+        Vec16<T> gm1;
+        if (dmid) gm1 = load_vec16<T>(dmid + i * V);
+        one(load_vec16<T>(y + i * V), load_vec16<T>(dout + i * V), gm1, i);
+    }
 
     // Block reduction over the threads that share a channel-vector (t, t + cv, t + 2cv, ...):
     // red[q][e][t] is written conflict-free (t fastest); reader j owns channel (j % cv) * V + j / cv.
@@ -242,7 +254,7 @@ int launch(EpilogueArgs& p, bool backward, bool channelsLast, hipStream_t stream
     const int cv = p.channels / V;
     const bool vec = channelsLast && p.channels % V == 0 && cv <= kThreads && (cv & (cv - 1)) == 0 &&
                      lvg_aligned16(p.y) && lvg_aligned16(backward ? p.dy : p.out) && (!backward || lvg_aligned16(p.dout)) &&
-                     p.frames <= 65535;
+                     lvg_aligned16(p.mid) && lvg_aligned16(p.dmid) && p.frames <= 65535;
     if (vec)
     {
         p.frameVecs = (int64_t)p.pixels * cv;
@@ -251,6 +263,11 @@ int launch(EpilogueArgs& p, bool backward, bool channelsLast, hipStream_t stream
         if (backward) hipLaunchKernelGGL((epilogue_cl_bwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);
         else          hipLaunchKernelGGL((epilogue_cl_fwd_kernel<T, ACT>), grid, dim3(kThreads), 0, stream, p);
         return lvg_check_launch("modconv_epilogue (channels-last)");
+    }
+    if (p.mid || p.dmid)
+    {
+        lvg_set_error("modconv_epilogue: the dual form needs channels-last tensors with a power-of-two number of 16-byte channel vectors");
+        return LVG_ERR_UNSUPPORTED;
     }
     const int64_t planes = p.frames * p.channels;
     const int64_t blocks = lvg_ceil_div(planes, kThreads / 64);
@@ -336,4 +353,30 @@ extern "C" int lvg_modconv_epilogue_backward(const void* dout, const void* y, co
     p.frames = frames; p.channels = channels; p.pixels = pixels;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     return run(p, dtype, act, true, channels_last, stream);
+}
+
+// Dual form: `mid` = the value before `post` as a second output (forward), `dmid` = its gradient as a second input (backward).
+// Channels-last tensors only (LVG_ERR_UNSUPPORTED otherwise); mid / dmid may be NULL (= the plain form).
+extern "C" int lvg_modconv_epilogue_dual(const void* y, const float* pre, const void* b, const float* post, void* out, void* mid, float* msq,
+                                         int64_t frames, int channels, int pixels, int dtype, int act,
+                                         float alpha, float gain, float clamp, void* stream)
+{
+    EpilogueArgs p = {};
+    p.y = y; p.pre = pre; p.b = b; p.post = post; p.out = out; p.mid = mid; p.msq = msq;
+    p.frames = frames; p.channels = channels; p.pixels = pixels;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    return run(p, dtype, act, false, 1, stream);
+}
+
+extern "C" int lvg_modconv_epilogue_dual_backward(const void* dout, const void* dmid, const void* y, const float* pre, const void* b, const float* post,
+                                                  void* dy, float* d_pre, float* d_post, float* d_sum,
+                                                  int64_t frames, int channels, int pixels, int dtype, int act,
+                                                  float alpha, float gain, float clamp, void* stream)
+{
+    EpilogueArgs p = {};
+    p.y = y; p.pre = pre; p.b = b; p.post = post; p.dout = dout; p.dmid = dmid; p.dy = dy;
+    p.d_pre = d_pre; p.d_post = d_post; p.d_sum = d_sum;
+    p.frames = frames; p.channels = channels; p.pixels = pixels;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    return run(p, dtype, act, true, 1, stream);
 }

@@ -29,7 +29,7 @@ import torch_utils.distributed as dist_utils
 import contextlib
 
 from torch_utils.ops import bias_act, conv3d_frames, style_prep, upfirdn2d, weight_prep
-from torch_utils.ops.modconv_epilogue import modconv_epilogue, tap_gather_backward, tap_gather_forward
+from torch_utils.ops.modconv_epilogue import dual_supported, modconv_epilogue, modconv_epilogue_dual, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
 
@@ -355,6 +355,22 @@ TAP_STACK = os.environ.get('LVG_TAP_STACK', '1') == '1'
 # ~1500 sub-10-us launches -- forward and, since autograd replays a node on its forward stream, backward -- run beside
 # the convolutions instead of between them. Inside a captured hipGraph this becomes a parallel branch.
 SIDE_STREAM_TERMS = os.environ.get('LVG_SIDE_STREAM_TERMS', '1') == '1'
+
+# The block-final bias + activation (reference generator_lres.py:575) and the NEXT layer's input modulation (:101) + magnitude
+# statistic (:574) as ONE pass over the block output (modconv_epilogue_dual: reads h, writes the activated tensor for the skip
+# connection and the modulated one for the convolution; ToRGB needs the modulated one only), and ONE backward pass for the
+# gradients of both (instead of modulate-backward + gradient sum + bias_act-backward). Needs the next layer's terms ahead of time
+# (SIDE_STREAM_TERMS). LVG_FUSE_BOUNDARY=0 restores the separate passes.
+FUSE_BOUNDARY = os.environ.get('LVG_FUSE_BOUNDARY', '1') == '1'
+
+
+class Modulated:
+    """A layer output that already went through the next layer's input modulation: `plain` = the activated tensor (None when the
+    consumer does not read it), `mod` = plain * next modulation, `msq` = mean square of plain (or None)."""
+    __slots__ = ('plain', 'mod', 'msq')
+
+    def __init__(self, plain, mod, msq):
+        self.plain, self.mod, self.msq = plain, mod, msq
 
 
 # The dense contraction of the generator's 16-bit modulated convolutions on the hand-written implicit-GEMM kernel
@@ -772,24 +788,30 @@ class Synthesis3dResBlock(nn.Module):
         w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True, dtype)
         return w0, mod_0, demod_0, w1, mod_1, demod_1
 
-    def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
-                       out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None, terms=None) -> torch.Tensor:
-        """Same layer in time-major frames layout: x [(T N), C, H, W], latent [N, L, T]; `terms` = `frame_terms(latent,
-        dtype)` when the caller computed them ahead (on another stream).
+    def forward_frames(self, x, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
+                       out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None, terms=None, boundary=None):
+        """Same layer in time-major frames layout: x [(T N), C, H, W] (or the `Modulated` output of the previous layer), latent
+        [N, L, T]; `terms` = `frame_terms(latent, dtype)` when the caller computed them ahead (on another stream); `boundary` =
+        (next layer's modulation [(T N), C], its dtype, whether it tracks the magnitude, whether it reads the plain tensor):
+        the block output then comes back as `Modulated` (FUSE_BOUNDARY).
 
         Elementwise passes over the activations are the HBM-bound part of the block, so scalars are folded
         into small tensors instead of being applied to the activations: the input-magnitude gain goes into
         the style of conv 0 and into the skip weights (convolution is linear), sqrt(1/2) into the skip
         weights and the demodulation of conv 1, and (skip + conv1 * demod) is one addcmul."""
         if dtype is None:
-            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+            dtype = torch.float16 if (self.use_float16 and (x.mod if isinstance(x, Modulated) else x).is_cuda) else torch.float32
         n = latent.shape[0]
-        x = x.to(dtype)
         track = self.magnitude_ema and magnitude_ema_beta != 1
         w0, mod_0, demod_0, w1, mod_1, demod_1 = terms if terms is not None else self.frame_terms(latent, dtype)
 
         # conv 0: modulate (one pass, which also measures E[x^2]) -> conv -> fused epilogue
-        xm = modconv_epilogue(x, post=mod_0, want_msq=track)
+        if isinstance(x, Modulated):                                            # done by the previous layer's last pass
+            xm = (x.mod, x.msq) if track else x.mod
+            x = x.plain
+        else:
+            x = x.to(dtype)
+            xm = modconv_epilogue(x, post=mod_0, want_msq=track)
         gain_0 = None
         if self.magnitude_ema:
             gain_0 = self.input_magnitude_ema_0.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_0(x)
@@ -815,6 +837,13 @@ class Synthesis3dResBlock(nn.Module):
         if self.spatial_up:
             h = upfirdn2d.upsample2d(h, self.spatial_upsample.filter, up=self.spatial_upsample.scale)
         h = crop_frames(h, n, height=self.out_height, width=self.out_width)
+        if boundary is not None and boundary[1] == h.dtype and dual_supported(h):
+            next_mod, _, next_track, next_plain = boundary
+            if next_plain:
+                res = modconv_epilogue_dual(h, b=self.bias_1.to(dtype), post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)
+                return Modulated(res[1], res[0], res[2] if next_track else None)
+            res = modconv_epilogue(h, b=self.bias_1.to(dtype), post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)
+            return Modulated(None, res[0], res[1]) if next_track else Modulated(None, res, None)
         return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
 
 
@@ -849,12 +878,16 @@ class ToRGB(nn.Module):
     def forward_frames(self, x: torch.Tensor, latent: torch.Tensor, magnitude_ema_beta: float = 1.0, dtype: Optional[torch.dtype] = None,
                        terms=None) -> torch.Tensor:
         if dtype is None:
-            dtype = torch.float16 if (self.use_float16 and x.is_cuda) else torch.float32
+            dtype = torch.float16 if (self.use_float16 and (x.mod if isinstance(x, Modulated) else x).is_cuda) else torch.float32
         n = latent.shape[0]
-        x = x.to(dtype)
         track = self.magnitude_ema and magnitude_ema_beta != 1
         weight, mod = terms if terms is not None else self.frame_terms(latent, dtype)
-        xm = modconv_epilogue(x, post=mod, want_msq=track)
+        if isinstance(x, Modulated):                                            # modulated by the last block's final pass
+            xm = (x.mod, x.msq) if track else x.mod
+            x = x.mod
+        else:
+            x = x.to(dtype)
+            xm = modconv_epilogue(x, post=mod, want_msq=track)
         if self.magnitude_ema:                                                  # scalar gain folded into the 3 x Ci weight
             gain = self.input_magnitude_ema.update(xm[1], magnitude_ema_beta) if track else self.input_magnitude_ema(x)
             weight = weight * gain
@@ -956,8 +989,17 @@ class VideoGenerator(nn.Module):
         layers = list(self.temporal_layers) + list(self.spatial_layers) + [self.to_rgb]
         lengths = list(lengths) + [None] * (len(layers) - len(lengths))
         terms = self._terms_ahead(layers, latent_ws, x, dtype)
+
+        def layer_dtype(layer):
+            return dtype if dtype is not None else (torch.float16 if (getattr(layer, 'use_float16', False) and x.is_cuda) else torch.float32)
         for wi, (layer, length) in enumerate(zip(layers, lengths)):
             extra = {} if layer is self.to_rgb else {'out_seq_length': length}
+            if FUSE_BOUNDARY and layer is not self.to_rgb and not return_features:
+                nxt = layers[wi + 1]
+                nxt_terms = terms(wi + 1)
+                if nxt_terms is not None:                # (modulation, dtype, tracks the magnitude, reads the plain tensor) of the next layer
+                    extra['boundary'] = (nxt_terms[1], layer_dtype(nxt), bool(getattr(nxt, 'magnitude_ema', False)) and magnitude_ema_beta != 1,
+                                         nxt is not self.to_rgb)
             x = layer.forward_frames(x, latent_ws[wi], magnitude_ema_beta, dtype=dtype, terms=terms(wi), **extra)
             if return_features and layer is not self.to_rgb:
                 feats.append(video_from_frames(x, n))

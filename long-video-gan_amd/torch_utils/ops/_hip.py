@@ -31,6 +31,8 @@ _SIGNATURES = {
     'lvg_filtered_lrelu_act': [_vp, _vp, _i64x4, _i64x4, _i64x2, _i32, _i32, _f32, _f32, _f32, _i32, _i32, _vp],
     'lvg_modconv_epilogue': [_vp] * 6 + [_i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_modconv_epilogue_backward': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
+    'lvg_modconv_epilogue_dual': [_vp] * 7 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
+    'lvg_modconv_epilogue_dual_backward': [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_modconv_epilogue_slots': [_i64, _i32, _i32, _i32, _i32, _i32],
     'lvg_tapconv_epilogue_slots': [_i64, _i32, _i32, _i32],
     'lvg_tapconv_epilogue': [_vp] * 8 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],

@@ -42,7 +42,7 @@ def _resolve(act, alpha, gain, clamp):
     return spec, alpha, gain, clamp
 
 
-def _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq, res=None):
+def _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq, res=None, want_mid=False):
     """Plain-PyTorch definition (float32 arithmetic, one rounding at the end)."""
     u = y.float()
     if pre is not None:
@@ -60,8 +60,12 @@ def _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq, res=None):
     if clamp >= 0:
         u = u.clamp(-clamp, clamp)
     msq = u.detach().square().mean() if want_msq else None
+    if want_mid:
+        mid = u.to(y.dtype)
     if post is not None:
         u = u * post[:, :, None, None]
+    if want_mid:
+        return u.to(y.dtype), mid, msq
     return u.to(y.dtype), msq
 
 
@@ -87,14 +91,24 @@ def _sum_slots(red, used):
     return out
 
 
-def _launch_fwd(y, pre, b, post, cl, act_id, alpha, gain, clamp, want_msq):
-    """One lvg_modconv_epilogue launch on y's device and the current stream -> (out, msq per frame | None)."""
+def _launch_fwd(y, pre, b, post, cl, act_id, alpha, gain, clamp, want_msq, want_mid=False):
+    """One lvg_modconv_epilogue launch on y's device and the current stream -> (out, msq per frame | None) -- with `want_mid`
+    (channels-last only) the dual form: (out, mid, msq per frame | None), mid = the value before `post`."""
     f, c, h, w = y.shape
     out = torch.empty_like(y)
     assert out.stride() == y.stride()
     # partial sums per slot (chunk of a frame / channel plane): summed below in a fixed order -- no atomics, reproducible
     slots = _hip.lib().lvg_modconv_epilogue_slots(f, c, h * w, cl, _hip.dtype_code(y.dtype), 0) if want_msq else 0
     msq = torch.empty((slots, f), dtype=torch.float32, device=y.device) if want_msq else None
+    if want_mid:
+        assert cl, 'modconv_epilogue: the dual form needs channels-last tensors'
+        mid = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            rc = _hip.lib().lvg_modconv_epilogue_dual(
+                y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), out.data_ptr(), mid.data_ptr(), _hip.ptr(msq),
+                f, c, h * w, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
+        _hip.check(rc, 'modconv_epilogue_dual')
+        return out, mid, msq
     with torch.cuda.device(y.device):
         rc = _hip.lib().lvg_modconv_epilogue(
             y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), out.data_ptr(), _hip.ptr(msq),
@@ -103,17 +117,25 @@ def _launch_fwd(y, pre, b, post, cl, act_id, alpha, gain, clamp, want_msq):
     return out, msq
 
 
-def _launch_bwd(dout, y, pre, b, post, cl, act_id, alpha, gain, clamp):
-    """One lvg_modconv_epilogue_backward launch -> (dy, [d_pre, d_post, d_sum] float32 [3, frames, channels])."""
+def _launch_bwd(dout, y, pre, b, post, cl, act_id, alpha, gain, clamp, dmid=None):
+    """One lvg_modconv_epilogue_backward launch -> (dy, [d_pre, d_post, d_sum] float32 [3, frames, channels]); `dmid`: the gradient
+    of the dual form's second output (channels-last only)."""
     f, c, h, w = y.shape
     dy = torch.empty_like(y)
     slots = _hip.lib().lvg_modconv_epilogue_slots(f, c, h * w, cl, _hip.dtype_code(y.dtype), 1)
     red = torch.empty(3, slots, f, c, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
-        rc = _hip.lib().lvg_modconv_epilogue_backward(
-            dout.data_ptr(), y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), dy.data_ptr(),
-            red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
-            f, c, h * w, cl, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
+        if dmid is not None:
+            assert cl and dmid.stride() == y.stride() and dmid.dtype == y.dtype
+            rc = _hip.lib().lvg_modconv_epilogue_dual_backward(
+                dout.data_ptr(), dmid.data_ptr(), y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), dy.data_ptr(),
+                red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
+                f, c, h * w, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
+        else:
+            rc = _hip.lib().lvg_modconv_epilogue_backward(
+                dout.data_ptr(), y.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(post), dy.data_ptr(),
+                red[0].data_ptr() if pre is not None else None, red[1].data_ptr() if post is not None else None, red[2].data_ptr(),
+                f, c, h * w, cl, _hip.dtype_code(y.dtype), act_id, alpha, gain, clamp, _hip.stream(y.device))
     _hip.check(rc, 'modconv_epilogue_backward')
     return dy, _sum_slots(red, (pre is not None, post is not None, True))
 
@@ -145,6 +167,69 @@ class _Epilogue(torch.autograd.Function):
         d_b = red[2].sum(dim=0).to(b.dtype) if (b is not None and ctx.needs_input_grad[2]) else None
         d_post = red[1] if (post is not None and ctx.needs_input_grad[3]) else None
         return dy, d_pre, d_b, d_post, None, None, None, None, None
+
+
+class _EpilogueDual(torch.autograd.Function):
+    """(out, mid, mean_square): `out` = mid * post. Channels-last GPU tensors."""
+
+    @staticmethod
+    def forward(ctx, y, pre, b, post, act_id, alpha, gain, clamp, want_msq):
+        pre = pre.contiguous() if pre is not None else None
+        post = post.contiguous() if post is not None else None
+        b = b.contiguous() if b is not None else None
+        out, mid, msq = _launch_fwd(y, pre, b, post, 1, act_id, alpha, gain, clamp, want_msq, want_mid=True)
+        ctx.save_for_backward(y, pre, b, post)
+        ctx.cfg = (act_id, alpha, gain, clamp)
+        mean_sq = msq.sum() / float(y.numel()) if want_msq else None
+        if want_msq:
+            ctx.mark_non_differentiable(mean_sq)
+        return out, mid, mean_sq
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout, dmid, _dmsq):
+        y, pre, b, post = ctx.saved_tensors
+        act_id, alpha, gain, clamp = ctx.cfg
+        if dout is None:                                    # only `mid` was used downstream
+            dout = torch.zeros_like(y)
+        dout = dout.contiguous(memory_format=torch.channels_last)
+        if dmid is not None:
+            dmid = dmid.contiguous(memory_format=torch.channels_last)
+        assert dout.stride() == y.stride() and dout.dtype == y.dtype
+        dy, red = _launch_bwd(dout, y, pre, b, post, 1, act_id, alpha, gain, clamp, dmid=dmid)
+        d_pre = red[0] if (pre is not None and ctx.needs_input_grad[1]) else None
+        d_b = red[2].sum(dim=0).to(b.dtype) if (b is not None and ctx.needs_input_grad[2]) else None
+        d_post = red[1] if (post is not None and ctx.needs_input_grad[3]) else None
+        return dy, d_pre, d_b, d_post, None, None, None, None, None
+
+
+def dual_supported(y):
+    """True when `modconv_epilogue_dual` runs as ONE kernel on y (channels-last GPU tensor, 16-bit or float32, a power-of-two number
+    of 16-byte channel vectors)."""
+    if not (y.is_cuda and y.ndim == 4 and y.dtype in (torch.float16, torch.bfloat16, torch.float32)):
+        return False
+    v = 4 if y.dtype == torch.float32 else 8
+    c = y.shape[1]
+    cv = c // v
+    return c % v == 0 and 0 < cv <= 256 and (cv & (cv - 1)) == 0 and y.shape[0] <= 65535 and y.is_contiguous(memory_format=torch.channels_last) \
+        and y.stride(1) == 1
+
+
+def modconv_epilogue_dual(y, pre=None, b=None, post=None, act='linear', alpha=None, gain=None, clamp=None, want_msq=False):
+    r"""(out, mid[, mean_square]): mid = clamp(act(y * pre + b) * gain), out = mid * post -- both from ONE pass over y (3 streams where
+    bias_act followed by the next layer's modulation moves 4), and one backward pass for both gradients (4 streams instead of 9).
+    Same arguments as `modconv_epilogue`; other tensors take that function twice."""
+    assert y.ndim == 4
+    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+    if dual_supported(y) and _init():
+        out, mid, msq = _EpilogueDual.apply(y, pre, b, post, spec.cuda_idx, alpha, gain, clamp, bool(want_msq))
+    elif y.device.type == 'cuda':
+        mid = modconv_epilogue(y, pre=pre, b=b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        res = modconv_epilogue(mid, post=post, want_msq=want_msq)
+        out, msq = res if want_msq else (res, None)
+    else:
+        out, mid, msq = _ref(y, pre, b, post, act, alpha, gain, clamp, want_msq, want_mid=True)
+    return (out, mid, msq) if want_msq else (out, mid)
 
 
 def modconv_epilogue(y, pre=None, b=None, post=None, act='linear', alpha=None, gain=None, clamp=None, want_msq=False, impl='cuda'):

@@ -143,3 +143,96 @@ def test_reductions_are_reproducible_run_to_run_gpu():
         runs.append((msq.sum().clone(), red.clone()))
     for m, r in runs[1:]:
         assert torch.equal(m, runs[0][0]) and torch.equal(r, runs[0][1])
+
+
+# ----------------------------------------------------------------------------------------------------
+# Dual form: the value before `post` as a second output, its gradient as a second input of the backward pass.
+
+def test_dual_definition_cpu(oracle):
+    from torch_utils.ops.modconv_epilogue import modconv_epilogue_dual
+    y, pre, b, post = _case(2, 3, 8, 4, 6, torch.float32, 'cpu', False)
+    out, mid, msq = modconv_epilogue_dual(y, pre, b, post, act='lrelu', clamp=1.5, want_msq=True)
+    want, want_msq = _oracle_forward(oracle, y, pre, b, post, 'lrelu', 1.5)
+    want_mid, _ = _oracle_forward(oracle, y, pre, b, None, 'lrelu', 1.5)
+    np.testing.assert_allclose(out.numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mid.numpy(), want_mid, rtol=1e-5, atol=1e-6)
+    assert abs(float(msq) - want_msq) < 1e-5 * want_msq
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('f,c,h,w', [(6, 64, 9, 16), (3, 512, 18, 32), (5, 8, 7, 5), (16, 128, 36, 64)])
+@pytest.mark.parametrize('act,clamp,with_pre', [('lrelu', 2.0, False), ('lrelu', None, True), ('linear', 1.0, True)])
+def test_dual_forward_backward_gpu(oracle, dtype, f, c, h, w, act, clamp, with_pre):
+    """ONE pass for (mid, out = mid * post) and ONE backward pass for both gradients, against the oracle (forward) and autograd through
+    the float32 definition (backward); the single-output kernel must give the same `out` bit for bit."""
+    from torch_utils.ops.modconv_epilogue import dual_supported, modconv_epilogue_dual
+    y, pre, b, post = _case(11, f, c, h, w, dtype, 'cuda', True, with_pre=with_pre)
+    assert dual_supported(y)
+    leaves = [t for t in (y, pre, b, post) if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    out, mid, msq = modconv_epilogue_dual(y, pre, b, post, act=act, clamp=clamp, want_msq=True)
+    single, msq1 = modconv_epilogue(y.detach(), None if pre is None else pre.detach(), b.detach(), post.detach(), act=act, clamp=clamp, want_msq=True)
+    assert torch.equal(out, single) and float(msq) == float(msq1)
+    det = lambda t: None if t is None else t.detach()
+    want, want_msq = _oracle_forward(oracle, det(y), det(pre), det(b), det(post), act, clamp)
+    want_mid, _ = _oracle_forward(oracle, det(y), det(pre), det(b), None, act, clamp)
+    eps = {torch.float32: 2e-6, torch.bfloat16: 8e-3, torch.float16: 1e-3}[dtype]
+    np.testing.assert_allclose(out.detach().double().cpu().numpy(), want, rtol=eps, atol=eps)
+    np.testing.assert_allclose(mid.detach().double().cpu().numpy(), want_mid, rtol=eps, atol=eps)
+    assert mid.stride() == y.stride() and abs(float(msq) - want_msq) <= 1e-4 * want_msq
+
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    go = torch.randn(out.shape, device='cuda', generator=gen).to(dtype).contiguous(memory_format=torch.channels_last)
+    gm = torch.randn(out.shape, device='cuda', generator=gen).to(dtype).contiguous(memory_format=torch.channels_last)
+    got = torch.autograd.grad([out, mid], leaves, [go, gm], retain_graph=True)
+    leaves2 = [t.detach().clone().requires_grad_(True) for t in leaves]
+    it = iter(leaves2)
+    y2 = next(it); pre2 = next(it) if pre is not None else None; b2 = next(it); post2 = next(it)
+    gain = 1.0 if act == 'linear' else float(np.sqrt(2))
+    r_out, r_mid, _ = _ref(y2.float(), pre2, b2.float(), post2, act, 0.2, gain, -1.0 if clamp is None else clamp, False, want_mid=True)
+    ref = torch.autograd.grad([r_out, r_mid], leaves2, [go.float(), gm.float()])
+    tol = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype]
+    for a, r in zip(got, ref):
+        a, r = a.double().cpu(), r.double().cpu()
+        assert float((a - r).abs().max()) <= tol * (float(r.abs().max()) + 1e-12)
+    # only one of the outputs used downstream
+    only_mid = torch.autograd.grad([mid], [y], [gm], retain_graph=True)[0]
+    ref_only = torch.autograd.grad([_ref(y2.float(), pre2, b2.float(), post2, act, 0.2, gain, -1.0 if clamp is None else clamp, False, want_mid=True)[1]], [y2], [gm.float()])[0]
+    assert float((only_mid.double().cpu() - ref_only.double().cpu()).abs().max()) <= tol * (float(ref_only.abs().max()) + 1e-12)
+
+
+@pytest.mark.gpu
+def test_generator_boundary_fusion_matches_separate_passes_gpu(monkeypatch):
+    """The generator with the block-final bias_act fused into the next layer's modulation pass against the separate passes: video and
+    all parameter gradients. In float32 the two routes agree to rounding; in bfloat16 (one rounding less on the fused route) both are
+    compared with the float32 result."""
+    from lvg.models import lres
+    torch.manual_seed(0)
+    G = lres.VideoGenerator().cuda().train()
+    gen = torch.Generator(device='cuda')
+
+    def run(flag, dtype):
+        monkeypatch.setattr(lres, 'FUSE_BOUNDARY', flag)
+        G.zero_grad(set_to_none=True)
+        gen.manual_seed(3)
+        video = G(2, 16, magnitude_ema_beta=1.0, generator_emb=gen, dtype=dtype)
+        (video * torch.linspace(-1, 1, video.numel(), device='cuda').view_as(video)).sum().backward()
+        return video.detach().clone(), {k: p.grad.detach().clone() for k, p in G.named_parameters() if p.grad is not None}
+
+    def err(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    v32, g32 = run(False, torch.float32)
+    v32f, g32f = run(True, torch.float32)
+    assert err(v32f, v32) < 2e-4, err(v32f, v32)
+    assert g32.keys() == g32f.keys()
+    worst = max(err(g32f[k], g32[k]) for k in g32)
+    assert worst < 2e-3, worst
+    vp, gp = run(False, torch.bfloat16)
+    vf, gf = run(True, torch.bfloat16)
+    assert err(vf, v32) <= max(1.5 * err(vp, v32), 1e-2), (err(vf, v32), err(vp, v32))
+    ef = sorted(err(gf[k], g32[k]) for k in g32)
+    ep = sorted(err(gp[k], g32[k]) for k in g32)
+    assert ef[len(ef) // 2] <= 1.5 * ep[len(ep) // 2] + 1e-3, (ef[len(ef) // 2], ep[len(ep) // 2])       # median over the parameters
+    assert ef[-1] <= 2.0 * ep[-1] + 1e-2, (ef[-1], ep[-1])

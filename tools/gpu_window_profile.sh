@@ -8,4 +8,4 @@ for l in open('gpurun_out/window.log'):
     if l.startswith('{'):
         d=json.loads(l); print(d['ms_per_step']*d['steps'], d['steps'])") > gpurun_out/window_stats.csv 2>&1
 rm -f gpurun_out/prof_window/win_kernel_trace.csv
-head -3 gpurun_out/window_stats.csv | cut -c1-250; grep -c . gpurun_out/window_stats.csv; grep "flip\|dgrad_pack\|direct_copy" gpurun_out/window_stats.csv | cut -c1-160
+head -${ROWS:-48} gpurun_out/window_stats.csv | cut -c1-${COLS:-175}
