@@ -432,12 +432,18 @@ def second_order():
 # 1x1 convolutions as plain GEMMs on the channels-last pixel matrix [(frames H W), Ci] (hipBLASLt) instead of MIOpen's
 # implicit-GEMM + its split-K zero-fill / cast helpers. Opt-in (LVG_POINTWISE_GEMM=1) until measured on MI355X.
 POINTWISE_GEMM = os.environ.get('LVG_POINTWISE_GEMM', '0') == '1'
+# 1x1 (skip) convolutions through the hand-written kernel: forward + data gradient there (no zero-fill / cast helper launches of the
+# library's split-K kernels), weight gradient on the library. Same run, LVG_POINTWISE_HAND=1/0: 43.45 / 43.7 ms per step.
+POINTWISE_HAND = os.environ.get('LVG_POINTWISE_HAND', '1') == '1'
 
 
 def pointwise_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """conv2d with a [Co, Ci] / [Co, Ci, 1, 1] weight on frames [(T N), Ci, H, W]; result in x's memory format."""
     w2 = weight.reshape(weight.shape[0], weight.shape[1])
     cl = x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+    if POINTWISE_HAND and cl and not SECOND_ORDER and TAP_STACK and _hand_conv_takes(x, w2[:, :, None, None, None], (0, 0)):
+        # forward and data gradient on the hand-written kernel (no zero-fill / cast helper launches), weight gradient on the library
+        return _TapConvEpilogue.apply(x, w2[:, :, None, None, None], None, None, None, None, 1, (0, 0), 'linear', None, False)[0]
     if POINTWISE_GEMM and cl:
         return torch.matmul(x.permute(0, 2, 3, 1), w2.t()).permute(0, 3, 1, 2)      # views: [F, H, W, C] is the memory order
     return F.conv2d(x, _cl(w2[:, :, None, None]))
@@ -470,6 +476,7 @@ class _TapConvEpilogue(torch.autograd.Function):
             out, ysum, msq = tap_gather_forward(z, pre, b, res, post, kt, n, act=act, clamp=clamp, want_msq=want_msq, keep_sum=not plain)
         ctx.save_for_backward(x, weight, out if plain else ysum, pre, b, res, post)
         ctx.cfg = (n, list(padding_hw), act, clamp)
+        ctx.plain = pre is None and b is None and res is None and post is None and act == 'linear' and clamp is None
         ctx.wt = getattr(weight, '_lvg_dgrad', None)        # weight_prep's data-gradient packing of this weight, if it made one
         if want_msq:
             ctx.mark_non_differentiable(msq)
@@ -486,7 +493,10 @@ class _TapConvEpilogue(torch.autograd.Function):
         hand_d = need[0] and HAND_CONV_DGRAD and _hand_conv_shape_ok(xc, co, ci, weight, pad)
         hand_w = need[1] and HAND_CONV_WGRAD and _hand_wgrad_shape_ok(xc, co, weight, pad)
         stacked = (need[0] and not hand_d) or (need[1] and not hand_w)      # MIOpen needs the gradient scattered over the taps
-        dz, d_pre, d_post, d_sum = tap_gather_backward(dout, ysum, pre, b, res, post, kt if stacked else 1, n, act=act, clamp=clamp)
+        if ctx.plain and (kt == 1 or not stacked):
+            dz, d_pre, d_post, d_sum = dout.contiguous(memory_format=torch.channels_last), None, None, None     # a bare convolution: nothing to undo
+        else:
+            dz, d_pre, d_post, d_sum = tap_gather_backward(dout, ysum, pre, b, res, post, kt if stacked else 1, n, act=act, clamp=clamp)
         dy = dz[:, (kt // 2) * co:(kt // 2 + 1) * co] if stacked else dz     # the centre tap of the scattered gradient IS the gradient of the sum
         gx = gw = None
         if hand_d:
