@@ -66,34 +66,37 @@ class OpTimer:
             def recorded(*args, **kwargs):
                 out = orig(*args, **kwargs)
                 if self.enabled:
-                    self.calls.append((op(args), orig, args, kwargs, bytes_fn(args, out)))
+                    self.calls.append((op(args), orig, args, kwargs, bytes_fn(args, out, kwargs)))
                 return out
             setattr(mod, name, recorded)
 
         # bias_act._launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp): x, y (+ xref / yref / dy)
-        def ba_bytes(args, out):
+        def ba_bytes(args, out, kw):
             streams = 2 + sum(1 for t in args[2:5] if t is not None and t.numel() > 0)
             return out.numel() * out.element_size() * streams
         wrap(bias_act, '_launch', lambda a: 'bias_act_fwd' if a[5] == 0 else 'bias_act_bwd', ba_bytes)
         # bias_act._launch_grad_bias(dy, xref, yref, slots, ...): the backward launch that also leaves the bias gradient (dy, yref -> dx)
         wrap(bias_act, '_launch_grad_bias', lambda a: 'bias_act_bwd',
-             lambda args, out: out[0].numel() * out[0].element_size() * (2 + sum(1 for t in args[1:3] if t is not None and t.numel() > 0)))
+             lambda args, out, kw: out[0].numel() * out[0].element_size() * (2 + sum(1 for t in args[1:3] if t is not None and t.numel() > 0)))
         # upfirdn2d._launch(x, f, ...): (N_in + N_out) * s
-        wrap(upfirdn2d, '_launch', lambda a: 'upfirdn2d', lambda args, out: (args[0].numel() + out.numel()) * out.element_size())
+        wrap(upfirdn2d, '_launch', lambda a: 'upfirdn2d', lambda args, out, kw: (args[0].numel() + out.numel()) * out.element_size())
         # modconv_epilogue: forward y -> out (2 streams), backward dout, y -> dy (3 streams)
-        wrap(modconv_epilogue, '_launch_fwd', lambda a: 'modconv_epilogue_fwd', lambda args, out: 2 * args[0].numel() * args[0].element_size())
-        wrap(modconv_epilogue, '_launch_bwd', lambda a: 'modconv_epilogue_bwd', lambda args, out: 3 * args[0].numel() * args[0].element_size())
+        # (the dual form writes a second output / reads a second gradient: one stream more each way)
+        wrap(modconv_epilogue, '_launch_fwd', lambda a: 'modconv_epilogue_fwd',
+             lambda args, out, kw: (3 if kw.get('want_mid') else 2) * args[0].numel() * args[0].element_size())
+        wrap(modconv_epilogue, '_launch_bwd', lambda a: 'modconv_epilogue_bwd',
+             lambda args, out, kw: (4 if kw.get('dmid') is not None else 3) * args[0].numel() * args[0].element_size())
         # tapconv_epilogue (tap-stacked temporal conv, sum fused into the epilogue; lres binds the launch functions
         # by name, so they are wrapped there). forward: z (taps*N) -> out (+ saved sum) (+ residual); backward:
         # dout, saved sum (+ residual) -> dz (taps*N)
         from lvg.models import lres
 
-        def tap_fwd_bytes(args, out):
+        def tap_fwd_bytes(args, out, kw):
             z, res = args[0], args[3]
             streams = z.numel() + out[0].numel() + (out[1].numel() if out[1] is not None else 0) + (res.numel() if res is not None else 0)
             return streams * z.element_size()
 
-        def tap_bwd_bytes(args, out):
+        def tap_bwd_bytes(args, out, kw):
             dout, ysum, res = args[0], args[1], args[4]
             streams = dout.numel() + ysum.numel() + (res.numel() if res is not None else 0) + out[0].numel()
             return streams * ysum.element_size()
@@ -103,7 +106,7 @@ class OpTimer:
         # (written in the forward of a training pass, read in its backward) -- SURVEY.md 8(d)
         from torch_utils.ops import filtered_lrelu
 
-        def fl_bytes(args, out):
+        def fl_bytes(args, out, kw):
             x, si = args[0], args[4]
             y, so, rc = out
             if rc < 0 or y is None:
@@ -121,14 +124,15 @@ class OpTimer:
         # 2 * N_out * Cin * kt * kh * kw, not in bytes.
         from torch_utils.ops import conv3d_frames
 
-        def conv_flops(args, out):
+        def conv_flops(args, out, kw):
             x, w = args[0], args[1]
             return 2 * x.shape[0] * x.shape[2] * x.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3] * w.shape[4]
-        wrap(conv3d_frames, 'conv3d_frames_forward', lambda a: 'conv3d_igemm', conv_flops)
+        # 1 x 1 (skip) convolutions run on the same kernel but are a memory stream (K = Ci): counted apart from the dense contraction
+        wrap(conv3d_frames, 'conv3d_frames_forward', lambda a: 'conv3d_igemm' if a[1].shape[2] * a[1].shape[3] * a[1].shape[4] > 1 else 'conv3d_igemm_1x1', conv_flops)
         # conv3d_frames_wgrad(x, dy, kt, kh, kw, shift): the hand-written weight gradient (its own kernel, csrc/conv3d_wgrad.hip)
         wrap(conv3d_frames, 'conv3d_frames_wgrad', lambda a: 'conv3d_wgrad',
-             lambda args, out: 2 * args[0].shape[0] * args[0].shape[2] * args[0].shape[3] * args[0].shape[1] * args[1].shape[1] * args[2] * args[3] * args[4])
-        self.flop_ops = {'conv3d_igemm', 'conv3d_wgrad'}
+             lambda args, out, kw: 2 * args[0].shape[0] * args[0].shape[2] * args[0].shape[3] * args[0].shape[1] * args[1].shape[1] * args[2] * args[3] * args[4])
+        self.flop_ops = {'conv3d_igemm', 'conv3d_igemm_1x1', 'conv3d_wgrad'}
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step
