@@ -1229,6 +1229,7 @@ int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
         // streaming form: enough lanes even for short frames thanks to row chunks of 16 output rows
         // (equal chunks: 18 output rows are 2 x 10/8, not 16 + 2 -- the short tail chunk measured 37 % slower)
         p.rowChunks = (p.oh + 15) / 16;
+        if (const char* e = getenv("LVG_UPFIRDN_CHUNKS")) { if (*e && atoi(e) > 0) p.rowChunks = std::min(atoi(e), (p.oh + 1) / 2); }   // measurement override
         p.chunkRows = (((p.oh + p.rowChunks - 1) / p.rowChunks) + 1) & ~1;
         p.rowChunks = (p.oh + p.chunkRows - 1) / p.chunkRows;
         const int64_t threads = (int64_t)p.n * p.rowChunks * p.ow * (p.c / V);
