@@ -796,7 +796,9 @@ class Synthesis3dResBlock(nn.Module):
         lat = latent.permute(2, 0, 1).reshape(t * n, c)                         # rows ordered (t n), like the frames
         w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True, dtype)
         w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True, dtype)
-        return w0, mod_0, demod_0, w1, mod_1, demod_1
+        # parameter casts / constant scales: small launches that do not depend on the activations -- they belong here (second stream)
+        w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
+        return w0, mod_0, demod_0, w1, mod_1, demod_1, self.bias_0.to(dtype), self.bias_1.to(dtype), w_skip
 
     def forward_frames(self, x, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,
                        out_seq_length: Optional[int] = None, dtype: Optional[torch.dtype] = None, terms=None, boundary=None):
@@ -813,7 +815,7 @@ class Synthesis3dResBlock(nn.Module):
             dtype = torch.float16 if (self.use_float16 and (x.mod if isinstance(x, Modulated) else x).is_cuda) else torch.float32
         n = latent.shape[0]
         track = self.magnitude_ema and magnitude_ema_beta != 1
-        w0, mod_0, demod_0, w1, mod_1, demod_1 = terms if terms is not None else self.frame_terms(latent, dtype)
+        w0, mod_0, demod_0, w1, mod_1, demod_1, b0, b1, w_skip = terms if terms is not None else self.frame_terms(latent, dtype)
 
         # conv 0: modulate (one pass, which also measures E[x^2]) -> conv -> fused epilogue
         if isinstance(x, Modulated):                                            # done by the previous layer's last pass
@@ -828,13 +830,12 @@ class Synthesis3dResBlock(nn.Module):
         xm = xm[0] if track else xm
         # conv 0 and its epilogue: demodulation * input gain, bias, activation, clamp AND the modulation of conv 1
         hm = temporal_conv_epilogue(xm, w0, n, self.padding[1:], pre=(demod_0 if gain_0 is None else demod_0 * gain_0),
-                                    b=self.bias_0.to(dtype), post=mod_1, act=self.activation, clamp=self.activation_clamp, want_msq=track)
+                                    b=b0, post=mod_1, act=self.activation, clamp=self.activation_clamp, want_msq=track)
         gain_1 = None
         if self.magnitude_ema:
             gain_1 = self.input_magnitude_ema_1.update(hm[1], magnitude_ema_beta) if track else self.input_magnitude_ema_1.magnitude_ema.rsqrt()
         hm = hm[0] if track else hm
 
-        w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
         if gain_0 is not None:
             w_skip = w_skip * gain_0
         skip = pointwise_conv(x, w_skip.to(dtype))
@@ -850,11 +851,11 @@ class Synthesis3dResBlock(nn.Module):
         if boundary is not None and boundary[1] == h.dtype and dual_supported(h):
             next_mod, _, next_track, next_plain = boundary
             if next_plain:
-                res = modconv_epilogue_dual(h, b=self.bias_1.to(dtype), post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)
+                res = modconv_epilogue_dual(h, b=b1, post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)
                 return Modulated(res[1], res[0], res[2] if next_track else None)
-            res = modconv_epilogue(h, b=self.bias_1.to(dtype), post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)
+            res = modconv_epilogue(h, b=b1, post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)
             return Modulated(None, res[0], res[1]) if next_track else Modulated(None, res, None)
-        return bias_act.bias_act(h, self.bias_1.to(dtype), act=self.activation, clamp=self.activation_clamp)
+        return bias_act.bias_act(h, b1, act=self.activation, clamp=self.activation_clamp)
 
 
 class ToRGB(nn.Module):

@@ -85,6 +85,10 @@ def _sum_slots(red, used):
     if red.shape[1] == 1:
         return red[:, 0]
     out = torch.empty((3,) + tuple(red.shape[2:]), dtype=red.dtype, device=red.device)
+    first = next(i for i, u in enumerate(used) if u)
+    if all(used[first:]):                                   # the used rows are one contiguous block: ONE reduction launch instead of one per row
+        torch.sum(red[first:], dim=1, out=out[first:])
+        return out
     for i, u in enumerate(used):
         if u:
             torch.sum(red[i], dim=0, out=out[i])
