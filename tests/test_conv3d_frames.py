@@ -102,6 +102,8 @@ GPU_CASES = [
     (1, 2, 64, 64, 36, 64, 1, 3, 3, True),           # W = 64: band of 258 rows, single band
     (7, 1, 256, 128, 5, 8, 3, 3, 3, False),          # four chunks
     (6, 2, 64, 128, 8, 8, 5, 3, 3, False),           # discriminator kernel: 5 temporal taps (45 taps in all)
+    (3, 2, 64, 64, 7, 9, 1, 5, 5, False),            # 5 x 5 spatial taps: reach of 2 rows + 2 pixels (25 mask bits)
+    (8, 1, 64, 64, 4, 5, 7, 1, 3, True),             # 7 temporal taps (the mask's temporal bits), kh != kw, frames shorter than the reach
 ]
 
 
