@@ -1,3 +1,4 @@
+# (build first: hipcc ... -DLVG_CONV_ABL=512 -c conv3d_igemm.hip + link with the other objects -> lib/variant_conv_abl512.so, see tools/build_conv_variants.sh)
 # A/B of the convolution's LDS-staged 16-byte stores against the direct 8-byte stores (variant library built with -DLVG_CONV_ABL=512):
 # parity tests on the new path, then per-layer timings and the default bench line with both libraries in the same call.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
