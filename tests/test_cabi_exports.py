@@ -52,3 +52,30 @@ def test_gpu_tensor_without_library_fails_loudly(monkeypatch):
     monkeypatch.setenv('LVG_HIP_LIB', '/nonexistent/liblvg_hip.so')
     with pytest.raises(custom_ops.PluginUnavailable):
         _hip.lib()
+
+
+def test_planning_queries_without_a_gpu(monkeypatch):
+    """The launch-planning queries of the C ABI are host arithmetic (no device work): tile / slot / split counts for the shapes of
+    BASELINE.json configs[1], and 0 = "no kernel for this shape" where the callers keep the library route."""
+    from torch_utils.ops import _hip
+    for var in ('LVG_CONV_BM', 'LVG_CONV_BN', 'LVG_CONV_NB', 'LVG_WGRAD_SPLITS', 'LVG_WGRAD_TARGET'):
+        monkeypatch.delenv(var, raising=False)
+    lib = _hip.lib()
+    wg = lib.lvg_conv3d_frames_workgroups
+    # 640 frames of 9x16, 512 -> 512 channels, 3x3x3 taps: 128-pixel x 128-channel tiles
+    assert wg(640, 9, 16, 512, 512, 3, 3, 3) == (640 * 9 * 16 // 128) * 4
+    # 64 output channels: 64-channel tiles; 32 input channels / 7x7 taps: no kernel
+    assert wg(1024, 36, 64, 64, 64, 1, 3, 3) == 1024 * 36 * 64 // 128
+    assert wg(1024, 64, 64, 32, 64, 1, 3, 3) == 0 and wg(16, 8, 8, 64, 64, 1, 7, 7) == 0
+    # weight gradient: one full round of workgroups, rounded down (2 per CU; 1 for 64-pixel-wide frames), at least 8 K-steps each
+    sp = lib.lvg_conv3d_frames_wgrad_splits
+    assert sp(640, 9, 16, 512, 512, 3, 3, 3) == 512 // (8 * 8 * 3)
+    assert sp(1024, 18, 32, 128, 128, 1, 3, 3) == 512 // 4
+    assert sp(1024, 36, 64, 64, 64, 1, 3, 3) == 256
+    assert sp(1024, 36, 64, 64, 64, 1, 1, 1) == 0 and sp(1024, 3, 4, 512, 512, 3, 3, 3) == 0      # 1x1 taps / 4-pixel-wide frames: library route
+    # fused bias gradient: channels-last streams whose channel vector count divides the block
+    slots = lib.lvg_bias_act_grad_bias_slots
+    n = 1024 * 64 * 36 * 64
+    assert slots(n, 64, 2) == n // 8 // 1024 and slots(n, 24, 2) == 0 and slots(1024, 64, 2) == 0
+    # epilogue partial-sum slots are positive for any shape
+    assert lib.lvg_modconv_epilogue_slots(1024, 64, 36 * 64, 1, 2, 1) >= 1 and lib.lvg_tapconv_epilogue_slots(1024, 64, 36 * 64, 2) >= 1
