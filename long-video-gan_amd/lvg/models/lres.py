@@ -848,7 +848,7 @@ class Synthesis3dResBlock(nn.Module):
         if self.spatial_up:
             h = upfirdn2d.upsample2d(h, self.spatial_upsample.filter, up=self.spatial_upsample.scale)
         h = crop_frames(h, n, height=self.out_height, width=self.out_width)
-        if boundary is not None and boundary[1] == h.dtype and dual_supported(h):
+        if boundary is not None and boundary[1] == h.dtype and (dual_supported(h) or not h.is_cuda):      # CPU tensors: the plain-PyTorch definition
             next_mod, _, next_track, next_plain = boundary
             if next_plain:
                 res = modconv_epilogue_dual(h, b=b1, post=next_mod, act=self.activation, clamp=self.activation_clamp, want_msq=next_track)

@@ -247,3 +247,45 @@ def test_frames_block_tracks_input_magnitude_like_the_layer_definition():
     got = video_from_frames(rgb2.forward_frames(frames_from_video(x), latent, 0.9), 2)
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rgb2.input_magnitude_ema.magnitude_ema, rgb.input_magnitude_ema.magnitude_ema, rtol=1e-5, atol=1e-6)
+
+
+def test_block_boundary_plumbing_cpu():
+    """Two generator blocks + ToRGB chained through `Modulated` (the block-final bias_act fused with the next layer's modulation,
+    lres.FUSE_BOUNDARY) against the separate passes, float32 on the CPU (plain-PyTorch definitions of the ops): values and gradients."""
+    from lvg.models import lres
+    torch.manual_seed(1)
+    n, t, L = 2, 4, 32
+    a = lres.Synthesis3dResBlock(L, 16, 16, out_width=8, out_height=6, temporal_ksize=3, spatial_ksize=3)
+    b = lres.Synthesis3dResBlock(L, 16, 8, out_width=8, out_height=6, temporal_ksize=1, spatial_ksize=3)
+    rgb = lres.ToRGB(L, 8)
+    x0 = torch.randn(t * n, 16, 6, 8)
+    lat = [torch.randn(n, L, t) for _ in range(3)]
+    params = [p for m in (a, b, rgb) for p in m.parameters()]
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        ta, tb, tr = a.frame_terms(lat[0], torch.float32), b.frame_terms(lat[1], torch.float32), rgb.frame_terms(lat[2], torch.float32)
+        ka = dict(boundary=(tb[1], torch.float32, True, True)) if fused else {}
+        kb = dict(boundary=(tr[1], torch.float32, True, False)) if fused else {}
+        h = a.forward_frames(x, lat[0], 0.9, out_seq_length=t, dtype=torch.float32, terms=ta, **ka)
+        assert isinstance(h, lres.Modulated) == fused
+        h = b.forward_frames(h, lat[1], 0.9, out_seq_length=t, dtype=torch.float32, terms=tb, **kb)
+        assert isinstance(h, lres.Modulated) == fused and (not fused or h.plain is None)
+        y = rgb.forward_frames(h, lat[2], 0.9, dtype=torch.float32, terms=tr)
+        grads = torch.autograd.grad((y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum(), [x] + params, allow_unused=True)
+        emas = [float(m.magnitude_ema) for mod in (a, b, rgb) for m in mod.modules() if isinstance(m, lres.MagnitudeEMA)]
+        return y.detach(), grads, emas
+
+    def reset():
+        for mod in (a, b, rgb):
+            for m in mod.modules():
+                if isinstance(m, lres.MagnitudeEMA):
+                    m.magnitude_ema.fill_(1.0)
+    reset(); y0, g0, e0 = run(False)
+    reset(); y1, g1, e1 = run(True)
+    assert float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    assert max(abs(p - q) for p, q in zip(e0, e1)) < 1e-6
+    for p, q in zip(g0, g1):
+        assert (p is None) == (q is None)
+        if p is not None:
+            assert float((p - q).abs().max()) <= 2e-4 * (float(p.abs().max()) + 1e-12)
