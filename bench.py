@@ -207,13 +207,22 @@ def main():
                          '(configs[2] body: update_G + update_D + R1 every 16th step + EMA, batch 32 / world, 2 micro-batches, 160-frame generator '
                          'clips cropped to 128, DiffAugment + temporal-scale augment) with backward-overlapped bucketed all-reduce, eager launches')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the forward-only / MFMA / super-resolution legs appended to the N=1 line')
+    ap.add_argument('--selftest-launch', action='store_true',
+                    help='only bring up the ranks (RCCL on GPUs, gloo without), all-reduce the rank ids and print one JSON line: checks the N>1 launch path')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the step from a captured hipGraph (removes ~2800 host launches per step)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # invoked plainly (`python bench.py --gpus N`): start the N ranks ourselves, one process per GPU, the way the
+        # reference's launcher contract reads the environment (torch_utils/distributed.py:42-69: RANK / LOCAL_RANK /
+        # WORLD_SIZE / MASTER_* with single-process defaults)
+        sys.exit(_spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.selftest_launch:
+        return _launch_selftest(args, world, rank, local_rank)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get('LVG_FORCE_DIST'):
@@ -399,6 +408,44 @@ def main():
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(n):
+    """Re-run this command line under torch.distributed.run: one process per GPU on this node, rendezvous on 127.0.0.1
+    (the container hostname may not resolve). The ranks inherit stdout, so rank 0's JSON line is this process's output."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _launch_selftest(args, world, rank, local_rank):
+    """The N>1 launch path without the workload: process group up (RCCL when GPUs are visible, gloo otherwise), one
+    all-reduce of the rank ids, one JSON line on rank 0. Runs on a CPU-only host (tests/test_bench_launch.py)."""
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= max(world, 1)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl' if use_gpu else 'gloo', init_method='env://')
+    t = torch.tensor([float(rank)], device=torch.device('cuda', local_rank) if use_gpu else 'cpu')
+    dist.all_reduce(t)
+    dist.barrier()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if rank == 0:
+        print(json.dumps({'launch_selftest': True, 'n_gpus': world, 'backend': dist.get_backend(), 'rank_sum': float(t.item())}), flush=True)
+    dist.destroy_process_group()
 
 
 def _train_lres_workload(args, world, rank, dev, dtype):

@@ -25,6 +25,27 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu through gpurun)')
 
 
+def record_measured(name, **values):
+    """Append measured parity errors to gpurun_out/parity_measured.json (best effort; merged back by gpurun) and print them,
+    so that every gate in the suite can be read next to the number it gates."""
+    import json
+    vals = {k: float(v) for k, v in values.items()}
+    print(f'[measured] {name}: ' + ', '.join(f'{k}={v:.4g}' for k, v in vals.items()))
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'parity_measured.json')
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[name] = vals
+        with open(path, 'w') as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except (OSError, ValueError):
+        pass
+
+
 def load_golden(name):
     """dict of arrays from tests/golden/<name>.npz; '*_spec' entries are parsed back to dicts."""
     raw = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, record_measured
 from helpers.modconv3d_inputs import inputs
 from torch_utils.ops import conv3d_frames as cf
 
@@ -281,10 +281,16 @@ def test_generator_block_hand_conv_vs_miopen_route_gpu(monkeypatch):
     hand = run(True, torch.bfloat16)
     miopen = run(False, torch.bfloat16)
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    worst = dict(hand=0.0, miopen=0.0, hand_vs_miopen=0.0)
     for i, (h, m, tr) in enumerate(zip(hand, miopen, truth)):
         eh, em = rel(h, tr), rel(m, tr)
-        assert eh < 8e-2 and eh <= 1.25 * em + 2e-3, (i, eh, em)           # bf16 gradients: both routes sit at 2-5 %
-        assert rel(h, m) < 8e-2, (i, rel(h, m))
+        worst = dict(hand=max(worst['hand'], eh), miopen=max(worst['miopen'], em), hand_vs_miopen=max(worst['hand_vs_miopen'], rel(h, m)))
+        # the gate that matters: the hand-written route is not further from float32 than the library route it replaces
+        assert eh <= 1.25 * em + 2e-3, (i, eh, em)
+        # bf16 end to end through two modulated convolutions (K up to 3456 terms) and their backward: relative L2 error of
+        # every tensor (output, input gradient, 10 parameter gradients) below 6e-2; the measured worst case is recorded
+        assert eh < 6e-2 and rel(h, m) < 6e-2, (i, eh, rel(h, m))
+    record_measured('lres_block_bf16_rel_l2_vs_f32', **worst)
 
 
 @pytest.mark.gpu

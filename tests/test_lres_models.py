@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import load_golden, record_measured
 from helpers.named_fill import fill_named, analytic_buffers
 
 from lvg.models.lres import VideoGenerator, VideoDiscriminator
@@ -86,15 +86,17 @@ def test_generator_discriminator_match_reference_gpu():
 
 @pytest.mark.gpu
 def test_bf16_forward_close_to_fp32_gpu():
-    """bfloat16 activations/contraction vs the float32 golden: SURVEY.md 7 measured 1.1e-2 max on the
-    reference's own bf16 CPU run (outputs in [-0.43, 0.26]); gate at 3e-2 abs / 4e-3 mean."""
+    """bfloat16 activations / contraction vs the float32 golden of the reference. SURVEY.md 7 measured the deviation of the
+    reference's OWN bf16 run from its float32 run at 1.1e-2 max / 1.5e-3 mean (outputs in [-0.43, 0.26]); the gate is twice
+    that band, 2.2e-2 / 3e-3. The measured errors are printed and recorded (conftest.record_measured)."""
     g = load_golden('lres_models')
     G, _ = _build('cuda')
     with torch.no_grad():
         ws = G.compute_latent_ws(G.temporal_emb.blur(torch.tensor(g['noise'], device='cuda')), T)
         video = G.synthesize_video(G._temporal_input(ws), ws, T, dtype=torch.bfloat16)
     err = np.abs(video.cpu().numpy() - g['video'])
-    assert err.max() < 6e-2 and err.mean() < 6e-3, (float(err.max()), float(err.mean()))
+    record_measured('lres_T16_bf16_video_vs_reference_f32', max_abs=err.max(), mean_abs=err.mean(), ref_range=np.abs(g['video']).max())
+    assert err.max() < 2.2e-2 and err.mean() < 3e-3, (float(err.max()), float(err.mean()))
 
 
 def _run_t128(device, dtype=None):
@@ -135,10 +137,13 @@ def test_t128_generator_matches_reference_gpu():
 
 @pytest.mark.gpu
 def test_t128_bf16_generator_gate_gpu():
-    """configs[1] runs bf16 activations: gate the 128-frame bf16 video against the float32 reference video
-    (range +-0.84) at 8e-2 max / 8e-3 mean absolute error, and the logit at 0.1."""
+    """configs[1] runs bf16 activations: the 128-frame bf16 video against the float32 reference video. Its range is +-0.84,
+    1.95 x the 16-frame golden's, so twice the SURVEY.md 7 band (1.1e-2 max / 1.5e-3 mean on a range of 0.43) scales to
+    4.3e-2 max / 5.9e-3 mean; the logit is gated at 0.1. Measured values are printed and recorded."""
     err, logits, g = _run_t128('cuda', dtype=torch.bfloat16)
-    assert err.max() < 8e-2 and err.mean() < 8e-3, (float(err.max()), float(err.mean()))
+    record_measured('lres_T128_bf16_video_vs_reference_f32', max_abs=err.max(), mean_abs=err.mean(), ref_range=np.abs(g['t128_video'].astype(np.float32)).max(),
+                    logit_abs=abs(float(logits.reshape(-1)[0]) - float(g['t128_logits'].reshape(-1)[0])))
+    assert err.max() < 4.3e-2 and err.mean() < 5.9e-3, (float(err.max()), float(err.mean()))
     assert abs(float(logits.reshape(-1)[0]) - float(g['t128_logits'].reshape(-1)[0])) < 0.1
 
 
