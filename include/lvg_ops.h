@@ -280,6 +280,42 @@ int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float
                                int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream);
 int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, const void* oth_a, const void* oth_b, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_src, int c_dst, int c_a, int c_b, int dtype, void* stream);
+/* lvg_modconv2d_nchw_to_nhwc writing into the interior of a LARGER channels-last frame: source planes src_h x src_w go to
+ * dst [n][dst_h][dst_w][c_dst] at (off_y, off_x). The border is not written: the caller zero-fills dst once (the explicit zero
+ * padding of lvg_conv2d_frames / lvg_conv2d_frames_wgrad). oth / partial as above (dense frames of src_h * src_w pixels). */
+int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                                      int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
+                                      int dst_h, int dst_w, int off_y, int off_x, int dtype, void* stream);
+
+/*
+ * Dense 3 x 3 contraction of the super-resolution networks as a hand-written implicit GEMM (csrc/conv2d_igemm.hip) and its
+ * weight gradient (csrc/conv2d_wgrad.hip), on channels-last frames whose zero padding is written explicitly in memory
+ * ('valid' correlation; float16 / bfloat16, float32 accumulation):
+ *
+ *   lvg_conv2d_frames:  out[n][oy][ox][co] = pre[n][co] * sum_{dh, dw, ci} x[n][oy + in_off_y + dh][ox + in_off_x + dw][ci] * w[dh][dw][co][ci]
+ *     x [n][hi][wi] pixels of x_pixel_stride elements (>= ci, % 8; 0 = ci), w [3][3][co][ci] tap-major, out [n][ho][wo] pixels of
+ *     out_pixel_stride elements (0 = co), ho <= hi - in_off_y - 2, wo <= wi - in_off_x - 2; pre float32 [n][co] or NULL (= 1); ci % 64 == 0, co % 64 == 0;
+ *     fewer than 2^32 bytes of x. Run on the padded output gradient with the weight mirrored in both taps and its channel
+ *     roles exchanged it is the data gradient.
+ *   lvg_conv2d_frames_wgrad:  part[s][dh][dw][co][ci] = sum over the K-steps of range s of dy[n][oy][ox][co] * x[n][oy + dh][ox + dw][ci]
+ *     dy [n][hd][wd] (hd % 4 == 0, wd % 16 == 0: 4 x 16 pixel patches; rows / columns past the true gradient hold zeros),
+ *     x [n][hx][wx] with hx >= hd + 2, wx >= wd + 2 (finite everywhere); part float32 [splits][3][3][co][ci], the caller adds the
+ *     ranges in order (reproducible); splits = lvg_conv2d_frames_wgrad_splits(...) (0: no kernel for the shape).
+ *   lvg_conv2d_frames_workgroups: workgroups lvg_conv2d_frames launches (0: no kernel for the shape).
+ *
+ * Replace the library convolution inside the reference's modulated_conv2d (model/generator_sres.py:63-66:
+ * conv2d_gradfix.conv2d(..., padding = kernel - 1, groups = batch) -- here one dense convolution between the style / demodulation
+ * passes of lvg_modconv2d_*) and what autograd derives for it (torch_utils/ops/conv2d_gradfix.py:37-45). No reference plugin
+ * entry point (the reference calls cuDNN through F.conv2d); binding: long-video-gan_amd/torch_utils/ops/conv2d_frames.py.
+ */
+int64_t lvg_conv2d_frames_workgroups(int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int kh, int kw);
+int lvg_conv2d_frames(const void* x, const void* w, const float* pre, void* out,
+                      int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int kh, int kw, int in_off_y, int in_off_x,
+                      int64_t x_pixel_stride, int64_t out_pixel_stride, int dtype, void* stream);
+int lvg_conv2d_frames_wgrad_splits(int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw);
+int lvg_conv2d_frames_wgrad(const void* x, const void* dy, float* part,
+                            int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw,
+                            int64_t x_pixel_stride, int64_t dy_pixel_stride, int splits, int dtype, void* stream);
 
 /*
  * Adam step over one flat float32 range, optionally followed by the exponential moving average of the updated

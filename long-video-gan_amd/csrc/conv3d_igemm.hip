@@ -42,602 +42,9 @@
 //    on the 512-channel layers (profiles/r02_conv_direct_weights.log) -- fragment-shaped loads (32 rows x 32 bytes per
 //    instruction, every weight byte fetched by two waves) saturate the texture-address path long before the matrix pipe.
 
-#include "epilogue_common.h"
-#include <stdlib.h>
-#include <string.h>
+#include "igemm_kernel.h"
 
 namespace {
-
-struct ConvArgs
-{
-    const void*  x;
-    const void*  w;
-    const float* pre;
-    const void*  b;
-    const void*  res;
-    const float* post;
-    void*        out;
-    void*        ysum;
-    float*       msqPartial;   // one float per workgroup (sum of squares of the value before `post`), or NULL
-    int64_t      M;            // frames * H * W
-    int64_t      tShift;       // pixels between consecutive time steps (= clips * H * W)
-    int          H, W, Ci, Co, kt, kh, kw;
-    int          xStride;      // elements between consecutive pixels of x (>= Ci: x may be a channel slice of a wider tensor)
-    int          reach;        // (kh/2) * W + kw/2: pixels of halo on each side of a tile
-    int          bandRows;     // BM + 2 * reach, rounded up to a multiple of 8
-    int          nABuf;        // 2 when there is more than one band per tile
-    int          nBBuf;        // weight-tile ring: 2 (prefetch one K-step ahead) or 3 (two)
-    int          nTiles;       // Co / BN
-    float        slopeNeg;     // activation as max-free form: u > 0 ? u : u * slopeNeg (linear 1, relu 0, lrelu alpha)
-    float        gain, clamp;
-};
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-template <class T> struct Mma;
-template <> struct Mma<bf16_t>
-{
-    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, const f32x16& c)
-    {
-        bf16x8 av, bv;
-        __builtin_memcpy(&av, &a, 16);
-        __builtin_memcpy(&bv, &b, 16);
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
-    }
-};
-template <> struct Mma<f16_t>
-{
-    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, const f32x16& c)
-    {
-        f16x8 av, bv;
-        __builtin_memcpy(&av, &a, 16);
-        __builtin_memcpy(&bv, &b, 16);
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
-    }
-};
-
-// Measurement builds only (-DLVG_CONV_ABL=bits): 1 no staging in the K loop, 2 no MFMA, 4 no fragment reads,
-// 16 no wait / barrier, 64 no band staging, 128 no weight staging, 256 no output stores, 512 direct 8-byte stores (no LDS transpose).
-// The shipped library is built with 0.
-#ifndef LVG_CONV_ABL
-#define LVG_CONV_ABL 0
-#endif
-constexpr int kAbl = LVG_CONV_ABL;
-#ifndef LVG_CONV_PIN
-#define LVG_CONV_PIN 1
-#endif
-constexpr bool kPinOrder = LVG_CONV_PIN != 0;
-#ifndef LVG_CONV_PRIO
-#define LVG_CONV_PRIO 1
-#endif
-constexpr int kPrio = LVG_CONV_PRIO;        // 1: the arithmetic of a K-step (fragment reads + MFMAs) runs at wave priority 1, staging / waits at 0
-constexpr int kBK = 64;       // input channels per K-step (one 128-byte LDS row)
-constexpr int kRowBytes = kBK * 2;
-constexpr int kZeroBytes = 1024;   // LDS [0, 1024): zeros (what masked lanes read); the tiles follow
-
-// One 1-KiB piece (8 LDS rows x 128 B) per wave instruction: lane -> (row in piece, physical chunk).
-// Returns the LOGICAL 16-byte chunk this lane must fetch so that the lane-linear LDS image is the swizzled one.
-__device__ __forceinline__ int piece_chunk(int piece, int lane)
-{
-    const int row = piece * 8 + (lane >> 3);
-    return (lane & 7) ^ ((row >> 1) & 7);
-}
-
-// LDS-DMA of 16 bytes per lane: LDS address = ldsPiece (wave-uniform, via M0) + lane * 16; source = base (SGPR pair)
-// + 32-bit lane offset. Inline assembly on purpose: hipcc orders every later ds_read behind a
-// `__builtin_amdgcn_global_load_lds` it has seen (s_waitcnt vmcnt(0) before the first fragment read of the K-step,
-// i.e. no overlap of the prefetch with the MFMAs of the same wave); an asm statement is outside its bookkeeping, the
-// kernel waits (vmcnt) itself before the barrier that publishes the tile. M0 is not used by anything else here.
-__device__ __forceinline__ void dma16(const unsigned char* base, uint32_t laneOff, uint32_t ldsPiece)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(laneOff), "s"(base), "s"(ldsPiece) : "memory");
-}
-
-template <int N> __device__ __forceinline__ void wait_vm_const()
-{
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
-
-template <class T, int BM, int BN, int PB, int NB>
-__global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(ConvArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW  = BM / (32 * PB) * 2;      // waves: BM / (32 PB) along the pixels x 2 along the output channels
-    constexpr int NCB = BN / 64;                 // 32-channel MFMA blocks per wave
-    constexpr int NWA = NW / 4;                  // band-staging waves (the last NWA) when the kernel has spatial taps
-    constexpr int NWB = NW - NWA;                // weight-staging waves then
-    constexpr int NBP = BN / 8;                  // weight pieces per K-step
-    constexpr int NBI = (NBP + NWB - 1) / NWB;   // ... per wave, at most
-    constexpr int MAXAI = 6;                     // band pieces per wave and K-step (host guarantees)
-    constexpr int bBytes = BN * kRowBytes;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    // XCD-aware tile order: the dispatcher puts workgroup b on XCD b % 8; give every XCD a contiguous range of
-    // tiles (channel tile fastest), so that the workgroups sharing an L2 share bands and walk the weights together.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
-    const int mt = tile / p.nTiles, nt = tile - mt * p.nTiles;
-    const int64_t m0 = (int64_t)mt * BM;
-    const int co0 = nt * BN;
-
-    // LDS: [zero page | nBBuf weight tiles | nABuf bands]
-    const int aBytes = p.bandRows * kRowBytes;
-    const uint32_t ldsBase = (uint32_t)(uintptr_t)smem;                 // generic -> LDS byte address (low 32 bits)
-    const int bOff = kZeroBytes, aOff = kZeroBytes + p.nBBuf * bBytes;
-
-    const int ntap = p.kh * p.kw;
-    const int nchunk = p.Ci / kBK;
-    const int nMacro = p.kt * nchunk;
-    const int nSteps = nMacro * ntap;
-    const int nAI = p.bandRows >> 3;                                   // band pieces in total
-    // weight-tile ring: NB slots with spatial taps (tiles staged NB - 1 K-steps ahead), 2 without (host sets nBBuf)
-    const int dist = p.nBBuf - 1;
-    // Without spatial taps (one K-step per band) everything is staged by all waves one K-step ahead (host: nBBuf = 2).
-    const bool split = ntap > 1;
-    const int bWaves = split ? NWB : NW, aWaves = split ? NWA : NW, aWave0 = split ? NWB : 0;
-    const bool isB = wave < bWaves;
-    const int aPerStep = (nAI + aWaves * ntap - 1) / (aWaves * ntap);  // per band wave and K-step (<= MAXAI)
-    const int aPerStep0 = (nAI + NW * ntap - 1) / (NW * ntap);         // prologue: all waves
-    const int pt = p.kt >> 1;
-
-    const unsigned char* const xb = static_cast<const unsigned char*>(p.x);
-    const unsigned char* const wb = static_cast<const unsigned char*>(p.w);
-    const uint32_t rowStride = (uint32_t)p.Ci * 2;                     // bytes per weight row
-    const uint32_t xRowStride = (uint32_t)p.xStride * 2;               // bytes per pixel of x
-
-    if (tid < kZeroBytes / 16) reinterpret_cast<uint4*>(smem)[tid] = make_uint4(0, 0, 0, 0);
-
-    // ---- staging -----------------------------------------------------------------------------------------------
-    // Weight tiles: per lane and piece the source offset inside a tile is fixed; the tile base is a running pointer.
-    uint32_t bLaneOff[NBI];
-    int bPiece[NBI];                                                   // LDS piece of each; a wave with fewer pieces repeats its last
-    #pragma unroll
-    for (int i = 0; i < NBI; i++)
-    {
-        int piece = wave + i * bWaves;
-        if (piece >= NBP) piece -= bWaves;                             // NBI - 1 pieces exist for every weight wave
-        bPiece[i] = piece;
-        bLaneOff[i] = (uint32_t)(piece * 8 + (lane >> 3)) * rowStride + piece_chunk(piece, lane) * 16;
-    }
-    const uint64_t tapStride = (uint64_t)p.Co * rowStride;             // bytes between the tiles of consecutive taps
-    const uint64_t macroJump = (uint64_t)ntap * tapStride - (uint64_t)(nchunk - 1) * kRowBytes;   // last chunk -> next temporal tap
-    const unsigned char* wMacro = wb + (uint64_t)co0 * rowStride;      // tap 0 of the band the NEXT staged tile belongs to
-    const unsigned char* wNext = wMacro;                               // the next tile to stage
-    int nTap = 0, nKc = 0;                                             // its (spatial tap, chunk)
-    auto issueB = [&](int buf) -> int
-    {
-        int issued = 0;
-        #pragma unroll
-        for (int i = 0; i < NBI; i++)
-        {
-            const int piece = wave + i * bWaves;
-            if (isB && piece < NBP)
-            {
-                dma16(wNext, bLaneOff[i], ldsBase + bOff + buf * bBytes + piece * 1024);
-                issued++;
-            }
-        }
-        // advance to the tile of the next K-step: next tap; then next chunk of the same temporal tap; then next temporal tap
-        if (++nTap == ntap)
-        {
-            nTap = 0;
-            if (++nKc == nchunk) { nKc = 0; wMacro += macroJump; }
-            else wMacro += kRowBytes;
-            wNext = wMacro;
-        }
-        else wNext += tapStride;
-        return issued;
-    };
-    // Band pieces of (dt, kc) that this wave brings in during K-step `tapSlot` of the previous band (waves w0 .. w0 + nw - 1
-    // share the band, `per` pieces per wave and K-step). Source rows are clamped into the tensor: clamped rows are only
-    // ever read by masked lanes.
-    const uint32_t aChunkOff = (uint32_t)(lane & 7);
-    auto issueA = [&](int dt, int kc, int tapSlot, int buf, int per, int nw, int w0)
-    {
-        const int g0 = (int)(m0 - p.reach + (int64_t)(dt - pt) * p.tShift);     // |.| < 2^31 (host check)
-        const int last = (int)p.M - 1;
-        #pragma unroll
-        for (int i = 0; i < MAXAI; i++)
-        {
-            const int piece = (tapSlot * per + i) * nw + (wave - w0);
-            if (i < per && wave >= w0 && piece < nAI)
-            {
-                int g = g0 + piece * 8 + (lane >> 3);
-                g = g < 0 ? 0 : (g > last ? last : g);
-                const uint32_t chunk = aChunkOff ^ (uint32_t)(((piece * 8 + (lane >> 3)) >> 1) & 7);
-                const uint32_t off = (uint32_t)g * xRowStride + (uint32_t)kc * kRowBytes + chunk * 16;  // < 2^32 (host check)
-                dma16(xb, off, ldsBase + aOff + buf * aBytes + piece * 1024);
-            }
-        }
-    };
-
-    // ---- which temporal taps and which spatial taps read a real pixel, per lane and pixel block ------------------
-    uint32_t vmask[PB];
-    int jrow[PB];
-    #pragma unroll
-    for (int pb = 0; pb < PB; pb++)
-    {
-        const int j = wr * (32 * PB) + pb * 32 + l31;
-        jrow[pb] = j;
-        const int64_t m = m0 + j;
-        uint32_t mask = 0;
-        if (m < p.M)
-        {
-            const uint32_t row = (uint32_t)m / (uint32_t)p.W;         // M < 2^31 (host check)
-            const int ww = (int)((uint32_t)m - row * (uint32_t)p.W);
-            const int hh = (int)(row % (uint32_t)p.H);
-            uint32_t sp = 0;
-            for (int dh = 0; dh < p.kh; dh++)
-                for (int dw = 0; dw < p.kw; dw++)
-                {
-                    const int y = hh + dh - (p.kh >> 1), x = ww + dw - (p.kw >> 1);
-                    if (y >= 0 && y < p.H && x >= 0 && x < p.W) sp |= 1u << (dh * p.kw + dw);
-                }
-            mask = sp;                                                // bits 0 .. 24: spatial taps; bits 25 .. 31: temporal taps
-            for (int dt = 0; dt < p.kt; dt++)
-            {
-                const int64_t ms = m + (int64_t)(dt - pt) * p.tShift;
-                if (ms >= 0 && ms < p.M) mask |= 1u << (25 + dt);
-            }
-        }
-        vmask[pb] = mask;
-    }
-
-    f32x16 acc[NCB][PB];
-    #pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-        #pragma unroll
-        for (int pb = 0; pb < PB; pb++)
-            #pragma unroll
-            for (int r = 0; r < 16; r++) acc[cb][pb][r] = 0.f;
-
-    // Fragment addresses. Row r, logical chunk c = 2 ks + hi lives at byte r * 128 + ((c ^ key(r)) << 4), key = (r >> 1) & 7,
-    // and (2 ks + hi) ^ key = (hi ^ key) ^ 2 ks: address = rowBase + (e ^ (ks << 5)) with e = (hi ^ key) << 4.
-    uint32_t wAddr[NCB][4];                                           // weight fragments: fixed per lane (+ ring position)
-    #pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-    {
-        const int row = wc * (BN / 2) + cb * 32 + l31;
-        const uint32_t e = (uint32_t)(hi ^ ((row >> 1) & 7)) << 4;
-        #pragma unroll
-        for (int ks = 0; ks < 4; ks++) wAddr[cb][ks] = (uint32_t)(bOff + row * kRowBytes) + (e ^ (uint32_t)(ks << 5));
-    }
-
-    // ---- prologue: first band (all waves), first `dist` weight tiles ------------------------------------------------
-    for (int t = 0; t < ntap; t++) issueA(0, 0, t, 0, aPerStep0, NW, 0);
-    for (int d = 0; d < dist; d++)
-        if (d < nSteps) issueB(d);
-    wait_vm_const<0>();
-    __syncthreads();
-
-    // ---- K loop: (dt, kc) = band, tap = spatial tap inside it --------------------------------------------------------
-    int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
-    (void)dh;
-    int bufNext = dist;                                               // ring slot the next staged weight tile goes to
-    uint32_t curB = 0;                                                // byte offset of the current weight tile in the ring
-    uint32_t curA = (uint32_t)aOff;                                   // byte offset of the current band
-    const uint32_t ringBytes = (uint32_t)(p.nBBuf * bBytes);
-
-    // One K-step of arithmetic: fragment addresses of this tap, then 4 x (fragment reads, MFMAs) with the reads of
-    // sub-step ks + 1 issued ahead of the MFMAs of sub-step ks (two fragment register sets).
-    int shift = 0, tbit = 25;                                         // dh * W + dw and 25 + dt of the current K-step
-    auto compute = [&]() __attribute__((always_inline))
-    {
-        uint32_t xBase[PB], xE[PB];
-        #pragma unroll
-        for (int pb = 0; pb < PB; pb++)
-        {
-            const uint32_t rb = (uint32_t)(jrow[pb] + shift);
-            const bool ok = (vmask[pb] >> tap) & (vmask[pb] >> tbit) & 1u;
-            xE[pb] = ((uint32_t)hi ^ ((rb >> 1) & 7u)) << 4;
-            // masked lanes read zeros from the 256-byte zero page at the SAME bank position (row parity kept): the
-            // conflict-free bank pattern of the group survives
-            xBase[pb] = ok ? curA + (rb << 7) : ((rb & 1u) << 7);
-        }
-        uint4 wf[2][NCB], xf[2][PB];
-        auto fetch = [&](int ks, int set) __attribute__((always_inline))
-        {
-            if constexpr (!(kAbl & 4))
-            {
-                #pragma unroll
-                for (int cb = 0; cb < NCB; cb++)
-                    wf[set][cb] = *reinterpret_cast<const uint4*>(smem + (wAddr[cb][ks] + curB));
-                #pragma unroll
-                for (int pb = 0; pb < PB; pb++)
-                    xf[set][pb] = *reinterpret_cast<const uint4*>(smem + (xBase[pb] + (xE[pb] ^ (uint32_t)(ks << 5))));
-            }
-            else
-            {
-                #pragma unroll
-                for (int cb = 0; cb < NCB; cb++) wf[set][cb] = make_uint4(ks, tap, cb, 1);
-                #pragma unroll
-                for (int pb = 0; pb < PB; pb++) xf[set][pb] = make_uint4(ks, tap, pb, xBase[pb]);
-            }
-        };
-        if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(1);
-        fetch(0, 0);
-        #pragma unroll
-        for (int ks = 0; ks < kBK / 16; ks++)
-        {
-            if (ks + 1 < kBK / 16) fetch(ks + 1, (ks + 1) & 1);
-            if constexpr (!(kAbl & 2))
-            {
-                #pragma unroll
-                for (int pb = 0; pb < PB; pb++)
-                    #pragma unroll
-                    for (int cb = 0; cb < NCB; cb++)
-                        acc[cb][pb] = Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
-            }
-            else
-            {
-                #pragma unroll
-                for (int cb = 0; cb < NCB; cb++)
-                    #pragma unroll
-                    for (int pb = 0; pb < PB; pb++)
-                        acc[cb][pb][ks] += __uint_as_float(wf[ks & 1][cb].x ^ xf[ks & 1][pb].y ^ wf[ks & 1][cb].w ^ xf[ks & 1][pb].z);
-            }
-        }
-        // Pin the order the source states (hipcc otherwise re-uses ONE fragment register set and issues the reads of sub-step
-        // ks + 1 behind the MFMAs of sub-step ks, exposing the LDS latency four times per K-step): reads(0), then
-        // 3 x [reads(ks + 1), MFMAs(ks)], MFMAs(3).   masks: 0x100 = DS read, 0x8 = MFMA
-        if constexpr (kAbl == 0 && kPinOrder)
-        {
-            __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
-            #pragma unroll
-            for (int ks = 0; ks < kBK / 16 - 1; ks++)
-            {
-                __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
-        }
-        if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(0);
-    };
-    // counters of the next K-step
-    auto advance = [&]() __attribute__((always_inline))
-    {
-        curB += bBytes;
-        if (curB == ringBytes) curB = 0;
-        if (++bufNext == p.nBBuf) bufNext = 0;
-        shift++;
-        if (++dw == p.kw) { dw = 0; dh++; shift += p.W - p.kw; }
-        if (++tap == ntap)
-        {
-            tap = 0; dh = 0; dw = 0; shift = 0; macro++;
-            if (++kc == nchunk) { kc = 0; dt++; tbit++; }
-            curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);  // nABuf == 1 only when there is one band
-        }
-    };
-
-    if (!split)
-    {
-        // no spatial taps: every wave stages its share of both operands one K-step ahead
-        for (int step = 0; step < nSteps; step++)
-        {
-            const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;
-            const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
-            if (step + dist < nSteps && !(kAbl & (1 | 128))) issueB(bufNext);
-            if (macro + 1 < nMacro && !(kAbl & (1 | 64))) issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
-            compute();
-            if constexpr (!(kAbl & 16)) { wait_vm_const<0>(); __syncthreads(); }
-            advance();
-        }
-    }
-    else if (isB)
-    {
-        // Weight waves: NBI pieces per K-step, always (where no tile is left to stage an earlier one is staged again into a ring
-        // slot nobody reads any more): no branches between the staging and the MFMAs, counted wait. The taps of a band are two
-        // plain loops -- while the staged tile (NB - 1 K-steps ahead) still belongs to this band, and after it moved on to the
-        // next band -- so the per-step scalar work is the staging itself and a handful of counters.
-        constexpr int D = NB - 1;
-        const uint32_t ldsB0 = ldsBase + bOff;
-        uint32_t stageOff = (uint32_t)(D * bBytes);                    // ring offset of the slot being staged
-        auto kstep = [&]() __attribute__((always_inline))
-        {
-            if constexpr (!(kAbl & (1 | 128)))
-            {
-                #pragma unroll
-                for (int i = 0; i < NBI; i++)
-                    dma16(wNext, bLaneOff[i], ldsB0 + stageOff + bPiece[i] * 1024);
-                wNext += tapStride;
-            }
-            compute();
-            if constexpr (!(kAbl & 16))
-            {
-                wait_vm_const<(D > 1 ? NBI : 0)>();
-                __syncthreads();
-            }
-            stageOff += bBytes;
-            if (stageOff == ringBytes) stageOff = 0;
-            curB += bBytes;
-            if (curB == ringBytes) curB = 0;
-            tap++;
-            shift++;
-            if (++dw == p.kw) { dw = 0; dh++; shift += p.W - p.kw; }
-        };
-        // the prologue staged the first D tiles of band 0 through the generic path: wNext already points D taps in
-        for (macro = 0; macro < nMacro; macro++)
-        {
-            tap = 0; dh = 0; dw = 0; shift = 0;
-            curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
-            for (int t = 0; t < ntap - D; t++) kstep();
-            // the staged tile moves on to the next band (on the last band: back to this band's first tile, never read)
-            if (macro + 1 < nMacro) wMacro += (kc + 1 == nchunk) ? macroJump : (uint64_t)kRowBytes;
-            wNext = wMacro;
-            for (int t = 0; t < D; t++) kstep();
-            if (++kc == nchunk) { kc = 0; dt++; tbit++; }
-        }
-    }
-    else
-    {
-        // band waves: the pieces of the next band, spread over the taps of this one; waited for at its last tap
-        for (int step = 0; step < nSteps; step++)
-        {
-            const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;
-            const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
-            if (macro + 1 < nMacro && !(kAbl & (1 | 64))) issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
-            compute();
-            if constexpr (!(kAbl & 16))
-            {
-                if (tap == ntap - 1) wait_vm_const<0>();
-                __syncthreads();
-            }
-            advance();
-        }
-    }
-
-    // ---- epilogue: registers -> LDS (wave-private rows of this wave's 64 / 32 output channels) -> 16-byte channels-last stores -------
-    // A result lane holds ONE pixel and 4 output channels per register quad: stored directly, a wave instruction writes 16 bytes to
-    // each of 32 cache lines (measured: 36 % of the kernel time on the 128-channel layers, ablation bit 256). Through LDS a wave
-    // instruction writes whole 128-byte (64-byte for 32-channel wave tiles) pixel rows instead.
-    // Staging rows have a pitch of row bytes + 16; the two 8-byte halves of a 16-byte chunk are exchanged in rows 16 .. 31 of a pixel
-    // block, which makes the 8-byte writes of the 32 lanes of a half wave hit 64 distinct banks (exchanged back, statically, on read).
-    const T* bias = static_cast<const T*>(p.b);
-    const T* res  = static_cast<const T*>(p.res);
-    T* out  = static_cast<T*>(p.out);
-    T* ysum = static_cast<T*>(p.ysum);
-    const uint32_t hw = (uint32_t)(p.H * p.W);
-    constexpr int WCO = NCB * 32;                 // output channels of a wave tile
-    constexpr int RB = WCO * 2;                   // bytes of a staged pixel row
-    constexpr int PITCH = RB + 16;
-    constexpr int ROWS = PB * 32;                 // pixels of a wave tile
-    constexpr int CPR = RB / 16;                  // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;                 // rows per wave instruction on the way out
-    constexpr int NI = ROWS / RPI;
-    constexpr bool kLdsStore = !(kAbl & 512);
-    unsigned char* const stage = smem + wave * (ROWS * PITCH);
-    if constexpr (kLdsStore)
-    {
-        wait_vm_const<0>();                       // weight waves leave the K loop with re-staged tiles still in flight towards LDS
-        __syncthreads();
-    }
-    const int flipW = (l31 >> 4) & 1;
-    // 16-byte stores of the staged wave tile to `dst` (rows = pixels m0 + wr * ROWS + ..., this wave's channel range)
-    auto flush = [&](T* dst) __attribute__((always_inline))
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        #pragma unroll
-        for (int i = 0; i < NI; i++)
-        {
-            const int R = i * RPI + lane / CPR, c = lane % CPR;
-            uint4 v = *reinterpret_cast<const uint4*>(stage + R * PITCH + c * 16);
-            if (((i * RPI) >> 4) & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-            const int64_t m = m0 + wr * ROWS + R;
-            if (m < p.M) *reinterpret_cast<uint4*>(dst + m * p.Co + (co0 + wc * WCO + c * 8)) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    float sq = 0.f;
-    #pragma unroll
-    for (int pb = 0; pb < PB; pb++)
-    {
-        const int64_t mt_ = m0 + jrow[pb];
-        const bool valid = mt_ < p.M;
-        if constexpr (!kLdsStore) { if (!valid) continue; }
-        const int64_t m = valid ? mt_ : p.M - 1;                     // rows past the end: computed on the last pixel's terms, never stored
-        const int64_t f = (uint32_t)m / hw;
-        #pragma unroll
-        for (int cb = 0; cb < NCB; cb++)
-            #pragma unroll
-            for (int qd = 0; qd < 4; qd++)
-            {
-                const int co = co0 + wc * (BN / 2) + cb * 32 + 8 * qd + 4 * hi;
-                float pre4[4] = {1.f, 1.f, 1.f, 1.f}, post4[4] = {1.f, 1.f, 1.f, 1.f}, add4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.pre)  { const float4 v = *reinterpret_cast<const float4*>(p.pre + f * p.Co + co);  pre4[0] = v.x; pre4[1] = v.y; pre4[2] = v.z; pre4[3] = v.w; }
-                if (p.post) { const float4 v = *reinterpret_cast<const float4*>(p.post + f * p.Co + co); post4[0] = v.x; post4[1] = v.y; post4[2] = v.z; post4[3] = v.w; }
-                if (bias)
-                {
-                    uint2 raw = *reinterpret_cast<const uint2*>(bias + co);
-                    T t4[4];
-                    __builtin_memcpy(t4, &raw, 8);
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
-                }
-                if (res)
-                {
-                    uint2 raw = *reinterpret_cast<const uint2*>(res + m * p.Co + co);
-                    T t4[4];
-                    __builtin_memcpy(t4, &raw, 8);
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
-                }
-                T o4[4], y4[4];
-                float sqq = 0.f;
-                #pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    const float a = acc[cb][pb][qd * 4 + e];
-                    const float u = fmaf(a, pre4[e], add4[e]);
-                    float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
-                    if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
-                    if constexpr (kLdsStore) sqq = fmaf(g, g, sqq); else sq = fmaf(g, g, sq);
-                    o4[e] = from_acc<T>(g * post4[e]);
-                    y4[e] = from_acc<T>(a);
-                }
-                if (kLdsStore && valid) sq += sqq;
-                uint2 ov, yv;
-                __builtin_memcpy(&ov, o4, 8);
-                __builtin_memcpy(&yv, y4, 8);
-                if constexpr (kLdsStore)
-                    *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
-                else if (!(kAbl & 256) || sq == 12345.f)                 // (ablation 256: no output stores)
-                {
-                    *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
-                    if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
-                }
-            }
-    }
-    if constexpr (kLdsStore)
-    {
-        if (!(kAbl & 256) || sq == 12345.f)
-        {
-            flush(out);
-            if (ysum)
-            {
-                #pragma unroll
-                for (int pb = 0; pb < PB; pb++)
-                    #pragma unroll
-                    for (int cb = 0; cb < NCB; cb++)
-                        #pragma unroll
-                        for (int qd = 0; qd < 4; qd++)
-                        {
-                            T y4[4];
-                            #pragma unroll
-                            for (int e = 0; e < 4; e++) y4[e] = from_acc<T>(acc[cb][pb][qd * 4 + e]);
-                            uint2 yv;
-                            __builtin_memcpy(&yv, y4, 8);
-                            *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = yv;
-                        }
-                flush(ysum);
-            }
-        }
-        __syncthreads();                          // the statistic below re-uses the front of the LDS
-    }
-    if (p.msqPartial)
-    {
-        sq = wave_sum(sq);
-        float* red = reinterpret_cast<float*>(smem) + 64;   // the K loop ended with a barrier; LDS past the zero rows in use
-        if (lane == 0) red[wave] = sq;
-        __syncthreads();
-        if (tid == 0)
-        {
-            float tot = 0.f;
-            for (int i = 0; i < NW; i++) tot += red[i];
-            p.msqPartial[tile] = tot;
-        }
-    }
-}
 
 struct Plan
 {

@@ -48,6 +48,10 @@ struct LayoutArgs
     int cDst;                              // nhwc_to_nchw: channels written
     int cOth;                              // nchw_to_nhwc: channels (= pixel stride) of the NHWC reduction partner
     int vecP;                              // 1: pixel rows of the NCHW tensors may be accessed as 16-byte vectors
+    // nchw_to_nhwc into a LARGER frame (the explicitly zero-padded frames of conv2d_igemm.hip / conv2d_wgrad.hip): source pixel
+    // p = y * srcW + x goes to pixel (y + offY) * dstW + (x + offX) of a frame of dstHW pixels; srcW == 0: same frame (pixel p).
+    // The border is NOT written here (the caller zero-fills the tensor once).
+    int srcW, dstW, dstHW, offY, offX;
 };
 
 template <class T> __device__ __forceinline__ float ld1(const T* p) { return (float)to_acc(*p); }
@@ -113,7 +117,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
                 const float s = (a.scale && cc + j < cSrc) ? a.scale[n * cSrc + cc + j] : 1.0f;
                 out.v[j] = from_acc<T>(x[j] * s);
             }
-            store_vec16<T>((T*)a.dst + (n * a.hw + p) * (int64_t)a.cNhwc + cc, out);
+            int64_t dp = n * a.hw + p;
+            if (a.srcW > 0)
+            {
+                const int y = p / a.srcW, x = p - y * a.srcW;
+                dp = n * a.dstHW + (int64_t)(y + a.offY) * a.dstW + (x + a.offX);
+            }
+            store_vec16<T>((T*)a.dst + dp * (int64_t)a.cNhwc + cc, out);
             if (a.partial && cc < a.cOth)
             {
                 const Vec16<T> o = load_vec16<T>((const T*)a.othA + (n * a.hw + p) * (int64_t)a.cOth + cc);
@@ -229,8 +239,33 @@ int check_common(const char* what, int64_t n, int64_t hw, int dtype)
 
 } // namespace
 
+static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                               int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream,
+                               int src_w, int dst_h, int dst_w, int off_y, int off_x);
+
 extern "C" int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                           int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream)
+{
+    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, hw, c_a, c_b, c_dst, c_oth, dtype, stream, 0, 0, 0, 0, 0);
+}
+
+// The same pass writing into the interior of a larger channels-last frame [n][dst_h][dst_w][c_dst] at (off_y, off_x): source planes are
+// src_h x src_w (hw = src_h * src_w). The caller zero-fills `dst` beforehand (border pixels and nothing else keep that zero). `oth` /
+// `partial` (the reduction partner, dense frames of hw pixels) as in lvg_modconv2d_nchw_to_nhwc.
+extern "C" int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                                                 int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
+                                                 int dst_h, int dst_w, int off_y, int off_x, int dtype, void* stream)
+{
+    LVG_REQUIRE(src_h >= 1 && src_w >= 1 && off_y >= 0 && off_x >= 0 && dst_h >= src_h + off_y && dst_w >= src_w + off_x,
+                "modconv2d_nchw_to_nhwc_padded: the source plane must fit inside the destination frame");
+    LVG_REQUIRE((int64_t)dst_h * dst_w <= 0x3fffffffLL, "modconv2d_nchw_to_nhwc_padded: destination frame too large");
+    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, (int64_t)src_h * src_w, c_a, c_b, c_dst, c_oth, dtype, stream,
+                               src_w, dst_h, dst_w, off_y, off_x);
+}
+
+static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                               int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream,
+                               int src_w, int dst_h, int dst_w, int off_y, int off_x)
 {
     if (int rc = check_common("modconv2d_nchw_to_nhwc", n, hw, dtype)) return rc;
     LVG_REQUIRE(src_a && dst && c_a >= 1 && c_b >= 0 && (c_b == 0 || src_b), "modconv2d_nchw_to_nhwc: bad sources");
@@ -241,6 +276,7 @@ extern "C" int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, 
     LayoutArgs a = {};
     a.srcA = src_a; a.srcB = src_b; a.othA = oth; a.dst = dst; a.scale = scale; a.partial = partial;
     a.n = (int)n; a.hw = (int)hw; a.cA = c_a; a.cB = c_b; a.cNhwc = c_dst; a.cOth = c_oth;
+    a.srcW = src_w; a.dstW = dst_w; a.dstHW = dst_h * dst_w; a.offY = off_y; a.offX = off_x;
     a.vecP = (hw % 8 == 0) && lvg_aligned16(src_a) && (!src_b || lvg_aligned16(src_b));
     dim3 grid((unsigned)lvg_ceil_div(hw, kTile), (unsigned)lvg_ceil_div(c_dst, kTile), (unsigned)n);
     if (dtype == LVG_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -49,6 +49,11 @@ _SIGNATURES = {
     'lvg_video_from_uint8': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nchw_to_nhwc': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nhwc_to_nchw': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
+    'lvg_modconv2d_nchw_to_nhwc_padded': [_vp] * 6 + [_i64] + [_i32] * 11 + [_vp],
+    'lvg_conv2d_frames_workgroups': [_i64] + [_i32] * 8,
+    'lvg_conv2d_frames': [_vp] * 4 + [_i64] + [_i32] * 10 + [_i64, _i64, _i32, _vp],
+    'lvg_conv2d_frames_wgrad_splits': [_i64] + [_i32] * 8,
+    'lvg_conv2d_frames_wgrad': [_vp] * 3 + [_i64] + [_i32] * 8 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
     'lvg_tapconv_epilogue_backward': [_vp] * 10 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
 }
@@ -65,7 +70,7 @@ def lib():
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_bias_act_grad_bias_slots') else ctypes.c_int
+            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_bias_act_grad_bias_slots', 'lvg_conv2d_frames_workgroups') else ctypes.c_int
         _lib = handle
     return _lib
 

@@ -1,0 +1,129 @@
+"""Dense 3 x 3 contraction of the super-resolution networks on the hand-written kernels: `lvg_conv2d_frames`
+(csrc/conv2d_igemm.hip: implicit GEMM on v_mfma_f32_32x32x16 over 8 x 16 pixel tiles, forward and -- with the weight
+mirrored and its channel roles exchanged -- data gradient) and `lvg_conv2d_frames_wgrad` (csrc/conv2d_wgrad.hip).
+
+This is the `conv2d_gradfix.conv2d(x, w, padding = p)` inside the reference's `modulated_conv2d`
+(model/generator_sres.py:63-66; F.conv2d on torch >= 1.11, torch_utils/ops/conv2d_gradfix.py:37-45) and what autograd
+derives for it, restated on channels-last frames whose ZERO PADDING IS WRITTEN IN MEMORY: the layout prologue that
+produces the frames (modconv2d_layout) writes the interior of a zero-filled, slightly larger frame, after which the
+convolution is a 'valid' correlation and neither kernel has a mask or an edge case.
+
+Coordinates (`Geometry`): a plane of h x w pixels convolved with 3 x 3 taps and padding p in {0, 1, 2}.
+  input frame    hx x wx, the plane at (2, 2):   hx = hd + 2, wx = wd + 2
+  valid positions (a, b) of the correlation over that frame: output pixel (oy, ox) of the padded convolution is position
+                 (oy + q, ox + q) with q = 2 - p; positions outside the output carry no gradient
+  gradient frame hd x wd = the valid positions rounded up to whole 4 x 16 pixel patches (the K-step of the weight
+                 gradient): hd = ceil4(h + 2), wd = ceil16(w + 2); the output gradient sits at (q, q), zeros elsewhere
+so that  gw[dh][dw] = sum dy_frame[a][b] * x_frame[a + dh][b + dw]  and  dx[y][x] = sum dy_frame[y + dh][x + dw] * w[2 - dh][2 - dw]
+hold without offsets. Tensors here are plain contiguous [N, H, W, C] arrays; channel counts are multiples of 64.
+
+CPU tensors take the explicit PyTorch composition below (the definition the GPU tests compare against, next to the C oracle)."""
+
+import torch
+import torch.nn.functional as F
+
+from . import _hip
+from .modconv_epilogue import _init
+
+CH = 64            # channel counts of the kernels' operands are multiples of this
+PATCH_H, PATCH_W = 4, 16
+
+stats = {'flops': 0, 'launches': 0}     # algorithmic work handed to the hand-written kernels (read by bench.py's FLOP tally)
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Geometry:
+    def __init__(self, h, w, padding, k=3):
+        assert k == 3 and 0 <= padding <= 2, 'hand-written 2-D contraction: 3 x 3 taps, padding 0..2'
+        self.h, self.w, self.padding = h, w, padding
+        self.ho, self.wo = h + 2 * padding - 2, w + 2 * padding - 2
+        self.q = 2 - padding
+        self.hd, self.wd = round_up(h + 2, PATCH_H), round_up(w + 2, PATCH_W)
+        self.hx, self.wx = self.hd + 2, self.wd + 2
+
+
+def pack_weight(weight, dtype, ci_pad, co_pad):
+    """[Co, Ci, 3, 3] -> [3, 3, co_pad, ci_pad] in `dtype` (tap-major, input channel fastest), zero-padded channels."""
+    co, ci = weight.shape[:2]
+    wp = torch.zeros([3, 3, co_pad, ci_pad], dtype=dtype, device=weight.device)
+    wp[:, :, :co, :ci] = weight.to(dtype).permute(2, 3, 0, 1)
+    return wp
+
+
+def pack_weight_dgrad(weight, dtype, ci_pad, co_pad):
+    """[Co, Ci, 3, 3] -> [3, 3, ci_pad, co_pad]: taps mirrored, channel roles exchanged (the weight of the data gradient)."""
+    co, ci = weight.shape[:2]
+    wp = torch.zeros([3, 3, ci_pad, co_pad], dtype=dtype, device=weight.device)
+    wp[:, :, :ci, :co] = weight.to(dtype).flip(2, 3).permute(2, 3, 1, 0)
+    return wp
+
+
+def supported(x, wp):
+    """x [N, Hi, Wi, Ci] contiguous, wp [3, 3, Co, Ci] contiguous, 16-bit, on the GPU, channels multiples of 64."""
+    if x.device.type != 'cuda' or x.dtype not in (torch.float16, torch.bfloat16) or wp.dtype != x.dtype:
+        return False
+    if x.dim() != 4 or wp.dim() != 4 or not x.is_contiguous() or not wp.is_contiguous():
+        return False
+    if wp.shape[0] != 3 or wp.shape[1] != 3 or wp.shape[3] != x.shape[3] or x.shape[3] % CH or wp.shape[2] % CH:
+        return False
+    return x.numel() * 2 < 2 ** 32 and _init()
+
+
+def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None):
+    """out[n, oy, ox, co] = pre[n, co] * sum x[n, oy + offset[0] + dh, ox + offset[1] + dw, ci] * wp[dh, dw, co, ci].
+
+    x [N, Hi, Wi, Ci], wp [3, 3, Co, Ci] -> out [N, ho, wo, Co] (x's dtype); ho <= Hi - offset[0] - 2, wo <= Wi - offset[1] - 2."""
+    n, hi, wi, ci = x.shape
+    co = wp.shape[2]
+    assert ho <= hi - offset[0] - 2 and wo <= wi - offset[1] - 2 and wp.shape == (3, 3, co, ci)
+    if x.device.type == 'cuda' and _init():
+        assert supported(x, wp), 'conv2d_frames: no hand-written kernel for this shape / dtype / layout'
+        out = torch.empty([n, ho, wo, co], dtype=x.dtype, device=x.device)
+        pre = None if pre is None else pre.float().contiguous()
+        with torch.cuda.device(x.device):
+            rc = _hip.lib().lvg_conv2d_frames(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), n, hi, wi, ho, wo, ci, co, 3, 3,
+                                              offset[0], offset[1], ci, co, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+        _hip.check(rc, 'conv2d_frames')
+        stats['flops'] += 2 * n * ho * wo * co * ci * 9
+        stats['launches'] += 1
+        return out
+    v = x[:, offset[0]:offset[0] + ho + 2, offset[1]:offset[1] + wo + 2].permute(0, 3, 1, 2).float()
+    y = F.conv2d(v, wp.permute(2, 3, 0, 1).float())
+    if pre is not None:
+        y = y * pre.float()[:, :, None, None]
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def wgrad_splits(n, hx, wx, hd, wd, ci, co):
+    return int(_hip.lib().lvg_conv2d_frames_wgrad_splits(n, hx, wx, hd, wd, ci, co, 3, 3))
+
+
+def conv2d_wgrad(x, dy):
+    """gw[dh, dw, co, ci] = sum_{n, a, b} dy[n, a, b, co] * x[n, a + dh, b + dw, ci]  (float32 [3, 3, Co, Ci]).
+
+    x [N, Hx, Wx, Ci], dy [N, Hd, Wd, Co] contiguous with Hd % 4 == 0, Wd % 16 == 0, Hx >= Hd + 2, Wx >= Wd + 2."""
+    n, hx, wx, ci = x.shape
+    n2, hd, wd, co = dy.shape
+    assert n == n2 and hd % PATCH_H == 0 and wd % PATCH_W == 0 and hx >= hd + 2 and wx >= wd + 2
+    if x.device.type == 'cuda' and _init():
+        assert x.dtype in (torch.float16, torch.bfloat16) and dy.dtype == x.dtype and x.is_contiguous() and dy.is_contiguous() and ci % CH == 0 and co % CH == 0, \
+            'conv2d_frames_wgrad: no hand-written kernel for this shape / dtype / layout'
+        splits = wgrad_splits(n, hx, wx, hd, wd, ci, co)
+        assert splits > 0, 'conv2d_frames_wgrad: no hand-written kernel for this shape'
+        part = torch.empty([splits, 3, 3, co, ci], dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _hip.lib().lvg_conv2d_frames_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), n, hx, wx, hd, wd, ci, co, 3, 3,
+                                                    ci, co, splits, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+        _hip.check(rc, 'conv2d_frames_wgrad')
+        stats['flops'] += 2 * n * hd * wd * co * ci * 9
+        stats['launches'] += 1
+        return part.sum(0) if splits > 1 else part[0]                 # fixed summation order: reproducible
+    xv = x[:, :hd + 2, :wd + 2].permute(0, 3, 1, 2).float()
+    w0 = torch.zeros(co, ci, 3, 3, dtype=torch.float32, device=x.device, requires_grad=True)
+    with torch.enable_grad():
+        y = F.conv2d(xv, w0)
+    gw = torch.autograd.grad(y, w0, dy.permute(0, 3, 1, 2).float())[0]
+    return gw.permute(2, 3, 0, 1).contiguous()

@@ -14,10 +14,15 @@ modulation / demodulation (summed here; no atomics, run-to-run reproducible).
 
 float16 / bfloat16 on the GPU only; other tensors take the plain-PyTorch definition `_ref`."""
 
+import os
+
 import torch
 import torch.nn.functional as F
 
 from . import _hip
+from . import conv2d_frames
+
+HAND_CONV = os.environ.get('LVG_SRES_HAND_CONV', '1') != '0'     # 3 x 3 layers on csrc/conv2d_igemm.hip / conv2d_wgrad.hip (0: the library convolution)
 
 PAD = 8   # NHWC channel counts are padded to a multiple of this (16-byte vectors of 16-bit elements)
 
@@ -52,6 +57,47 @@ def _nchw_to_nhwc(src_a, src_b, scale, c_dst, oth=None):
     return dst, partial
 
 
+def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None):
+    """cat(src_a, src_b) * scale -> the interior of the (zero-filled) frames dst [N, Hd, Wd, C] at `offset`; -> partial or None
+    (partial[n, tile, c] = sum over the 64 pixels of tile of src[n, c, p] * oth[n, p, c], oth [N, H, W, c_oth] dense frames)."""
+    n, c_a, h, w = src_a.shape
+    c_b = 0 if src_b is None else src_b.shape[1]
+    _, hd, wd, c_dst = dst.shape
+    assert dst.is_contiguous() and hd >= h + offset[0] and wd >= w + offset[1] and c_dst >= c_a + c_b
+    if src_a.device.type != 'cuda':
+        src = src_a if src_b is None else torch.cat((src_a, src_b), dim=1)
+        val = src.float() if scale is None else src.float() * scale[:, :, None, None]
+        dst[:, offset[0]:offset[0] + h, offset[1]:offset[1] + w, :c_a + c_b] = val.permute(0, 2, 3, 1).to(dst.dtype)
+        if oth is None:
+            return None
+        return (src.float().permute(0, 2, 3, 1) * oth[..., :c_a + c_b].float()).sum(dim=(1, 2))[:, None, :]
+    partial = None
+    if oth is not None:
+        assert oth.is_contiguous() and oth.shape[:3] == (n, h, w)
+        partial = torch.empty([n, (h * w + 63) // 64, c_a + c_b], dtype=torch.float32, device=src_a.device)
+    with torch.cuda.device(src_a.device):
+        rc = _hip.lib().lvg_modconv2d_nchw_to_nhwc_padded(
+            src_a.data_ptr(), None if src_b is None else src_b.data_ptr(), None if scale is None else scale.data_ptr(),
+            None if oth is None else oth.data_ptr(), dst.data_ptr(), None if partial is None else partial.data_ptr(),
+            n, h, w, c_a, c_b, c_dst, 0 if oth is None else oth.shape[3], hd, wd, offset[0], offset[1],
+            _hip.dtype_code(src_a.dtype), _hip.stream(src_a.device))
+    _hip.check(rc, 'modconv2d_nchw_to_nhwc_padded')
+    return partial
+
+
+def _frames_to_nchw(src, scale, c_dst, oth_a=None, oth_b=None):
+    """src [N, H, W, c_src] dense frames -> (dst [N, c_dst, H, W] contiguous = src[..., :c_dst] * scale, partial or None)."""
+    if src.device.type != 'cuda':
+        v = src[..., :c_dst].float().permute(0, 3, 1, 2)
+        dst = (v if scale is None else v * scale[:, :, None, None]).contiguous().to(src.dtype)
+        partial = None
+        if oth_a is not None:
+            oth = oth_a if oth_b is None else torch.cat((oth_a, oth_b), dim=1)
+            partial = (src[..., :oth.shape[1]].float().permute(0, 3, 1, 2) * oth.float()).sum(dim=(2, 3))[:, None, :]
+        return dst, partial
+    return _nhwc_to_nchw(src.permute(0, 3, 1, 2), scale, c_dst, oth_a=oth_a, oth_b=oth_b)
+
+
 def _nhwc_to_nchw(src, scale, c_dst, oth_a=None, oth_b=None):
     """src [N, c_src, H, W] channels-last -> (dst [N, c_dst, H, W] contiguous, partial or None)."""
     n, c_src, h, w = src.shape
@@ -61,6 +107,8 @@ def _nhwc_to_nchw(src, scale, c_dst, oth_a=None, oth_b=None):
     c_b = 0 if oth_b is None else oth_b.shape[1]
     if oth_a is not None:
         partial = torch.empty([n, (h * w + 63) // 64, c_a + c_b], dtype=torch.float32, device=src.device)
+    assert ((c_src == 1 or src.stride(1) == 1) and (w == 1 or src.stride(3) == c_src) and (h == 1 or src.stride(2) == w * c_src)
+            and (n == 1 or src.stride(0) == h * w * c_src)), 'dense channels-last frames expected'
     with torch.cuda.device(src.device):
         rc = _hip.lib().lvg_modconv2d_nhwc_to_nchw(
             src.data_ptr(), None if scale is None else scale.data_ptr(), None if oth_a is None else oth_a.data_ptr(),
@@ -93,6 +141,7 @@ class _Prologue(torch.autograd.Function):
         x, cond, mod = ctx.saved_tensors
         c_x = x.shape[1]
         d_out = _cl(d_out)
+        assert not ctx.needs_input_grad[1], 'modulated_conv2d: no gradient for the conditioning frames on the fused path'
         need_x, need_mod = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
         d_x, partial = _nhwc_to_nchw(d_out, mod[:, :c_x].contiguous(), c_x, oth_a=x if need_mod else None, oth_b=cond if need_mod else None)
         d_mod = partial.sum(dim=1) if need_mod else None
@@ -121,6 +170,61 @@ class _Epilogue(torch.autograd.Function):
         return d_y, d_demod, None
 
 
+class _ModConv2dHand(torch.autograd.Function):
+    """The whole modulated 3 x 3 convolution on the hand-written kernels:
+        prologue (cat, modulate, NCHW -> zero-padded channels-last frames)  ->  lvg_conv2d_frames  ->  epilogue (demodulate, -> NCHW)
+    and in the backward pass the epilogue's opposite kernel (gradient frames, d demod), the data gradient (the same convolution
+    kernel on the gradient frames), the weight gradient (lvg_conv2d_frames_wgrad) and the prologue's opposite kernel (d x, d mod).
+    One autograd node: every intermediate frame has the geometry the kernels want (conv2d_frames.Geometry)."""
+
+    @staticmethod
+    def forward(ctx, first, second, weight, mod, demod, padding):
+        first, mod = first.contiguous(), mod.float().contiguous()
+        second = None if second is None else second.contiguous()
+        demod = None if demod is None else demod.float().contiguous()
+        n, c_first, h, w = first.shape
+        co, ci = weight.shape[:2]
+        assert ci == c_first + (0 if second is None else second.shape[1]) and tuple(weight.shape[2:]) == (3, 3)
+        geo = conv2d_frames.Geometry(h, w, padding)
+        ci_pad, co_pad = conv2d_frames.round_up(ci, conv2d_frames.CH), conv2d_frames.round_up(co, conv2d_frames.CH)
+        xp = torch.zeros([n, geo.hx, geo.wx, ci_pad], dtype=first.dtype, device=first.device)
+        _nchw_to_nhwc_padded(first, second, mod, xp, (2, 2))
+        y = conv2d_frames.conv2d_valid(xp, conv2d_frames.pack_weight(weight, first.dtype, ci_pad, co_pad), geo.ho, geo.wo, offset=(geo.q, geo.q))
+        out, _ = _frames_to_nchw(y, demod, co)
+        ctx.save_for_backward(first, second, mod, demod, xp, y, weight)
+        ctx.geo = geo
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        first, second, mod, demod, xp, y, weight = ctx.saved_tensors
+        geo = ctx.geo
+        assert not ctx.needs_input_grad[1], 'modulated_conv2d: no gradient for the conditioning frames on the fused path'
+        n, c_first = first.shape[:2]
+        co, ci = weight.shape[:2]
+        ci_pad, co_pad = xp.shape[3], y.shape[3]
+        need_first, need_weight, need_mod, need_demod = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3], demod is not None and ctx.needs_input_grad[4]
+        # gradient frames: d_out * demod at (q, q) of the zero-filled patch-aligned frame; d demod = sum d_out * y from the same pass
+        dyp = torch.zeros([n, geo.hd, geo.wd, co_pad], dtype=first.dtype, device=first.device)
+        partial = _nchw_to_nhwc_padded(d_out.contiguous(), None, demod, dyp, (geo.q, geo.q), oth=y if need_demod else None)
+        d_demod = partial.sum(dim=1) if need_demod else None
+        d_weight = None
+        if need_weight:
+            gw = conv2d_frames.conv2d_wgrad(xp, dyp)                                   # [3, 3, co_pad, ci_pad] float32
+            d_weight = gw[:, :, :co, :ci].permute(2, 3, 0, 1).to(weight.dtype)
+        d_first = d_mod = None
+        if need_first or need_mod:
+            dxp = conv2d_frames.conv2d_valid(dyp, conv2d_frames.pack_weight_dgrad(weight, first.dtype, ci_pad, co_pad), geo.h, geo.w)
+            d_first, partial = _frames_to_nchw(dxp, mod[:, :c_first].contiguous(), c_first, oth_a=first if need_mod else None, oth_b=second if need_mod else None)
+            d_mod = partial.sum(dim=1) if need_mod else None
+        return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None
+
+
+def hand_conv_supported(first, weight):
+    return (HAND_CONV and first.device.type == 'cuda' and first.dtype in (torch.float16, torch.bfloat16) and tuple(weight.shape[2:]) == (3, 3))
+
+
 def supported(x, cond):
     t = cond if x is None else x
     return t.device.type == 'cuda' and t.dtype in (torch.float16, torch.bfloat16)
@@ -137,6 +241,8 @@ def modulated_conv2d(x, cond, weight, mod, demod, padding=0):
         second = second.to(dtype)
     c_in, c_out = weight.shape[1], weight.shape[0]
     assert c_in == first.shape[1] + (0 if second is None else second.shape[1])
+    if hand_conv_supported(first, weight) and 0 <= padding <= 2:
+        return _ModConv2dHand.apply(first, second, weight, mod, demod, padding)
     ci_pad, co_pad = _pad_to(c_in), _pad_to(c_out)
     xin = _Prologue.apply(first, second, mod.float(), ci_pad)
     w = weight.to(dtype)

@@ -246,6 +246,45 @@ def conv3d_frames_wgrad(x, dy, kt, kh, kw, shift=1):
     return gw
 
 
+def conv2d(x, w, padding=0):
+    """Plain cross-correlation with symmetric zero padding (orc_conv2d): x [N, Ci, H, W], w [Co, Ci, kh, kw] -> [N, Co, H', W']."""
+    x, w = _f64(x), _f64(w)
+    n, ci, h, wd = x.shape
+    co, ci2, kh, kw = w.shape
+    assert ci == ci2
+    y = np.empty((n, co, h + 2 * padding - kh + 1, wd + 2 * padding - kw + 1), dtype=np.float64)
+    rc = lib().orc_conv2d(_dp(x), _dp(w), _dp(y), ctypes.c_int64(n), ctypes.c_int(ci), ctypes.c_int(co), ctypes.c_int(h), ctypes.c_int(wd),
+                          ctypes.c_int(kh), ctypes.c_int(kw), ctypes.c_int(padding))
+    assert rc == 0, rc
+    return y
+
+
+def conv2d_wgrad(x, dy, kh, kw, padding=0):
+    """Weight gradient of `conv2d` (orc_conv2d_wgrad): x [N, Ci, H, W], dy [N, Co, H', W'] -> [Co, Ci, kh, kw]."""
+    x, dy = _f64(x), _f64(dy)
+    n, ci, h, wd = x.shape
+    co = dy.shape[1]
+    assert dy.shape[2:] == (h + 2 * padding - kh + 1, wd + 2 * padding - kw + 1)
+    gw = np.empty((co, ci, kh, kw), dtype=np.float64)
+    rc = lib().orc_conv2d_wgrad(_dp(x), _dp(dy), _dp(gw), ctypes.c_int64(n), ctypes.c_int(ci), ctypes.c_int(co), ctypes.c_int(h), ctypes.c_int(wd),
+                                ctypes.c_int(kh), ctypes.c_int(kw), ctypes.c_int(padding))
+    assert rc == 0, rc
+    return gw
+
+
+def conv2d_dgrad(dy, w, h, wd, padding=0):
+    """Data gradient of `conv2d` (orc_conv2d_dgrad): dy [N, Co, H', W'], w [Co, Ci, kh, kw] -> [N, Ci, h, wd]."""
+    dy, w = _f64(dy), _f64(w)
+    n, co = dy.shape[:2]
+    co2, ci, kh, kw = w.shape
+    assert co == co2 and dy.shape[2:] == (h + 2 * padding - kh + 1, wd + 2 * padding - kw + 1)
+    dx = np.empty((n, ci, h, wd), dtype=np.float64)
+    rc = lib().orc_conv2d_dgrad(_dp(dy), _dp(w), _dp(dx), ctypes.c_int64(n), ctypes.c_int(ci), ctypes.c_int(co), ctypes.c_int(h), ctypes.c_int(wd),
+                                ctypes.c_int(kh), ctypes.c_int(kw), ctypes.c_int(padding))
+    assert rc == 0, rc
+    return dx
+
+
 def modconv2d_prologue(x, cond, mod, c_pad):
     """cat(x, cond) * mod with zero channels up to c_pad. x may be None. NCHW in, NCHW out."""
     cond = _f64(cond)

@@ -1,0 +1,238 @@
+"""Hand-written 2-D implicit-GEMM convolution of the super-resolution networks (csrc/conv2d_igemm.hip, csrc/conv2d_wgrad.hip,
+torch_utils/ops/conv2d_frames.py) and the fused modulated convolution around it (modconv2d_layout._ModConv2dHand).
+
+CPU: the oracle's conv2d restatement (+ the modulation algebra of model/generator_sres.py:28-67) against vectors produced by
+the REFERENCE's `modulated_conv2d` incl. its gradients (tests/golden/make_golden_modconv2d.py); the frame geometry and the
+plumbing of the fused autograd node (plain-PyTorch composition of the same steps) against the same vectors.
+GPU: HIP vs oracle on seeded ragged cases (f16 / bf16; tiles overhanging the frame, several channel chunks, padded channel
+counts, paddings 0 / 1 / 2), the fused node vs the reference golden, and at the BASELINE.json configs[3] sizes the
+size-independent properties "a one-hot kernel is a shift" (bit-exact) and "the weight gradient is the adjoint of the forward"."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, record_measured
+from helpers.modconv2d_inputs import CASES, inputs
+from torch_utils.ops import conv2d_frames as c2
+from torch_utils.ops import modconv2d_layout as ml
+
+
+def _modulation(weight, style, gain):
+    """numpy restatement of generator_sres.py:43-62 -> (normalised weight, modulation [N,Ci], demodulation [N,Co])."""
+    w = weight / np.sqrt((weight ** 2).mean(axis=(1, 2, 3), keepdims=True))
+    s = style / np.sqrt((style ** 2).mean())
+    demod = 1.0 / np.sqrt(np.einsum('oiyx,ni->no', w ** 2, s ** 2) + 1e-8)
+    return w, s * gain, demod
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_oracle_matches_reference_modulated_conv2d(oracle, name):
+    """conv2d(x * mod, w') * demod with the oracle's conv2d == the reference's per-sample-weight grouped convolution; the
+    oracle's data / weight gradient restatements == what autograd derives through the reference (for fixed mod / demod)."""
+    g = load_golden('modconv2d')
+    x, weight, style, gain, dy = [t.double().numpy() for t in inputs(name)]
+    pad = CASES[name][6]
+    w, mod, demod = _modulation(weight, style, float(gain))
+    y = oracle.conv2d(x * mod[:, :, None, None], w, padding=pad) * demod[:, :, None, None]
+    np.testing.assert_allclose(y, g[name + '_y'], rtol=2e-4, atol=2e-5)
+    # d/dx with mod, demod as the reference computes them (they do not depend on x)
+    gx = oracle.conv2d_dgrad(dy * demod[:, :, None, None], w, x.shape[2], x.shape[3], padding=pad) * mod[:, :, None, None]
+    np.testing.assert_allclose(gx, g[name + '_gx'], rtol=2e-4, atol=2e-5)
+
+
+def _torch_modulation(weight, style, gain):
+    w = weight * weight.square().mean(dim=(1, 2, 3), keepdim=True).rsqrt()
+    s = style * style.square().mean().rsqrt()
+    demod = (torch.matmul(s.square(), w.square().sum(dim=(2, 3)).t()) + 1e-8).rsqrt()
+    return w, s * gain, demod
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_fused_node_plumbing_matches_reference_cpu(name):
+    """The fused autograd node on CPU tensors (every step through its plain-PyTorch composition: padded frames, offsets,
+    weight packing, gradient frames) reproduces the reference's output and all three gradients."""
+    g = load_golden('modconv2d')
+    x, weight, style, gain, dy = inputs(name)
+    n, ci, co, h, w_, k, pad = CASES[name]
+    c_first = ci // 2
+    x, weight, style = x.requires_grad_(True), weight.requires_grad_(True), style.requires_grad_(True)
+    first, second = x[:, :c_first], x[:, c_first:].detach()
+    wn, mod, demod = _torch_modulation(weight, style, gain)
+    y = ml._ModConv2dHand.apply(first, second, wn, mod, demod, pad)
+    np.testing.assert_allclose(y.detach().numpy(), g[name + '_y'], rtol=2e-4, atol=2e-5)
+    gx, gw, gs = torch.autograd.grad(y, [x, weight, style], dy)
+    np.testing.assert_allclose(gx[:, :c_first].numpy(), g[name + '_gx'][:, :c_first], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gw.numpy(), g[name + '_gw'], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(gs.numpy(), g[name + '_gs'], rtol=5e-4, atol=5e-5)
+
+
+def test_plain_definitions_match_oracle_cpu(oracle):
+    gen = torch.Generator().manual_seed(3)
+    geo = c2.Geometry(7, 21, 2)
+    assert (geo.ho, geo.wo, geo.q, geo.hd, geo.wd, geo.hx, geo.wx) == (9, 23, 0, 12, 32, 14, 34)
+    x = torch.randn(2, 7, 21, 5, generator=gen)
+    weight = torch.randn(6, 5, 3, 3, generator=gen)
+    xp = torch.zeros(2, geo.hx, geo.wx, 64)
+    xp[:, 2:9, 2:23, :5] = x
+    out = c2.conv2d_valid(xp, c2.pack_weight(weight, torch.float32, 64, 64), geo.ho, geo.wo, offset=(geo.q, geo.q))
+    ref = oracle.conv2d(x.permute(0, 3, 1, 2).numpy(), weight.numpy(), padding=2)
+    np.testing.assert_allclose(out[..., :6].permute(0, 3, 1, 2).numpy(), ref, rtol=1e-4, atol=1e-5)
+    assert float(out[..., 6:].abs().max()) == 0.0
+    dy = torch.randn(2, geo.ho, geo.wo, 6, generator=gen)
+    dyp = torch.zeros(2, geo.hd, geo.wd, 64)
+    dyp[:, :geo.ho, :geo.wo, :6] = dy
+    gw = c2.conv2d_wgrad(xp, dyp)
+    refg = oracle.conv2d_wgrad(x.permute(0, 3, 1, 2).numpy(), dy.permute(0, 3, 1, 2).numpy(), 3, 3, padding=2)
+    np.testing.assert_allclose(gw[:, :, :6, :5].permute(2, 3, 0, 1).numpy(), refg, rtol=1e-4, atol=1e-4)
+    dx = c2.conv2d_valid(dyp, c2.pack_weight_dgrad(weight, torch.float32, 64, 64), 7, 21)
+    refd = oracle.conv2d_dgrad(dy.permute(0, 3, 1, 2).numpy(), weight.numpy(), 7, 21, padding=2)
+    np.testing.assert_allclose(dx[..., :5].permute(0, 3, 1, 2).numpy(), refd, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: kernels vs the oracle
+
+GPU_CASES = [
+    # n, ci, co, hi, wi, ho, wo, off            (ho x wo ragged against the 8 x 16 tile on purpose)
+    (2, 64, 64, 12, 21, 10, 19, 0),             # one chunk, tiles overhanging right and bottom
+    (1, 128, 128, 19, 40, 15, 35, 1),           # two chunks (band double buffering), offset 1, BN = 128
+    (3, 192, 64, 10, 18, 8, 16, 0),             # exactly one tile per frame, three chunks
+    (2, 64, 192, 34, 50, 32, 48, 0),            # four tile rows, Co = 3 x 64
+    (1, 256, 128, 9, 70, 5, 66, 2),             # one ragged tile row, five tiles across, four chunks
+]
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _nchw(t):
+    return _np(t).transpose(0, 3, 1, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', GPU_CASES)
+def test_hip_forward_matches_oracle_gpu(oracle, case, dtype):
+    n, ci, co, hi, wi, ho, wo, off = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, hi, wi, ci, generator=g).to(dtype).cuda()
+    wp = (torch.randn(3, 3, co, ci, generator=g) / math.sqrt(9 * ci)).to(dtype).cuda()
+    pre = (0.5 + torch.rand(n, co, generator=g)).cuda()
+    assert c2.supported(x, wp)
+    out = c2.conv2d_valid(x, wp, ho, wo, offset=(off, off), pre=pre)
+    ref = oracle.conv2d(_nchw(x)[:, :, off:off + ho + 2, off:off + wo + 2], _np(wp).transpose(2, 3, 0, 1)) * _np(pre)[:, :, None, None]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # one output rounding; accumulation is float32
+    np.testing.assert_allclose(_nchw(out), ref, rtol=1.5 * eps, atol=eps * 0.05)
+
+
+WGRAD_CASES = [
+    # n, ci, co, hd, wd      (input frames hd + 2 x wd + 2)
+    (2, 64, 64, 8, 16),                          # 2 patches per frame
+    (1, 128, 64, 12, 48),                        # 9 patches, two ci tiles
+    (3, 64, 192, 4, 32),                         # patches straddling frames in the K range, three co tiles
+    (2, 128, 128, 20, 64),                       # 40 patches: several K ranges
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_hip_wgrad_matches_oracle_gpu(oracle, case, dtype):
+    n, ci, co, hd, wd = case
+    g = torch.Generator().manual_seed(5)
+    # operands with few mantissa bits: every product is exact in float32, the sum is compared tightly
+    x = (torch.randint(-4, 5, (n, hd + 2, wd + 2, ci), generator=g).float() / 4).to(dtype).cuda()
+    dy = (torch.randint(-4, 5, (n, hd, wd, co), generator=g).float() / 4).to(dtype).cuda()
+    gw = c2.conv2d_wgrad(x, dy)
+    gw2 = c2.conv2d_wgrad(x, dy)
+    assert torch.equal(gw, gw2)                                          # fixed-order range sums: reproducible
+    ref = oracle.conv2d_wgrad(_nchw(x), _nchw(dy), 3, 3, padding=0)      # [co, ci, 3, 3]
+    np.testing.assert_allclose(_np(gw).transpose(2, 3, 0, 1), ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(CASES))
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_fused_node_matches_reference_gpu(name, dtype):
+    """The modulated convolution as the generator runs it (prologue -> lvg_conv2d_frames -> epilogue, and the four backward
+    launches) vs the reference's modulated_conv2d and its gradients: 16-bit operands, float32 accumulation."""
+    g = load_golden('modconv2d')
+    x, weight, style, gain, dy = inputs(name)
+    n, ci, co, h, w_, k, pad = CASES[name]
+    c_first = ci // 2
+    first = x[:, :c_first].to(dtype).cuda().requires_grad_(True)
+    second = x[:, c_first:].to(dtype).cuda()
+    weight, style = weight.cuda().requires_grad_(True), style.cuda().requires_grad_(True)
+    wn, mod, demod = _torch_modulation(weight, style, gain.cuda())
+    y = ml.modulated_conv2d(first, second, wn, mod, demod, padding=pad)
+    assert c2.stats['launches'] > 0
+    tol = 4e-2 if dtype == torch.bfloat16 else 6e-3                      # values up to ~3; inputs, weights and outputs rounded to 16 bits
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), g[name + '_y'], rtol=0, atol=tol)
+    gx, gw, gs = torch.autograd.grad(y, [first, weight, style], dy.to(dtype).cuda())
+    scale = lambda a: float(np.abs(a).max())
+    np.testing.assert_allclose(gx.float().cpu().numpy(), g[name + '_gx'][:, :c_first], rtol=0, atol=tol * scale(g[name + '_gx']))
+    np.testing.assert_allclose(gw.cpu().numpy(), g[name + '_gw'], rtol=0, atol=tol * scale(g[name + '_gw']))
+    np.testing.assert_allclose(gs.cpu().numpy(), g[name + '_gs'], rtol=0, atol=tol * scale(g[name + '_gs']))
+
+
+@pytest.mark.gpu
+def test_fused_node_vs_library_route_full_layer_gpu(monkeypatch):
+    """One generator layer shape of BASELINE.json configs[3] (L8: 539 -> 512 channels, 148 x 92 planes, padding 2; 2 frames):
+    the hand-written route against the library-convolution route of the same op (same 16-bit operands), output and gradients."""
+    torch.manual_seed(0)
+    n, ci, co, h, w = 2, 539, 512, 92, 148
+    first = torch.randn(n, 512, h, w, device='cuda').half().requires_grad_(True)
+    second = torch.randn(n, 27, h, w, device='cuda').half()
+    weight = (torch.randn(co, ci, 3, 3, device='cuda') / math.sqrt(9 * ci)).requires_grad_(True)
+    mod = (1 + 0.3 * torch.randn(n, ci, device='cuda')).requires_grad_(True)
+    demod = (0.5 + torch.rand(n, co, device='cuda')).requires_grad_(True)
+    dy = torch.randn(n, co, h + 2, w + 2, device='cuda').half()
+
+    def run(flag):
+        monkeypatch.setattr(ml, 'HAND_CONV', flag)
+        y = ml.modulated_conv2d(first, second, weight, mod, demod, padding=2)
+        return [y.detach().float()] + [t.float() for t in torch.autograd.grad(y, [first, weight, mod, demod], dy)]
+    hand, lib = run(True), run(False)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    errs = {k: rel(a, b) for k, a, b in zip(('y', 'd_x', 'd_weight', 'd_mod', 'd_demod'), hand, lib)}
+    record_measured('sres_L8_hand_vs_library_rel_l2_f16', **errs)
+    assert max(errs.values()) < 2e-3, errs                               # both routes round the same operands to f16 and accumulate in float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(16, 576, 512, 94, 150), (16, 192, 128, 166, 278)])
+def test_one_hot_kernel_is_a_shift_full_size_gpu(shape):
+    """Size-independent property at the configs[3] sizes (L8 and L13 as padded: 16 frames): with w[dh, dw] = a one-hot matrix
+    the convolution copies channel ci_sel of the input, shifted by (dh, dw), into channel co_sel -- bit-exact, every tile."""
+    n, ci, co, ho, wo = shape
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, ho + 2, wo + 2, ci, generator=g).half().cuda()
+    for (dh, dw, co_sel, ci_sel) in [(0, 0, 0, ci - 1), (1, 2, co - 1, 0), (2, 1, 65, 64)]:
+        wp = torch.zeros(3, 3, co, ci, dtype=torch.float16, device='cuda')
+        wp[dh, dw, co_sel, ci_sel] = 1.0
+        out = c2.conv2d_valid(x, wp, ho, wo)
+        assert torch.equal(out[..., co_sel], x[:, dh:dh + ho, dw:dw + wo, ci_sel])
+        out[..., co_sel] = 0
+        assert float(out.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(16, 576, 512, 96, 160), (16, 192, 128, 168, 288)])
+def test_weight_gradient_is_the_adjoint_of_the_forward_full_size_gpu(shape):
+    """<dy, conv(x, w)> = <wgrad(x, dy), w> for a random w at the configs[3] sizes (gradient frames of whole patches): checks the
+    split-K ranges and the patch walk of the weight-gradient kernel against the forward kernel (itself checked bit-exactly above)."""
+    n, ci, co, hd, wd = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, hd + 2, wd + 2, ci, generator=g).half().cuda()
+    dy = torch.randn(n, hd, wd, co, generator=g).half().cuda()
+    wp = (torch.randn(3, 3, co, ci, generator=g) / math.sqrt(9 * ci)).half().cuda()
+    y = c2.conv2d_valid(x, wp, hd, wd)
+    lhs = float((y.double() * dy.double()).sum())
+    gw = c2.conv2d_wgrad(x, dy)
+    rhs = float((gw.double() * wp.double()).sum())
+    record_measured(f'sres_wgrad_adjoint_{ci}x{co}', lhs=lhs, rhs=rhs, rel=abs(lhs - rhs) / abs(lhs))
+    assert abs(lhs - rhs) <= 2e-3 * abs(lhs), (lhs, rhs)                 # y is rounded to f16 once (2^-11 per term, random signs)
