@@ -132,7 +132,14 @@ class OpTimer:
         # conv3d_frames_wgrad(x, dy, kt, kh, kw, shift): the hand-written weight gradient (its own kernel, csrc/conv3d_wgrad.hip)
         wrap(conv3d_frames, 'conv3d_frames_wgrad', lambda a: 'conv3d_wgrad',
              lambda args, out, kw: 2 * args[0].shape[0] * args[0].shape[2] * args[0].shape[3] * args[0].shape[1] * args[1].shape[1] * args[2] * args[3] * args[4])
-        self.flop_ops = {'conv3d_igemm', 'conv3d_igemm_1x1', 'conv3d_wgrad'}
+        # conv2d_frames.conv2d_valid(x [N,Hi,Wi,Ci], wp [3,3,Co,Ci], ho, wo, ...): the 2-D implicit-GEMM convolution of the sres generator
+        # (forward and data-gradient launches); conv2d_wgrad(x, dy): its weight gradient. FLOPs as launched (channels padded to 64).
+        from torch_utils.ops import conv2d_frames
+        wrap(conv2d_frames, 'conv2d_valid', lambda a: 'conv2d_igemm',
+             lambda args, out, kw: 2 * args[0].shape[0] * args[2] * args[3] * args[1].shape[2] * args[1].shape[3] * 9)
+        wrap(conv2d_frames, 'conv2d_wgrad', lambda a: 'conv2d_wgrad',
+             lambda args, out, kw: 2 * args[1].shape[0] * args[1].shape[1] * args[1].shape[2] * args[1].shape[3] * args[0].shape[3] * 9)
+        self.flop_ops = {'conv3d_igemm', 'conv3d_igemm_1x1', 'conv3d_wgrad', 'conv2d_igemm', 'conv2d_wgrad'}
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step
@@ -535,10 +542,11 @@ def _mfma_leg(step, sec_per_step):
             'scope': 'all dense contractions of the timed lres step / whole step time (end to end)'}
 
 
-def _sres_leg(dev, timer, segments=2, steps=4, warmup=2):
+def _sres_leg(dev, timer, segments=2, steps=6, warmup=2):
     """BASELINE.json configs[3]: generator_sres + discriminator_sres on 8-frame 144x256 segments (+-4 context frames of
     36x64 input), one generator update = G forward -> D forward -> softplus(-logits).mean().backward() -> Adam, f16
-    activations in the high-resolution layers as the reference (num_fp16_res = 4). Eager launches. The
+    activations in the high-resolution layers as the reference (num_fp16_res = 4). The compute part is replayed from a hipGraph like
+    the main step (falls back to eager launches if the capture is refused). The
     filtered_lrelu launches of one step are then re-timed per kernel family (OpTimer) for the roofline."""
     from torch.utils.flop_counter import FlopCounterMode
     from lvg.train_sres import SuperResTrainer
@@ -547,41 +555,87 @@ def _sres_leg(dev, timer, segments=2, steps=4, warmup=2):
                          in_augment_strength=0.0, lr_cond_prob=1.0, overlap_grad_sync=False, with_ema=False)
     lr = (torch.rand(segments, 3, tr.context_seq_length, 36, 64, device=dev) * 2 - 1)
 
+    def compute():
+        # the compute part of SuperResTrainer.update_G (zero the flat gradient, G forward, D forward, backward)
+        tr.G.requires_grad_(True)
+        tr.G_sync.zero()
+        logits = tr.run_D(tr.crop_to_seq_length(lr), tr.G(lr))
+        F.softplus(-logits).mean().backward()
+        tr.G.requires_grad_(False)
+
+    def update():
+        tr.G_sync.finish()          # gradient exchange (no-op collective at N = 1), then the fused Adam launch
+        tr.G_opt.step()
+
     def step():
-        tr.update_G(lr)
+        compute()
+        update()
     for _ in range(warmup):
-        step()
+        tr.update_G(lr)             # the trainer's own entry point: same launches as compute() + update()
     torch.cuda.synchronize()
+    graph, mode = None, 'eager'
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            compute()
+        graph.replay()
+        update()
+        torch.cuda.synchronize()
+        mode = 'hipgraph'
+    except Exception as err:  # pylint: disable=broad-except
+        print(f'[bench] sres leg: hipGraph capture refused ({type(err).__name__}: {str(err)[:200]}); timing eager launches', file=sys.stderr)
+        graph = None
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        if graph is not None:
+            graph.replay()
+            update()
+        else:
+            step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    del graph
     frames = segments * tr.seq_length
+    from torch_utils.ops import conv2d_frames
+    conv2d_frames.stats['flops'] = 0
     with FlopCounterMode(display=False) as fc:
         step()
     torch.cuda.synchronize()
-    flops = float(fc.get_total_flops())
+    flops = float(fc.get_total_flops()) + float(conv2d_frames.stats['flops'])     # dispatcher-level ops + the hand-written 2-D convolution
     timer.calls.clear()
     timer.enabled = True
     step()
     timer.enabled = False
-    ops = {k: v for k, v in timer.measure().items() if k.startswith('filtered_lrelu')}
+    measured = timer.measure()
+    convs = {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), tflops=round(v['gbps'] / 1e3, 1), frac=round(v['gbps'] / 1e3 / MFMA_PEAK_TFLOPS, 4))
+             for k, v in measured.items() if k.startswith('conv2d')}
+    ops = {k: v for k, v in measured.items() if k.startswith('filtered_lrelu')}
+    # the launches of the MFMA filtered_lrelu kernel (16-bit tensors, real resampling): the family the committed PMC traffic figure belongs to
+    mf = [v for k, v in ops.items() if '_f32_' not in k and 'u1d1' not in k]
+    mf_launches, mf_bytes = sum(v['launches'] for v in mf), sum(v['bytes'] for v in mf)
     tot_ms = sum(v['total_ms'] for v in ops.values())
     tot_b = sum(v['bytes'] for v in ops.values())
     n = sum(v['launches'] for v in ops.values())
     worst = min(ops.values(), key=lambda v: v['gbps']) if ops else None
     gb = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     out = {'metric': 'frames/sec sres G+D 8-frame 144x256 forward+backward (generator update)', 'value': round(frames / dt, 2), 'unit': 'frames/s',
-           'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warmup, 'dtype': 'f16', 'launch_mode': 'eager',
+           'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warmup, 'dtype': 'f16', 'launch_mode': mode,
            'config': {'workload': f'generator_sres + discriminator_sres, {segments} segments x 8 frames 144x256 from 36x64 (+-4 context), Adam step', 'global_batch': segments},
            'roofline': {'bound': 'hbm', 'kernel': 'filtered_lrelu', 'achieved': round(gb, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gb / HBM_PEAK_GBPS, 4),
                         'launches': n, 'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2), 'algorithmic_bytes_per_launch': int(tot_b / max(n, 1)),
-                        'traffic': _pmc_traffic('filtered_lrelu_mfma'),
+                        'traffic': _pmc_traffic('filtered_lrelu_mfma'), 'traffic_scope': 'per launch of the MFMA kernel family only (16-bit layers)',
+                        'algorithmic_bytes_per_launch_mfma_family': int(mf_bytes / max(mf_launches, 1)), 'launches_mfma_family': mf_launches,
                         'measured_on': 'all fused filtered_lrelu launches of one step (forward with mask write, backward with mask read), captured once each into a hipGraph per family, replayed 3x between HIP events',
                         'families': {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1)) for k, v in ops.items()},
                         'slowest_family_gbps': round(worst['gbps'], 1) if worst else None},
            'step_ms_in_filtered_lrelu': round(tot_ms, 3),
+           'conv2d': convs,
            'mfma': {'flops_per_step': int(flops), 'achieved_tflops': round(flops / dt / 1e12, 1), 'peak_tflops': MFMA_PEAK_TFLOPS,
                     'frac': round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4), 'scope': 'all dense contractions / whole step time (end to end)'}}
     return out

@@ -30,6 +30,7 @@ struct Plan2D
 {
     int bm, bn, bandRows, nABuf, ldsBytes, tilesX, tilesY;
     int64_t mTiles;
+    int coMain;      // output channels covered by the bn-channel tiles; the remaining 64 (Co = 128 k + 64) take a second launch of 64-channel tiles
 };
 
 int env_int2(const char* name, int dflt)
@@ -44,8 +45,11 @@ int make_plan2d(int64_t n, int ho, int wo, int ci, int co, Plan2D& pl)
 {
     const int fbm = env_int2("LVG_CONV2D_BM", 0), fbn = env_int2("LVG_CONV2D_BN", 0);
     pl.bm = fbm == 256 ? 256 : 128;
-    pl.bn = (co % 128 == 0) ? 128 : 64;
+    // Co = 128 k + 64 (k >= 1): k tiles of 128 channels + ONE of 64 (two launches) instead of 2 k + 1 tiles of 64 -- the 64-channel
+    // tile does half the MFMAs per fragment read and per staged band (measured: 576 output channels as 9 x 64 ran at 0.78 of 4 x 128 + 64)
+    pl.bn = co >= 128 ? 128 : 64;
     if (fbn == 64) pl.bn = 64;
+    pl.coMain = co / pl.bn * pl.bn;
     const int th = pl.bm / kTileW;
     pl.bandRows = (int)lvg_ceil_div((th + 2) * kPatchPitch, 8) * 8;
     pl.nABuf = ci / kBK > 1 ? 2 : 1;
@@ -84,15 +88,24 @@ int launch2d(const ConvArgs2D& a, const Plan2D& pl, hipStream_t stream)
         }
     }
     const int64_t blocks = pl.mTiles * a.nTiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM / 64 * 128), pl.ldsBytes, stream, a);
+    const int lds = std::max(kZeroBytes + pl.nABuf * pl.bandRows * kRowBytes + 2 * BN * kRowBytes, (BM / 64 * 2) * 64 * (BN + 16));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM / 64 * 128), lds, stream, a);
     return lvg_check_launch("conv2d_frames");
 }
 
 template <class T>
-int launch2d_tile(const ConvArgs2D& a, const Plan2D& pl, hipStream_t s)
+int launch2d_tile(const ConvArgs2D& a0, const Plan2D& pl, hipStream_t s)
 {
-    if (pl.bm == 256) return pl.bn == 128 ? launch2d<T, 256, 128>(a, pl, s) : launch2d<T, 256, 64>(a, pl, s);
-    return pl.bn == 128 ? launch2d<T, 128, 128>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
+    ConvArgs2D a = a0;
+    a.coBase = 0;
+    a.nTiles = pl.coMain / pl.bn;
+    int rc = LVG_OK;
+    if (pl.bm == 256) rc = pl.bn == 128 ? launch2d<T, 256, 128>(a, pl, s) : launch2d<T, 256, 64>(a, pl, s);
+    else              rc = pl.bn == 128 ? launch2d<T, 128, 128>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
+    if (rc != LVG_OK || pl.coMain == a.Co) return rc;
+    a.coBase = pl.coMain;                                                // the last 64 channels
+    a.nTiles = 1;
+    return pl.bm == 256 ? launch2d<T, 256, 64>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
 }
 
 } // namespace
@@ -102,7 +115,7 @@ extern "C" int64_t lvg_conv2d_frames_workgroups(int64_t n, int hi, int wi, int h
     Plan2D pl;
     if (!shape_ok2d(n, hi, wi, ho, wo, ci, co, kh, kw, ci, co)) return 0;
     if (make_plan2d(n, ho, wo, ci, co, pl) != 0) return 0;
-    return pl.mTiles * (co / pl.bn);
+    return pl.mTiles * (pl.coMain / pl.bn + (pl.coMain != co ? 1 : 0));
 }
 
 extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre, void* out,
@@ -137,7 +150,7 @@ extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre,
     a.bandRows = pl.bandRows;
     a.nABuf = pl.nABuf;
     a.nBBuf = 2;
-    a.nTiles = co / pl.bn;
+    a.nTiles = pl.coMain / pl.bn;
     a.slopeNeg = 1.f;
     a.gain = 1.f;
     a.clamp = -1.f;

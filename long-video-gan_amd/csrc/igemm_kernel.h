@@ -42,6 +42,7 @@ struct ConvArgs2D : ConvArgs
     int          tilesX, tilesY;
     int          oStride;      // elements between consecutive pixels of out (>= Co)
     int          offY, offX;   // output pixel (0, 0) reads input pixels (offY + dh, offX + dw)
+    int          coBase;       // first output channel of this launch (a launch may cover a channel range of the Co channels)
 };
 
 template <bool T2D> struct ConvArgsOf { typedef ConvArgs type; };
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
     const int mt = tile / p.nTiles, nt = tile - mt * p.nTiles;
     const int64_t m0 = (int64_t)mt * BM;
-    const int co0 = nt * BN;
+    int co0 = nt * BN;
+    if constexpr (T2D) co0 += p.coBase;
     // T2D: spatial tile -> (frame, tile row, tile column)
     int n2 = 0, y0 = 0, x0 = 0;
     if constexpr (T2D)
