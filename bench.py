@@ -405,9 +405,15 @@ def main():
             # dense-contraction (MFMA) figure of the step, and BASELINE.json configs[3] (super-resolution pair)
             # with the filtered_lrelu roofline. Failures here never take the main line down.
             del graph
-            for name, leg in (('forward_only', lambda: _forward_only_leg(G, B, T, dtype)),
-                              ('mfma', lambda: _mfma_leg(step, elapsed / args.steps)),
-                              ('sres', lambda: _sres_leg(dev, timer))):
+            legs = [('forward_only', lambda: _forward_only_leg(G, B, T, dtype)),
+                    ('mfma', lambda: _mfma_leg(step, elapsed / args.steps)),
+                    ('batch_sweep', lambda: _batch_sweep_leg(G, D, dtype, T)),
+                    ('sres', lambda: _sres_leg(dev, timer))]
+            if not os.environ.get('LVG_BENCH_NO_TRAIN_LEGS'):
+                # BASELINE.json configs[2] and configs[4] at N = 1 (the driver's multi-GPU runs use --workload train_lres)
+                legs += [('train_lres', lambda: _train_lres_run(1, 0, dev, dtype, T, steps=2, warmup=1, dtype_name=args.dtype)),
+                         ('train_sres', lambda: _train_sres_leg(dev))]
+            for name, leg in legs:
                 try:
                     result[name] = leg()
                 except Exception as err:  # pylint: disable=broad-except
@@ -462,27 +468,35 @@ def _train_lres_workload(args, world, rank, dev, dtype):
     augmentation in front of D. Gradients: FlatGradSync with overlap=True (each 128 MB bucket is all-reduced over
     RCCL from an autograd hook while the rest of the last backward still runs). Eager launches (the collectives
     cannot be captured into a hipGraph on this stack). One JSON line on rank 0, frames/s over all ranks."""
+    res = _train_lres_run(world, rank, dev, dtype, args.frames, args.steps, args.warmup, dtype_name=args.dtype)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dtype_name='bf16', total_batch=32, accum=None):
+    """-> the result dict (identical on every rank). Micro-batches: 2 per update as in the reference's 8-GPU recipe (batch 32 / 8 GPUs,
+    grad_accum 2 => per-GPU micro-batch 2); at N = 1 the 32 clips are cut into micro-batches of 8 (the size the main line measures)."""
     from lvg.train_lres import LowResTrainer
-    total_batch = 32
     assert total_batch % world == 0
     B = total_batch // world
-    accum = 2 if B % 2 == 0 else 1
+    if accum is None:
+        accum = max(2, B // 8) if B % 2 == 0 else 1
     torch.manual_seed(0)
-    tr = LowResTrainer(seq_length=args.frames, device=dev, compute_dtype=dtype, G_grad_accum=accum, D_grad_accum=accum,
+    tr = LowResTrainer(seq_length=frames_per_clip, device=dev, compute_dtype=dtype, G_grad_accum=accum, D_grad_accum=accum,
                        overlap_grad_sync=True, with_ema=True)
     torch.manual_seed(1 + rank)
-    real = torch.rand(B, 3, args.frames, 36, 64, device=dev) * 2 - 1
+    real = torch.rand(B, 3, frames_per_clip, 36, 64, device=dev) * 2 - 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
     step_no = 1
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         tr.train_step(step_no, real); step_no += 1
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         tr.train_step(step_no, real); step_no += 1
     barrier()
     elapsed = time.perf_counter() - t0
@@ -490,16 +504,103 @@ def _train_lres_workload(args, world, rank, dev, dtype):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    r1_steps = sum(1 for k in range(args.warmup + 1, args.warmup + args.steps + 1) if k % 16 == 0)
-    if rank == 0:
-        print(json.dumps({
-            'metric': 'frames/sec train_lres iteration (update_G + update_D + R1/16 + EMA), 128-frame 36x64 clips',
-            'value': round(total_batch * args.frames * args.steps / elapsed, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'launch_mode': 'eager',
-            'config': {'workload': f'train_lres.py step body, total batch {total_batch} ({B}/GPU, {accum} micro-batches), G at {args.frames + 32} frames cropped to {args.frames}, '
-                                   f'DiffAugment + temporal-scale augment, R1 steps in the timed region: {r1_steps}', 'global_batch': total_batch,
-                       'frames_per_clip': args.frames, 'parallelism': f'dp{world}', 'grad_sync': 'FlatGradSync(overlap=True), 128 MB buckets'}}), flush=True)
+    r1_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 16 == 0)
+    extra = {}
+    if r1_steps == 0:
+        # short runs see no R1 step (every 16th): time one R1 update on its own and report the amortised rate next to the plain one
+        tr.update_r1(real, gain=16)
+        barrier()
+        t1 = time.perf_counter()
+        tr.update_r1(real, gain=16)
+        barrier()
+        r1_ms = (time.perf_counter() - t1) * 1e3
+        extra = {'r1_update_ms': round(r1_ms, 2), 'value_with_r1_every_16': round(total_batch * frames_per_clip / (elapsed / steps + r1_ms * 1e-3 / 16), 2)}
+    del tr
+    return {
+        **extra,
+        'metric': 'frames/sec train_lres iteration (update_G + update_D + R1/16 + EMA), 128-frame 36x64 clips',
+        'value': round(total_batch * frames_per_clip * steps / elapsed, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': round(elapsed / steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': dtype_name, 'data': 'synthetic', 'launch_mode': 'eager',
+        'config': {'workload': f'train_lres.py step body, total batch {total_batch} ({B}/GPU, {accum} micro-batches), G at {frames_per_clip + 32} frames cropped to {frames_per_clip}, '
+                               f'DiffAugment + temporal-scale augment, R1 steps in the timed region: {r1_steps}', 'global_batch': total_batch,
+                   'frames_per_clip': frames_per_clip, 'parallelism': f'dp{world}', 'grad_sync': 'FlatGradSync(overlap=True), 128 MB buckets'}}
+
+
+def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):
+    """BASELINE.json configs[4] at N = 1: the step body of train_sres.py:241-264 (SuperResTrainer.train_step: update_G, update_D, R1 on every
+    16th step, ADA probability update on every 4th, generator EMA) on synthetic (low-resolution clip with context, high-resolution clip)
+    pairs, total batch 16 in micro-batches of 2 segments, ADA pipeline and conditioning augmentation on. Eager launches."""
+    from lvg.train_sres import SuperResTrainer
+    torch.manual_seed(0)
+    accum = max(1, total_batch // 2)
+    tr = SuperResTrainer(device=dev, compute_dtype=torch.float16, G_grad_accum=accum, D_grad_accum=accum, augment_p_init=0.2,
+                         overlap_grad_sync=True, with_ema=True)
+    lr = torch.rand(total_batch, 3, tr.context_seq_length, 36, 64, device=dev) * 2 - 1
+    hr = torch.rand(total_batch, 3, tr.seq_length, 144, 256, device=dev) * 2 - 1
+    step_no = 1
+    for _ in range(warmup):
+        tr.train_step(step_no, lr, hr); step_no += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(step_no, lr, hr); step_no += 1
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r1_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 16 == 0)
+    ada_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 4 == 0)
+    extra = {}
+    if r1_steps == 0:
+        lr_c = tr.crop_to_seq_length(lr)
+        tr.update_r1(lr_c, hr, gain=16)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr.update_r1(lr_c, hr, gain=16)
+        torch.cuda.synchronize()
+        r1_ms = (time.perf_counter() - t1) * 1e3
+        extra = {'r1_update_ms': round(r1_ms, 2), 'value_with_r1_every_16': round(total_batch * 8 / (dt + r1_ms * 1e-3 / 16), 2)}
+    del tr
+    return {**extra, 'metric': 'frames/sec train_sres iteration (update_G + update_D + R1/16 + ADA/4 + EMA), 8-frame 144x256 segments', 'value': round(total_batch * 8 / dt, 2),
+            'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'warmup': warmup, 'dtype': 'f16', 'launch_mode': 'eager', 'n_gpus': 1,
+            'config': {'workload': f'train_sres.py step body, total batch {total_batch} ({accum} micro-batches of 2 segments), ADA p = 0.2 + conditioning augmentation, '
+                                   f'R1 steps in the timed region: {r1_steps}, ADA updates: {ada_steps}', 'global_batch': total_batch}}
+
+
+def _batch_sweep_leg(G, D, dtype, T, batches=(1, 2, 4), steps=6):
+    """The main step (G forward, D forward, backward; hipGraph) at the per-GPU batch sizes of SURVEY.md 8(d) config 2 (b in {1, 2, 4}; the
+    reference's 8-GPU recipe runs micro-batches of 2): frames/s and ms per step, without the optimizer (parameters stay as they are)."""
+    from lvg.models import lres
+    out = {}
+    for b in batches:
+        def compute():
+            for p in G.parameters():
+                p.grad = None
+            video = G(b, T, magnitude_ema_beta=0.999, dtype=dtype)
+            F.softplus(-D(video, dtype=dtype)).mean().backward()
+        try:
+            for _ in range(2):
+                compute()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                compute()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                compute()
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            del g
+            out[str(b)] = {'frames_per_s': round(b * T / dt, 1), 'ms_per_step': round(dt * 1e3, 3)}
+        except Exception as err:  # pylint: disable=broad-except
+            out[str(b)] = {'error': f'{type(err).__name__}: {err}'[:200]}
+    return out
 
 
 

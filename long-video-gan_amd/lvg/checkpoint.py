@@ -18,11 +18,24 @@ def _module_state(module) -> Optional[dict]:
 
 
 def trainer_state(trainer, step: int) -> dict:
-    """Everything `load_trainer_state` needs to resume `trainer` bit-exactly (single rank; ranks hold identical copies)."""
-    return dict(format='lvg-train-1', step=int(step),
-                G=_module_state(trainer.G), D=_module_state(trainer.D), G_ema=_module_state(getattr(trainer, 'G_ema', None)),
-                G_opt=_cpu(trainer.G_opt.state_dict()), D_opt=_cpu(trainer.D_opt.state_dict()),
-                rng=dict(cpu=torch.get_rng_state()))
+    """Everything `load_trainer_state` needs to resume `trainer` (single rank; ranks hold identical copies): networks, generator
+    EMA, both optimizers, the random streams (CPU and the trainer's GPU) and -- for the super-resolution trainer -- the ADA state the
+    reference's `ckpt()` stores next to the networks (model/video_gan_sres.py: `augment`, `in_augment`, `real_sign_collector`):
+    the adapted probability `augment.p`, the conditioning-side pipe's buffers and the real-sign statistics accumulated since the
+    last probability update."""
+    state = dict(format='lvg-train-1', step=int(step),
+                 G=_module_state(trainer.G), D=_module_state(trainer.D), G_ema=_module_state(getattr(trainer, 'G_ema', None)),
+                 G_opt=_cpu(trainer.G_opt.state_dict()), D_opt=_cpu(trainer.D_opt.state_dict()),
+                 rng=dict(cpu=torch.get_rng_state()))
+    dev = getattr(trainer, 'device', None)
+    if dev is not None and torch.device(dev).type == 'cuda' and torch.cuda.is_available():
+        state['rng']['cuda'] = torch.cuda.get_rng_state(torch.device(dev))
+    for name in ('augment', 'in_augment'):
+        if getattr(trainer, name, None) is not None:
+            state[name] = _module_state(getattr(trainer, name))
+    if hasattr(trainer, '_real_sign_sum'):
+        state['real_sign_sum'] = trainer._real_sign_sum.detach().cpu().clone()
+    return state
 
 
 def _cpu(obj):
@@ -53,10 +66,18 @@ def load_trainer_state(trainer, state: dict) -> int:
         trainer.D.load_state_dict(state['D'])
         if state.get('G_ema') is not None and getattr(trainer, 'G_ema', None) is not None:
             trainer.G_ema.load_state_dict(state['G_ema'])
+        for name in ('augment', 'in_augment'):
+            if state.get(name) is not None:
+                assert getattr(trainer, name, None) is not None, f'the checkpoint holds `{name}` state but the trainer was built without it'
+                getattr(trainer, name).load_state_dict(state[name])
+        if state.get('real_sign_sum') is not None and hasattr(trainer, '_real_sign_sum'):
+            trainer._real_sign_sum.copy_(state['real_sign_sum'])
     trainer.G_opt.load_state_dict(state['G_opt'])
     trainer.D_opt.load_state_dict(state['D_opt'])
     if 'rng' in state and 'cpu' in state['rng']:
         torch.set_rng_state(state['rng']['cpu'])
+    if 'rng' in state and 'cuda' in state['rng'] and torch.cuda.is_available() and torch.device(getattr(trainer, 'device', 'cpu')).type == 'cuda':
+        torch.cuda.set_rng_state(state['rng']['cuda'], torch.device(trainer.device))
     return int(state['step'])
 
 

@@ -85,6 +85,7 @@ class FlatGradSync:
         self.overlap = overlap
         self._armed = False
         self._pending = [0] * len(self.buckets)
+        self._streams = [set() for _ in self.buckets]     # streams that accumulated gradients into each bucket since arm()
         self._launched = set()
         self._work = []
         self._hooks = []
@@ -104,11 +105,16 @@ class FlatGradSync:
         self.zero()
 
     def _make_hook(self, index: int):
-        def hook(_param):
+        def hook(param):
             self._fired[index] = True
             if not self._armed:
                 return
             b = self.bucket_of[index]
+            if param.is_cuda:
+                # Autograd accumulates a leaf's gradient on the stream the leaf was first USED on: parameters consumed on a side
+                # stream (lres: the weight / style terms run ahead of the convolutions there) accumulate on that stream, others
+                # on the main one. The hook runs right after the accumulation was enqueued, on that same stream: remember it.
+                self._streams[b].add(torch.cuda.current_stream(param.device))
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
@@ -118,6 +124,14 @@ class FlatGradSync:
         self._launched.add(b)
         if dist.is_available() and dist.is_initialized():
             s, e, _ = self.buckets[b]
+            if self.flat.is_cuda:
+                # the collective is ordered after the CURRENT stream only: make it wait for every stream that accumulated into
+                # this bucket (round-2 advisor finding: a bucket mixing side-stream and main-stream parameters could be reduced
+                # before the other stream's accumulation kernels finished)
+                cur = torch.cuda.current_stream(self.flat.device)
+                for st in self._streams[b]:
+                    if st != cur:
+                        cur.wait_stream(st)
             self._work.append(dist.all_reduce(self.flat[s:e], async_op=True))
 
     def zero(self) -> None:
@@ -134,6 +148,7 @@ class FlatGradSync:
         for b, (_, _, mem) in enumerate(self.buckets):
             self._pending[b] = sum(1 for i in mem if self.params[i].requires_grad)
         self._launched = set()
+        self._streams = [set() for _ in self.buckets]
         self._work = []
 
     def _adopt_replaced_grads(self) -> None:

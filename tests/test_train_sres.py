@@ -54,6 +54,37 @@ def test_train_step_cpu():
     assert float(tr.augment.p) == p
 
 
+def test_checkpoint_resumes_the_ada_state_cpu(tmp_path):
+    """A resumed super-resolution run continues with the adapted ADA probability, the conditioning-side pipe and the real-sign
+    statistics collected since the last probability update (what the reference's ckpt() keeps, model/video_gan_sres.py
+    `augment` / `in_augment` / `real_sign_collector`; round-2 advisor finding), and then takes the same next step."""
+    from lvg import checkpoint
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    a = SuperResTrainer(device='cpu', compute_dtype=torch.float32, **SMALL)
+    lr = torch.rand(2, 3, 4, 9, 16) * 2 - 1
+    hr = torch.rand(2, 3, 2, 36, 64) * 2 - 1
+    a.augment.p.fill_(0.1375)
+    a.update_D(lr, lr, hr)                                              # collects real-sign statistics, moves D
+    assert float(a._real_sign_sum[1]) > 0
+    path = tmp_path / 'sres.pt'
+    checkpoint.save_checkpoint(path, a, step=3)
+    torch.manual_seed(9)
+    b = SuperResTrainer(device='cpu', compute_dtype=torch.float32, **SMALL)      # different init, p = 0.3
+    assert checkpoint.load_checkpoint(path, b) == 3
+    assert float(b.augment.p) == float(a.augment.p) == pytest.approx(0.1375)
+    assert torch.equal(a._real_sign_sum, b._real_sign_sum)
+    for (k, x), (_, y) in zip(a.in_augment.state_dict().items(), b.in_augment.state_dict().items()):
+        assert torch.equal(x, y), k
+    for tr in (a, b):
+        torch.manual_seed(4)
+        tr.update_D(lr, lr, hr)
+        tr.update_ada(gain=4)
+    assert float(a.augment.p) == float(b.augment.p)
+    for (k, x), (_, y) in zip(a.D.state_dict().items(), b.D.state_dict().items()):
+        assert torch.equal(x, y), k
+
+
 def test_run_D_applies_one_transform_to_both_clips_cpu():
     torch.manual_seed(1)
     tr = SuperResTrainer(device='cpu', compute_dtype=torch.float32, **dict(SMALL, lr_cond_prob=1.0, in_augment_strength=0.0))
