@@ -43,7 +43,7 @@ int env_int2(const char* name, int dflt)
 // workgroups de-synchronise their barriers); 16 x 16 tiles on 8 waves through LVG_CONV2D_BM=256 (A/B measurements).
 int make_plan2d(int64_t n, int ho, int wo, int ci, int co, Plan2D& pl)
 {
-    const int fbm = env_int2("LVG_CONV2D_BM", 0), fbn = env_int2("LVG_CONV2D_BN", 0);
+    static const int fbm = env_int2("LVG_CONV2D_BM", 0), fbn = env_int2("LVG_CONV2D_BN", 0);                              // read once per process
     pl.bm = fbm == 256 ? 256 : 128;
     // Co = 128 k + 64 (k >= 1): k tiles of 128 channels + ONE of 64 (two launches) instead of 2 k + 1 tiles of 64 -- the 64-channel
     // tile does half the MFMAs per fragment read and per staged band (measured: 576 output channels as 9 x 64 ran at 0.78 of 4 x 128 + 64)

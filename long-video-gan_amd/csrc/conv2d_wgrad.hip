@@ -198,20 +198,28 @@ bool wgrad2d_plan(int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int
 
 int compute_units2d()
 {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    static int cache[64] = {0};                                        // per device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }   // MI355X (also what a box without a GPU plans for)
+    int& slot = cache[dev & 63];
+    if (slot == 0)
     {
-        (void)hipGetLastError();
-        cus = 256;                                                     // MI355X (also what a box without a GPU plans for)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        slot = cus;
     }
-    return cus;
+    return slot;
 }
 
 // Split K for ONE full round of workgroups, rounded down (the rule measured for conv3d_wgrad.hip: a partial second round costs 1.3x,
 // excess splits only partial-sum traffic): two workgroups per CU by registers. LVG_WGRAD2D_SPLITS overrides (measurements).
 int wgrad2d_splits(const WPlan2D& pl, int ci, int co)
 {
-    const char* f = getenv("LVG_WGRAD2D_SPLITS");
+    static const char* const f = getenv("LVG_WGRAD2D_SPLITS");         // measurement override: read once per process
     const int64_t tiles = (int64_t)(ci / 64) * (co / 64);
     const int64_t slots = (int64_t)compute_units2d() * 2;
     int64_t s = slots / tiles;

@@ -78,7 +78,7 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
         const int epilogue = (bm / 64 * 2) * 64 * (bn + 16);             // the epilogue stages every wave's 64-pixel x bn/2-channel tile, pitch bn + 16 bytes
         if (pl.ldsBytes < epilogue) pl.ldsBytes = epilogue;
     };
-    const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);
+    static const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);   // read once per process
     int bn = (Co % 128 == 0) ? 128 : 64;
     if (fbn == 64 || (fbn == 128 && Co % 128 == 0)) bn = fbn;
     int bm = (2 * reach >= 64 && bn == 128 && lvg_ceil_div(M, 256) * (Co / bn) >= 512) ? 256 : 128;

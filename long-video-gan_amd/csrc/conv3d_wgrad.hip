@@ -227,18 +227,21 @@ bool wgrad_plan(int64_t frames, int h, int w, int ci, int co, int kt, int kh, in
 
 int compute_units()
 {
-    static int cus = 0;
-    if (cus == 0)
+    static int cus[64] = {0};                                          // per device ordinal (a process may drive devices of different sizes)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }   // MI355X (also what a box without a GPU plans for)
+    int& slot = cus[dev & 63];
+    if (slot == 0)
     {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
         {
             (void)hipGetLastError();
-            n = 256;                                                   // MI355X (also what a box without a GPU plans for)
+            n = 256;
         }
-        cus = n;
+        slot = n;
     }
-    return cus;
+    return slot;
 }
 
 // Split K so that the launch is ONE full round of workgroups, rounded DOWN: 184 registers allow two workgroups per CU, the LDS band
@@ -247,8 +250,8 @@ int compute_units()
 // (1024 splits of the 64-channel layer wrote and re-read 151 MB). LVG_WGRAD_SPLITS / LVG_WGRAD_TARGET override (measurements).
 int wgrad_splits(const WPlan& pl, int ci, int co, int kt)
 {
-    const char* f = getenv("LVG_WGRAD_SPLITS");
-    const char* tg = getenv("LVG_WGRAD_TARGET");
+    static const char* const f = getenv("LVG_WGRAD_SPLITS");           // measurement overrides: read once per process
+    static const char* const tg = getenv("LVG_WGRAD_TARGET");
     const int64_t tiles = (int64_t)(ci / 64) * (co / 64) * kt;
     const int perCU = std::max(1, std::min(2, (160 * 1024) / pl.ldsBytes));
     const int64_t slots = (int64_t)compute_units() * perCU;

@@ -98,7 +98,7 @@ def run(forward_only=False, frames=16, budget_s=14.0, max_reps=5):
         med128, reps128 = _median_time(fwd128, 8.0, 3)
         what = 'forward' if forward_only else 'forward + D forward + backward'
         impl = ("the reference's own networks and impl='ref' ops (imported from " + REFERENCE_ROOT + ')') if kind == 'reference' else \
-               'this repo\'s networks, plain-PyTorch op definitions (reference CPU-fallback arithmetic)'
+               'NOT the reference\'s code (no reference checkout on this box): this repo\'s networks with the plain-PyTorch op definitions (the reference\'s CPU-fallback arithmetic, a different network decomposition)'
         return dict(value=round(frames / med, 3), unit='frames/s', cores=cores, kind=kind,
                     sample=f'{reps} x [G(1,{frames}) float32 {what}] on {cores} of {os.cpu_count()} host threads, median {med:.2f} s/step; {impl}',
                     one_thread=dict(value=round(frames / med1, 3), unit='frames/s', cores=1, sample=f'{reps1} x the same step, median {med1:.2f} s'),
