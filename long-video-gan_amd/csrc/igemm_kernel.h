@@ -6,6 +6,7 @@
 #include "epilogue_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 
 namespace {
 
@@ -110,6 +111,19 @@ __device__ __forceinline__ void dma16(const unsigned char* base, uint32_t laneOf
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(laneOff), "s"(base), "s"(ldsPiece) : "memory");
 }
+
+// f(integral_constant<int, 0>), ..., f(integral_constant<int, N - 1>): a loop whose counter is a compile-time constant in the body
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+#ifndef LVG_CONV2D_STATIC
+#define LVG_CONV2D_STATIC 1
+#endif
+constexpr bool kStaticTaps = LVG_CONV2D_STATIC != 0;   // T2D: K loop unrolled over the 9 taps of a band with compile-time tap geometry (0: the generic loop; A/B builds)
+#ifndef LVG_CONV2D_SPREAD
+#define LVG_CONV2D_SPREAD 0
+#endif
+constexpr bool kSpreadDma = LVG_CONV2D_SPREAD != 0;    // T2D static loop: the LDS-DMA pieces of a K-step are issued between its MFMA sub-steps instead of all in front
 
 template <int N> __device__ __forceinline__ void wait_vm_const()
 {
@@ -443,7 +457,156 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
         }
     };
 
-    if (!split)
+    if constexpr (T2D && kStaticTaps)
+    {
+        // ---- 2-D tiles, 3 x 3 taps (the host guarantees kt = 1, kh = kw = 3): the nine K-steps of a band are unrolled with the tap as
+        // a compile-time constant. Measured motivation (instruction mix of the generic loop, tools/isa_loop_count.py): the weight waves
+        // issue ~75 scalar + vector instructions next to the 16 MFMAs of a K-step, the BAND wave ~275 (piece -> patch pixel -> clamped
+        // source offset for three pieces, tap counters, the generic staging bookkeeping) -- and every K-step ends in a barrier, so the
+        // band wave paces the workgroup. Here everything a K-step needs is precomputed: fragment addresses per (tap column, pixel block,
+        // sub-step) with the tap row as an immediate offset, the lane offsets of all the band pieces of this wave, and the staging
+        // pointers advance by constants.
+        constexpr int NTAP = 9;
+        constexpr int NPIECE = ((BM / kTileW + 2) * kPatchPitch + 7) / 8;     // 1-KiB pieces of a band
+        constexpr int NPW = (NPIECE + NWA - 1) / NWA;                         // ... per band wave
+        constexpr int PER = (NPW + NTAP - 1) / NTAP;                          // ... per band wave and K-step
+        static_assert(PER <= MAXAI, "band pieces per K-step");
+        uint32_t xA[3][PB][4];
+        #pragma unroll
+        for (int c = 0; c < 3; c++)
+            #pragma unroll
+            for (int pb = 0; pb < PB; pb++)
+                #pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    xA[c][pb][ks] = ((uint32_t)(jrow[pb] + c) << 7) + ((((uint32_t)hi ^ (((uint32_t)(txl + c) >> 1) & 7u)) << 4) ^ (uint32_t)(ks << 5));
+        // one K-step of arithmetic on band `bandOff`, weight tile `wOff` (byte offsets in LDS, wave-uniform)
+        auto mma_step = [&](auto tapc, uint32_t bandOff, uint32_t wOff, auto&& stage) __attribute__((always_inline))
+        {
+            constexpr int TAP = decltype(tapc)::value, DH = TAP / 3, DW = TAP % 3;
+            uint4 wf[2][NCB], xf[2][PB];
+            auto fetch = [&](int ks, int set) __attribute__((always_inline))
+            {
+                #pragma unroll
+                for (int cb = 0; cb < NCB; cb++)
+                    wf[set][cb] = *reinterpret_cast<const uint4*>(smem + (wAddr[cb][ks] + wOff));
+                #pragma unroll
+                for (int pb = 0; pb < PB; pb++)
+                    xf[set][pb] = *reinterpret_cast<const uint4*>(smem + (xA[DW][pb][ks] + bandOff) + DH * kPatchPitch * kRowBytes);
+            };
+            if constexpr (!kSpreadDma) stage(std::integral_constant<int, -1>{});
+            if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(1);
+            fetch(0, 0);
+            static_for<kBK / 16>([&](auto ksc) __attribute__((always_inline))
+            {
+                constexpr int ks = decltype(ksc)::value;
+                if constexpr (ks + 1 < kBK / 16) fetch(ks + 1, (ks + 1) & 1);
+                #pragma unroll
+                for (int pb = 0; pb < PB; pb++)
+                    #pragma unroll
+                    for (int cb = 0; cb < NCB; cb++)
+                        acc[cb][pb] = Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
+                // this sub-step's share of the staging: the DMA instructions (volatile asm) sit between the MFMA groups in program order
+                if constexpr (kSpreadDma) stage(ksc);
+            });
+            if constexpr (kPinOrder && !kSpreadDma)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
+                #pragma unroll
+                for (int ks = 0; ks < kBK / 16 - 1; ks++)
+                {
+                    __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
+            }
+            if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(0);
+        };
+        const uint32_t ldsB0 = ldsBase + bOff;
+        if (isB)
+        {
+            // weight waves: the tile of the NEXT K-step goes into the other ring slot (the prologue staged the first tile; wNext = the second)
+            for (macro = 0; macro < nMacro; macro++)
+            {
+                const uint32_t bandOff = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
+                const bool more = macro + 1 < nMacro;
+                static_for<NTAP>([&](auto tapc) __attribute__((always_inline))
+                {
+                    constexpr int TAP = decltype(tapc)::value;
+                    const uint32_t stageOff = curB ^ (uint32_t)bBytes;              // two slots: the one not being read
+                    const unsigned char* const wStage = wNext;
+                    if constexpr (TAP == NTAP - 2)
+                    {
+                        // the tile after the last tap of this band is the first tap of the next band (on the last band: this band's first
+                        // tile once more, into a slot nobody reads again -- keeps the loop free of branches around the staging)
+                        if (more) wMacro += kRowBytes;
+                        wNext = wMacro;
+                    }
+                    else wNext += tapStride;
+                    // NBI pieces: all in front of the arithmetic (sub-step -1), or spread over the first three sub-steps
+                    constexpr int PER_KS = (NBI + 2) / 3;
+                    mma_step(tapc, bandOff, curB, [&](auto ksc) __attribute__((always_inline))
+                    {
+                        constexpr int ks = decltype(ksc)::value;
+                        #pragma unroll
+                        for (int i = 0; i < NBI; i++)
+                            if (ks < 0 || (i / PER_KS == ks))
+                                dma16(wStage, bLaneOff[i], ldsB0 + stageOff + bPiece[i] * 1024);
+                    });
+                    wait_vm_const<0>();
+                    __syncthreads();
+                    curB ^= (uint32_t)bBytes;
+                });
+            }
+        }
+        else
+        {
+            // band waves: lane offsets of this wave's pieces of a band (piece index = slot * NWA + wave - first band wave), relative to
+            // the 64-channel chunk; the pieces of the next band are spread over the nine K-steps of this one and waited for at the last
+            const int wsub = NWA == 1 ? 0 : wave - NWB;                               // this wave among the band waves
+            uint32_t aLane[NPW];
+            #pragma unroll
+            for (int sl = 0; sl < NPW; sl++)
+            {
+                const int piece = sl * NWA + wsub;
+                const int r = piece * 8 + (lane >> 3);
+                const int hy = r / kPatchPitch, hx = r - hy * kPatchPitch;
+                int yy = y0 + p.offY + hy, xx = x0 + p.offX + hx;
+                yy = yy > p.Hi - 1 ? p.Hi - 1 : yy;
+                xx = xx > p.Wi - 1 ? p.Wi - 1 : xx;
+                aLane[sl] = (uint32_t)((n2 * p.Hi + yy) * p.Wi + xx) * xRowStride + (aChunkOff ^ (uint32_t)((hx >> 1) & 7)) * 16;
+            }
+            const uint32_t pieceLds0 = ldsBase + (uint32_t)aOff + (uint32_t)(wsub * 1024);
+            for (macro = 0; macro < nMacro; macro++)
+            {
+                const uint32_t bandOff = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
+                const uint32_t nextLds = pieceLds0 + (uint32_t)(((macro + 1) & 1) * aBytes);
+                const bool more = macro + 1 < nMacro;
+                const unsigned char* const xNext = xb + (uint32_t)(macro + 1) * kRowBytes;      // next 64-channel chunk
+                static_for<NTAP>([&](auto tapc) __attribute__((always_inline))
+                {
+                    constexpr int TAP = decltype(tapc)::value;
+                    mma_step(tapc, bandOff, curB, [&](auto ksc) __attribute__((always_inline))
+                    {
+                        constexpr int ks = decltype(ksc)::value;
+                        if (more)
+                        {
+                            #pragma unroll
+                            for (int i = 0; i < PER; i++)
+                            {
+                                const int sl = TAP * PER + i;                        // compile-time after unrolling
+                                if ((ks < 0 || i == ks) && sl < NPW && sl * NWA + wsub < NPIECE)
+                                    dma16(xNext, aLane[sl < NPW ? sl : 0], nextLds + (uint32_t)(sl * NWA * 1024));
+                            }
+                        }
+                    });
+                    if constexpr (TAP == NTAP - 1) wait_vm_const<0>();
+                    __syncthreads();
+                    curB ^= (uint32_t)bBytes;
+                });
+            }
+        }
+    }
+    else if (!split)
     {
         // no spatial taps: every wave stages its share of both operands one K-step ahead
         for (int step = 0; step < nSteps; step++)
