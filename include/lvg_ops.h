@@ -296,7 +296,8 @@ int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, cons
  *     x [n][hi][wi] pixels of x_pixel_stride elements (>= ci, % 8; 0 = ci), w [3][3][co][ci] tap-major, out [n][ho][wo] pixels of
  *     out_pixel_stride elements (0 = co), ho <= hi - in_off_y - 2, wo <= wi - in_off_x - 2; pre float32 [n][co] or NULL (= 1); ci % 64 == 0, co % 64 == 0;
  *     fewer than 2^32 bytes of x. Run on the padded output gradient with the weight mirrored in both taps and its channel
- *     roles exchanged it is the data gradient.
+ *     roles exchanged it is the data gradient. out_dtype = dtype, or LVG_F32: the float32 accumulators are stored unrounded (the
+ *     output side of a float32-accurate contraction from operands split into 16-bit high / low parts stacked along ci).
  *   lvg_conv2d_frames_wgrad:  part[s][dh][dw][co][ci] = sum over the K-steps of range s of dy[n][oy][ox][co] * x[n][oy + dh][ox + dw][ci]
  *     dy [n][hd][wd] (hd % 4 == 0, wd % 16 == 0: 4 x 16 pixel patches; rows / columns past the true gradient hold zeros),
  *     x [n][hx][wx] with hx >= hd + 2, wx >= wd + 2 (finite everywhere); part float32 [splits][3][3][co][ci], the caller adds the
@@ -311,7 +312,7 @@ int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, cons
 int64_t lvg_conv2d_frames_workgroups(int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int kh, int kw);
 int lvg_conv2d_frames(const void* x, const void* w, const float* pre, void* out,
                       int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int kh, int kw, int in_off_y, int in_off_x,
-                      int64_t x_pixel_stride, int64_t out_pixel_stride, int dtype, void* stream);
+                      int64_t x_pixel_stride, int64_t out_pixel_stride, int dtype, int out_dtype, void* stream);
 int lvg_conv2d_frames_wgrad_splits(int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw);
 int lvg_conv2d_frames_wgrad(const void* x, const void* dy, float* part,
                             int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw,

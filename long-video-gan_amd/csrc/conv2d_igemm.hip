@@ -41,10 +41,10 @@ int env_int2(const char* name, int dflt)
 
 // 8 x 16 tiles on 4 waves, two workgroups per CU (the measured optimum of the time-major kernel: two independent 4-wave
 // workgroups de-synchronise their barriers); 16 x 16 tiles on 8 waves through LVG_CONV2D_BM=256 (A/B measurements).
-int make_plan2d(int64_t n, int ho, int wo, int ci, int co, Plan2D& pl)
+int make_plan2d(int64_t n, int ho, int wo, int ci, int co, Plan2D& pl, bool outF32 = false)
 {
     static const int fbm = env_int2("LVG_CONV2D_BM", 0), fbn = env_int2("LVG_CONV2D_BN", 0);                              // read once per process
-    pl.bm = fbm == 256 ? 256 : 128;
+    pl.bm = (fbm == 256 && !outF32) ? 256 : 128;
     // Co = 128 k + 64 (k >= 1): k tiles of 128 channels + ONE of 64 (two launches) instead of 2 k + 1 tiles of 64 -- the 64-channel
     // tile does half the MFMAs per fragment read and per staged band (measured: 576 output channels as 9 x 64 ran at 0.78 of 4 x 128 + 64)
     pl.bn = co >= 128 ? 128 : 64;
@@ -74,10 +74,10 @@ bool shape_ok2d(int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int k
     return n * hi * wi < ((int64_t)1 << 31) && n * hi * wi * xstride * 2 < ((int64_t)1 << 32) && n * ho * wo < ((int64_t)1 << 31);
 }
 
-template <class T, int BM, int BN>
+template <class T, int BM, int BN, bool OUTF = false>
 int launch2d(const ConvArgs2D& a, const Plan2D& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, 2, 2, true>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, 2, 2, true, OUTF>;
     if (pl.ldsBytes > 64 * 1024)
     {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -94,17 +94,19 @@ int launch2d(const ConvArgs2D& a, const Plan2D& pl, hipStream_t stream)
 }
 
 template <class T>
-int launch2d_tile(const ConvArgs2D& a0, const Plan2D& pl, hipStream_t s)
+int launch2d_tile(const ConvArgs2D& a0, const Plan2D& pl, hipStream_t s, bool outF32)
 {
     ConvArgs2D a = a0;
     a.coBase = 0;
     a.nTiles = pl.coMain / pl.bn;
     int rc = LVG_OK;
-    if (pl.bm == 256) rc = pl.bn == 128 ? launch2d<T, 256, 128>(a, pl, s) : launch2d<T, 256, 64>(a, pl, s);
-    else              rc = pl.bn == 128 ? launch2d<T, 128, 128>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
+    if (outF32)             rc = pl.bn == 128 ? launch2d<T, 128, 128, true>(a, pl, s) : launch2d<T, 128, 64, true>(a, pl, s);     // (8 x 16 tiles only)
+    else if (pl.bm == 256)  rc = pl.bn == 128 ? launch2d<T, 256, 128>(a, pl, s) : launch2d<T, 256, 64>(a, pl, s);
+    else                    rc = pl.bn == 128 ? launch2d<T, 128, 128>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
     if (rc != LVG_OK || pl.coMain == a.Co) return rc;
     a.coBase = pl.coMain;                                                // the last 64 channels
     a.nTiles = 1;
+    if (outF32) return launch2d<T, 128, 64, true>(a, pl, s);
     return pl.bm == 256 ? launch2d<T, 256, 64>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
 }
 
@@ -120,9 +122,11 @@ extern "C" int64_t lvg_conv2d_frames_workgroups(int64_t n, int hi, int wi, int h
 
 extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre, void* out,
                                  int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int kh, int kw, int in_off_y, int in_off_x,
-                                 int64_t x_pixel_stride, int64_t out_pixel_stride, int dtype, void* stream)
+                                 int64_t x_pixel_stride, int64_t out_pixel_stride, int dtype, int out_dtype, void* stream)
 {
-    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv2d_frames: float16 / bfloat16 only (dtype %d)", dtype);
+    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv2d_frames: float16 / bfloat16 operands only (dtype %d)", dtype);
+    LVG_REQUIRE(out_dtype == dtype || out_dtype == LVG_F32, "conv2d_frames: the output is the operand type or float32 (out_dtype %d)", out_dtype);
+    const bool outF32 = out_dtype == LVG_F32;
     LVG_REQUIRE(x && w && out, "conv2d_frames: null tensor");
     LVG_REQUIRE(lvg_aligned16(x) && lvg_aligned16(w) && lvg_aligned16(out) && lvg_aligned16(pre), "conv2d_frames: pointers must be 16-byte aligned");
     if (x_pixel_stride == 0) x_pixel_stride = ci;
@@ -134,7 +138,7 @@ extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre,
         return LVG_ERR_UNSUPPORTED;
     }
     Plan2D pl;
-    if (make_plan2d(n, ho, wo, ci, co, pl) != 0)
+    if (make_plan2d(n, ho, wo, ci, co, pl, outF32) != 0)
     {
         lvg_set_error("conv2d_frames: no tile plan");
         return LVG_ERR_UNSUPPORTED;
@@ -159,5 +163,5 @@ extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre,
     a.oStride = (int)out_pixel_stride;
     a.offY = in_off_y; a.offX = in_off_x;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == LVG_BF16 ? launch2d_tile<bf16_t>(a, pl, s) : launch2d_tile<f16_t>(a, pl, s);
+    return dtype == LVG_BF16 ? launch2d_tile<bf16_t>(a, pl, s, outF32) : launch2d_tile<f16_t>(a, pl, s, outF32);
 }

@@ -48,6 +48,8 @@ struct ConvArgs2D : ConvArgs
 
 template <bool T2D> struct ConvArgsOf { typedef ConvArgs type; };
 template <> struct ConvArgsOf<true> { typedef ConvArgs2D type; };
+__device__ __forceinline__ int ConvArgs2DStride(const ConvArgs2D& p) { return p.oStride; }
+__device__ __forceinline__ int ConvArgs2DStride(const ConvArgs& p) { return p.Co; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -139,7 +141,9 @@ template <int N> __device__ __forceinline__ void wait_vm_const()
 constexpr int kTileW = 16;
 constexpr int kPatchPitch = kTileW + 2;
 
-template <class T, int BM, int BN, int PB, int NB, bool T2D = false>
+// OUTF: the result leaves as float32 straight from the accumulators (one 16-byte store per lane and register quad; `out` is a float
+// tensor, `ysum` unused) -- the output side of the float32-accurate contraction built from split 16-bit operands (conv2d_frames.py).
+template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false>
 __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(typename ConvArgsOf<T2D>::type p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     constexpr int CPR = RB / 16;                  // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;                 // rows per wave instruction on the way out
     constexpr int NI = ROWS / RPI;
-    constexpr bool kLdsStore = !(kAbl & 512);
+    constexpr bool kLdsStore = !(kAbl & 512) && !OUTF;
     unsigned char* const stage = smem + wave * (ROWS * PITCH);
     if constexpr (kLdsStore)
     {
@@ -794,7 +798,26 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
                 uint2 ov, yv;
                 __builtin_memcpy(&ov, o4, 8);
                 __builtin_memcpy(&yv, y4, 8);
-                if constexpr (kLdsStore)
+                if constexpr (OUTF)
+                {
+                    float4 fv;
+                    {
+                        float o[4];
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++)
+                        {
+                            const float a = acc[cb][pb][qd * 4 + e];
+                            const float u = fmaf(a, pre4[e], add4[e]);
+                            float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
+                            if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
+                            o[e] = g * post4[e];
+                        }
+                        fv = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                    const int64_t ostr = T2D ? (int64_t)ConvArgs2DStride(p) : (int64_t)p.Co;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * ostr + co) = fv;
+                }
+                else if constexpr (kLdsStore)
                     *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
                 else if (!(kAbl & 256) || sq == 12345.f)                 // (ablation 256: no output stores)
                 {

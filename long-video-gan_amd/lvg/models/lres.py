@@ -383,6 +383,69 @@ HAND_CONV_WGRAD = os.environ.get('LVG_HAND_CONV_WGRAD', '1') == '1'      # weigh
 HAND_CONV_MIN_TILES = int(os.environ.get('LVG_HAND_CONV_MIN_TILES', '128'))
 
 
+# Channel counts that are multiples of 32 but not of 64 (the first discriminator block: 32 -> 32, 32 -> 64 at 64 x 64 pixels) reach the
+# hand-written kernels as PIXEL PAIRS: in channels-last memory two horizontally adjacent pixels of C channels ARE one pixel of 2 C channels
+# of a frame half as wide (a view, no copy), and a 3 x 3 (1 x 1) convolution of the pixels is a 3 x 3 (1 x 1) convolution of the pairs with
+# a [2 Co, 2 Ci] weight per tap in which half of the blocks are zero: output pixel 2 j + a reads input pixel 2 j + a + dw - 1 = pair
+# j + dj, half b. These layers are memory-bound (77 GFLOP on 0.5 GB of activations), so the wasted multiplications are free; what it buys is
+# the kernel's streaming rate instead of the library's small-channel kernels (0.43 / 0.89 ms forward / backward per layer, r02 profile).
+HAND_PAIR = os.environ.get('LVG_HAND_PAIR', '1') == '1'
+
+
+def _pairable(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    if not (HAND_CONV and HAND_PAIR and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and weight.dim() == 5):
+        return False
+    co, ci, _, kh, kw = weight.shape
+    if not ((ci % 64 or co % 64) and ci % 32 == 0 and co % 32 == 0) or (kh, kw) not in ((3, 3), (1, 1)) or x.shape[3] % 2 or x.shape[1] != ci:
+        return False
+    return True
+
+
+def _pair_view(t: torch.Tensor) -> torch.Tensor:
+    """[F, C, H, W] channels-last -> [F, 2 C, H, W / 2] channels-last over the same memory."""
+    t = _cl(t)
+    f, c, h, w = t.shape
+    return t.as_strided((f, 2 * c, h, w // 2), (h * w * c, 1, w * c, 2 * c))
+
+
+def _unpair_view(t: torch.Tensor) -> torch.Tensor:
+    f, c2, h, w2 = t.shape
+    return t.as_strided((f, c2 // 2, h, 2 * w2), (h * w2 * c2, 1, w2 * c2, c2 // 2))
+
+
+def pair_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Co, Ci, kt, kh, kw] -> [2 Co, 2 Ci, kt, kh, kw] acting on pixel pairs (output rows a * Co + co, input columns b * Ci + ci):
+    tap dw of output half a is tap dj + 1, input half b with 2 dj + b = a + dw - 1."""
+    co, ci, kt, kh, kw = w.shape
+    w2 = w.new_zeros(2 * co, 2 * ci, kt, kh, kw)
+    if kw == 1:
+        w2[:co, :ci] = w
+        w2[co:, ci:] = w
+        return w2
+    w2[:co, ci:, :, :, 0] = w[..., 0]      # a = 0: dw = 0 -> pair j - 1, half 1
+    w2[:co, :ci, :, :, 1] = w[..., 1]      #        dw = 1 -> pair j, half 0
+    w2[:co, ci:, :, :, 1] = w[..., 2]      #        dw = 2 -> pair j, half 1
+    w2[co:, :ci, :, :, 1] = w[..., 0]      # a = 1: dw = 0 -> pair j, half 0
+    w2[co:, ci:, :, :, 1] = w[..., 1]      #        dw = 1 -> pair j, half 1
+    w2[co:, :ci, :, :, 2] = w[..., 2]      #        dw = 2 -> pair j + 1, half 0
+    return w2
+
+
+def unpair_weight_grad(g2: torch.Tensor, co: int, ci: int) -> torch.Tensor:
+    """Gradient of `pair_weight`: every weight element appears twice."""
+    kw = g2.shape[4]
+    if kw == 1:
+        return g2[:co, :ci] + g2[co:, ci:]
+    return torch.stack((g2[:co, ci:, :, :, 0] + g2[co:, :ci, :, :, 1],
+                        g2[:co, :ci, :, :, 1] + g2[co:, ci:, :, :, 1],
+                        g2[:co, ci:, :, :, 1] + g2[co:, :ci, :, :, 2]), dim=-1)
+
+
+def _dup(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Per-channel terms of a paired tensor: both halves carry the same channels."""
+    return None if t is None else torch.cat((t, t), dim=-1)
+
+
 def _hand_conv_shape_ok(x: torch.Tensor, co: int, ci: int, weight: torch.Tensor, padding_hw) -> bool:
     """Would the hand-written kernel take the DATA GRADIENT of conv(x, weight): a convolution of a [frames, Co, H, W] gradient
     with the mirrored [Ci, Co, ...] weight (decided on shapes: the gradient tensor does not exist yet)."""
@@ -408,6 +471,9 @@ def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw, cl: bool
         return False
     if tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
         return False
+    if _pairable(x, weight):
+        co, ci, kt, kh, kw = weight.shape
+        return conv3d_frames.workgroups(x.shape[0], x.shape[2], x.shape[3] // 2, 2 * ci, 2 * co, kt, kh, kw) >= HAND_CONV_MIN_TILES
     if not conv3d_frames.supported(_cl(x) if cl else x, weight):
         return False
     # tiny layers (the 3x4 frames: 72 tiles on 256 CUs) stay on MIOpen: 173 us vs 138 us measured
@@ -435,6 +501,9 @@ POINTWISE_GEMM = os.environ.get('LVG_POINTWISE_GEMM', '0') == '1'
 # 1x1 (skip) convolutions through the hand-written kernel: forward + data gradient there (no zero-fill / cast helper launches of the
 # library's split-K kernels), weight gradient on the library. Same run, LVG_POINTWISE_HAND=1/0: 43.45 / 43.7 ms per step.
 POINTWISE_HAND = os.environ.get('LVG_POINTWISE_HAND', '1') == '1'
+# their weight gradient as one GEMM over the pixel matrices: measured SLOWER (50.4 vs 44.3 ms per step, gpurun_out/r03_pair_ab.log: the
+# library GEMM on a [Co, pixels] x [pixels, Ci] product with 10^5 .. 10^6 pixels); kept as a switch
+POINTWISE_WGRAD_GEMM = os.environ.get('LVG_POINTWISE_WGRAD_GEMM', '0') == '1'
 
 
 def pointwise_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -466,7 +535,15 @@ class _TapConvEpilogue(torch.autograd.Function):
         plain = pre is None and b is None and res is None and post is None and act == 'linear' and clamp is None
         if not any(ctx.needs_input_grad):
             plain = True                                    # inference: no backward pass will read the saved sum -- do not write it
-        if _hand_conv_takes(x, weight, padding_hw):
+        pair = _pairable(x, weight) and _hand_conv_takes(x, weight, padding_hw)
+        if pair:
+            # pixel pairs (see _pairable): the same launch on views with twice the channels and half the width
+            out, ysum, msq = conv3d_frames.conv3d_frames_forward(_pair_view(x), pair_weight(weight), n, _dup(pre), _dup(b),
+                                                                 None if res is None else _pair_view(res), _dup(post), act=act, clamp=clamp,
+                                                                 want_msq=want_msq, keep_sum=not plain)
+            out = _unpair_view(out)
+            ysum = None if ysum is None else _unpair_view(ysum)
+        elif _hand_conv_takes(x, weight, padding_hw):
             # contraction, temporal sum and epilogue in ONE hand-written MFMA kernel (csrc/conv3d_igemm.hip)
             out, ysum, msq = conv3d_frames.conv3d_frames_forward(_cl(x), weight, n, pre, b, res, post, act=act, clamp=clamp,
                                                                  want_msq=want_msq, keep_sum=not plain)
@@ -478,6 +555,7 @@ class _TapConvEpilogue(torch.autograd.Function):
         ctx.cfg = (n, list(padding_hw), act, clamp)
         ctx.plain = pre is None and b is None and res is None and post is None and act == 'linear' and clamp is None
         ctx.wt = getattr(weight, '_lvg_dgrad', None)        # weight_prep's data-gradient packing of this weight, if it made one
+        ctx.pair = pair
         if want_msq:
             ctx.mark_non_differentiable(msq)
         return out, msq
@@ -487,8 +565,23 @@ class _TapConvEpilogue(torch.autograd.Function):
     def backward(ctx, dout, _dmsq):
         x, weight, ysum, pre, b, res, post = ctx.saved_tensors
         n, pad, act, clamp = ctx.cfg
-        co, ci, kt, kh, kw = weight.shape
         need = ctx.needs_input_grad
+        if ctx.pair:
+            # the whole backward pass on the paired views; gradients of the duplicated per-channel terms fold their two halves
+            co1, ci1 = weight.shape[:2]
+            grads = _TapConvEpilogue._backward(ctx, _pair_view(x), pair_weight(weight), _pair_view(ysum), _dup(pre), _dup(b),
+                                               None if res is None else _pair_view(res), _dup(post), _pair_view(dout), None, need)
+            gx, gw, d_pre, d_b, d_res, d_post = grads
+            fold = lambda t, c: None if t is None else t[..., :c] + t[..., c:]
+            return ((None if gx is None else _unpair_view(gx)), (None if gw is None else unpair_weight_grad(gw, co1, ci1)), fold(d_pre, co1),
+                    fold(d_b, co1), (None if d_res is None else dout), fold(d_post, co1), None, None, None, None, None)
+        grads = _TapConvEpilogue._backward(ctx, x, weight, ysum, pre, b, res, post, dout, ctx.wt, need)
+        return (*grads, None, None, None, None, None)
+
+    @staticmethod
+    def _backward(ctx, x, weight, ysum, pre, b, res, post, dout, wt_packed, need):
+        n, pad, act, clamp = ctx.cfg
+        co, ci, kt, kh, kw = weight.shape
         xc = _cl(x)
         hand_d = need[0] and HAND_CONV_DGRAD and _hand_conv_shape_ok(xc, co, ci, weight, pad)
         hand_w = need[1] and HAND_CONV_WGRAD and _hand_wgrad_shape_ok(xc, co, weight, pad)
@@ -501,13 +594,18 @@ class _TapConvEpilogue(torch.autograd.Function):
         gx = gw = None
         if hand_d:
             # data gradient on the hand-written kernel: the same convolution with the taps mirrored and the channel roles swapped
-            wt = ctx.wt
+            wt = wt_packed
             if wt is not None and tuple(wt.shape) == (kt, kh, kw, ci, co) and wt.dtype == dy.dtype:
                 gx = conv3d_frames.conv3d_frames_forward(dy, wt.permute(3, 4, 0, 1, 2), n, keep_sum=False, packed=wt)[0]
             else:
                 gx = conv3d_frames.conv3d_frames_forward(dy, weight.flip(2, 3, 4).transpose(0, 1), n, keep_sum=False)[0]
         if hand_w:
             gw = conv3d_frames.conv3d_frames_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
+        if stacked and POINTWISE_WGRAD_GEMM and kt == kh == kw == 1 and not (need[0] and not hand_d) and conv3d_frames._pixel_stride(xc) == ci:
+            # weight gradient of a 1 x 1 convolution = one GEMM over the pixel matrices (views of the channels-last tensors): no zero-fill /
+            # cast helper launches of the library's split-K convolution kernels; float32 accumulation, one rounding to the compute dtype
+            gw = torch.matmul(_cl(dy).permute(0, 2, 3, 1).reshape(-1, co).t(), xc.permute(0, 2, 3, 1).reshape(-1, ci)).reshape(co, ci, 1, 1, 1)
+            stacked = False
         if stacked:
             gxm, gwst, _ = torch.ops.aten.convolution_backward(
                 _cl(dz), xc, _cl(stack_taps(weight)), None, [1, 1], pad, [1, 1], False, [0, 0], 1, [need[0] and not hand_d, need[1] and not hand_w, False])
@@ -520,7 +618,7 @@ class _TapConvEpilogue(torch.autograd.Function):
         if res is not None and need[4]:
             assert act == 'linear' and clamp is None and post is None, 'residual gradient: linear epilogue only'
             d_res = dout
-        return gx, gw, (d_pre if need[2] else None), d_b, d_res, (d_post if need[5] else None), None, None, None, None, None
+        return gx, gw, (d_pre if need[2] else None), d_b, d_res, (d_post if need[5] else None)
 
 
 def temporal_conv_epilogue(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw, pre: Optional[torch.Tensor] = None,

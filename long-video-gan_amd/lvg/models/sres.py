@@ -252,6 +252,11 @@ class SynthesisLayer(nn.Module):
         if fused:
             weight, mod, demod = modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=input_gain, low_precision=True)
             x = modconv2d_layout.modulated_conv2d(None if x is None else x.to(dtype), cond.to(dtype), weight, mod, demod, padding=self.conv_kernel - 1)
+        elif dtype == torch.float32 and modconv2d_layout.split_conv_supported(x, self.weight):
+            # float32 3 x 3 layers on the GPU: the contraction on the hand-written MFMA kernels with float32 accuracy (operands split into
+            # float16 high / low parts, float32 accumulation and output: modconv2d_layout._ModConv2dSplit) instead of the library convolution
+            weight, mod, demod = modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=input_gain, low_precision=False)
+            x = modconv2d_layout.modulated_conv2d(x.float(), None, weight, mod, demod, padding=self.conv_kernel - 1)
         else:
             x = modulated_conv2d(x.to(dtype), self.weight, style, demodulate=not self.is_torgb,
                                  padding=self.conv_kernel - 1, input_gain=input_gain)

@@ -51,7 +51,7 @@ _SIGNATURES = {
     'lvg_modconv2d_nhwc_to_nchw': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nchw_to_nhwc_padded': [_vp] * 6 + [_i64] + [_i32] * 11 + [_vp],
     'lvg_conv2d_frames_workgroups': [_i64] + [_i32] * 8,
-    'lvg_conv2d_frames': [_vp] * 4 + [_i64] + [_i32] * 10 + [_i64, _i64, _i32, _vp],
+    'lvg_conv2d_frames': [_vp] * 4 + [_i64] + [_i32] * 10 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_conv2d_frames_wgrad_splits': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames_wgrad': [_vp] * 3 + [_i64] + [_i32] * 8 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],

@@ -72,20 +72,22 @@ def supported(x, wp):
     return x.numel() * 2 < 2 ** 32 and _init()
 
 
-def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None):
+def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None, out_dtype=None):
     """out[n, oy, ox, co] = pre[n, co] * sum x[n, oy + offset[0] + dh, ox + offset[1] + dw, ci] * wp[dh, dw, co, ci].
 
-    x [N, Hi, Wi, Ci], wp [3, 3, Co, Ci] -> out [N, ho, wo, Co] (x's dtype); ho <= Hi - offset[0] - 2, wo <= Wi - offset[1] - 2."""
+    x [N, Hi, Wi, Ci], wp [3, 3, Co, Ci] -> out [N, ho, wo, Co] (x's dtype, or float32 with out_dtype=torch.float32: the accumulators
+    unrounded); ho <= Hi - offset[0] - 2, wo <= Wi - offset[1] - 2."""
+    out_dtype = x.dtype if out_dtype is None else out_dtype
     n, hi, wi, ci = x.shape
     co = wp.shape[2]
     assert ho <= hi - offset[0] - 2 and wo <= wi - offset[1] - 2 and wp.shape == (3, 3, co, ci)
     if x.device.type == 'cuda' and _init():
         assert supported(x, wp), 'conv2d_frames: no hand-written kernel for this shape / dtype / layout'
-        out = torch.empty([n, ho, wo, co], dtype=x.dtype, device=x.device)
+        out = torch.empty([n, ho, wo, co], dtype=out_dtype, device=x.device)
         pre = None if pre is None else pre.float().contiguous()
         with torch.cuda.device(x.device):
             rc = _hip.lib().lvg_conv2d_frames(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), n, hi, wi, ho, wo, ci, co, 3, 3,
-                                              offset[0], offset[1], ci, co, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+                                              offset[0], offset[1], ci, co, _hip.dtype_code(x.dtype), _hip.dtype_code(out_dtype), _hip.stream(x.device))
         _hip.check(rc, 'conv2d_frames')
         stats['flops'] += 2 * n * ho * wo * co * ci * 9
         stats['launches'] += 1
@@ -94,20 +96,40 @@ def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None):
     y = F.conv2d(v, wp.permute(2, 3, 0, 1).float())
     if pre is not None:
         y = y * pre.float()[:, :, None, None]
-    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+    return y.permute(0, 2, 3, 1).contiguous().to(out_dtype)
+
+
+def split16(t, dtype=torch.float16):
+    """float32 tensor -> (high, low) parts in `dtype` with high + low = t to ~2^-22 relative (float16: 11 + 11 mantissa bits).
+    The operand side of a float32-accurate contraction on the 16-bit matrix cores:
+        x . w  ~=  xh . wh + xl . wh + xh . wl        (the dropped xl . wl term is ~2^-22 of the product)
+    run as ONE contraction over three times the channels, [xh | xl | xh] against [wh | wh | wl], with float32 accumulation and
+    float32 output (lvg_conv2d_frames, out_dtype float32). float16 keeps 11 bits per part but has a narrow exponent: the callers
+    keep the operands O(1) (activations, normalised weights) or scale them by a power of two first (gradients)."""
+    hi = t.to(dtype)
+    lo = (t - hi.float()).to(dtype)
+    return hi, lo
+
+
+def pow2_scale(t, target=1024.0):
+    """A power of two s (0-d float32 tensor, computed on the device without synchronising) that brings max |t| to [target / 2, target]."""
+    amax = t.detach().abs().amax().clamp_min(1e-30).float()
+    return torch.exp2(torch.floor(torch.log2(target / amax)))
 
 
 def wgrad_splits(n, hx, wx, hd, wd, ci, co):
     return int(_hip.lib().lvg_conv2d_frames_wgrad_splits(n, hx, wx, hd, wd, ci, co, 3, 3))
 
 
-def conv2d_wgrad(x, dy):
+def conv2d_wgrad(x, dy, x_channels=None, dy_channels=None):
     """gw[dh, dw, co, ci] = sum_{n, a, b} dy[n, a, b, co] * x[n, a + dh, b + dw, ci]  (float32 [3, 3, Co, Ci]).
 
-    x [N, Hx, Wx, Ci], dy [N, Hd, Wd, Co] contiguous with Hd % 4 == 0, Wd % 16 == 0, Hx >= Hd + 2, Wx >= Wd + 2."""
-    n, hx, wx, ci = x.shape
-    n2, hd, wd, co = dy.shape
-    assert n == n2 and hd % PATCH_H == 0 and wd % PATCH_W == 0 and hx >= hd + 2 and wx >= wd + 2
+    x [N, Hx, Wx, Ci], dy [N, Hd, Wd, Co] contiguous with Hd % 4 == 0, Wd % 16 == 0, Hx >= Hd + 2, Wx >= Wd + 2.
+    `x_channels` / `dy_channels`: use only the first so many channels of a pixel (the tensors' channel counts are the pixel strides)."""
+    n, hx, wx, xs = x.shape
+    n2, hd, wd, ds = dy.shape
+    ci, co = (xs if x_channels is None else x_channels), (ds if dy_channels is None else dy_channels)
+    assert n == n2 and hd % PATCH_H == 0 and wd % PATCH_W == 0 and hx >= hd + 2 and wx >= wd + 2 and ci <= xs and co <= ds
     if x.device.type == 'cuda' and _init():
         assert x.dtype in (torch.float16, torch.bfloat16) and dy.dtype == x.dtype and x.is_contiguous() and dy.is_contiguous() and ci % CH == 0 and co % CH == 0, \
             'conv2d_frames_wgrad: no hand-written kernel for this shape / dtype / layout'
@@ -116,14 +138,14 @@ def conv2d_wgrad(x, dy):
         part = torch.empty([splits, 3, 3, co, ci], dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = _hip.lib().lvg_conv2d_frames_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), n, hx, wx, hd, wd, ci, co, 3, 3,
-                                                    ci, co, splits, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+                                                    xs, ds, splits, _hip.dtype_code(x.dtype), _hip.stream(x.device))
         _hip.check(rc, 'conv2d_frames_wgrad')
         stats['flops'] += 2 * n * hd * wd * co * ci * 9
         stats['launches'] += 1
         return part.sum(0) if splits > 1 else part[0]                 # fixed summation order: reproducible
-    xv = x[:, :hd + 2, :wd + 2].permute(0, 3, 1, 2).float()
+    xv = x[:, :hd + 2, :wd + 2, :ci].permute(0, 3, 1, 2).float()
     w0 = torch.zeros(co, ci, 3, 3, dtype=torch.float32, device=x.device, requires_grad=True)
     with torch.enable_grad():
         y = F.conv2d(xv, w0)
-    gw = torch.autograd.grad(y, w0, dy.permute(0, 3, 1, 2).float())[0]
+    gw = torch.autograd.grad(y, w0, dy[..., :co].permute(0, 3, 1, 2).float())[0]
     return gw.permute(2, 3, 0, 1).contiguous()

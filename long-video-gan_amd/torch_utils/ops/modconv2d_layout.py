@@ -221,6 +221,85 @@ class _ModConv2dHand(torch.autograd.Function):
         return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None
 
 
+class _ModConv2dSplit(torch.autograd.Function):
+    """The modulated 3 x 3 convolution of the FLOAT32 layers on the hand-written 16-bit MFMA kernels with float32 accuracy: every
+    operand is split into a float16 high and low part (conv2d_frames.split16) and the three significant partial products run as one
+    contraction over stacked channels, accumulated and stored in float32. The reference runs these layers in float32 with TF32 off
+    (train_sres.py:304-306); the split keeps ~22 mantissa bits per operand. Layout / modulation / splitting are plain tensor ops here
+    (the float32 layers are the three smallest of the network: 38 x 31 pixels)."""
+
+    @staticmethod
+    def forward(ctx, first, second, weight, mod, demod, padding):
+        c2 = conv2d_frames
+        n, c_first, h, w = first.shape
+        co, ci = weight.shape[:2]
+        geo = c2.Geometry(h, w, padding)
+        cip, cop = c2.round_up(ci, c2.CH), c2.round_up(co, c2.CH)
+        xin = (first if second is None else torch.cat((first, second), dim=1)).float() * mod.float()[:, :, None, None]
+        # float16 parts keep 11 bits each only for values within ~2^13 of the tensor's maximum (narrow exponent): bring every operand's
+        # maximum to ~2^10 by an exact power of two, undone on the float32 result
+        sx, sw = c2.pow2_scale(xin), c2.pow2_scale(weight)
+        xh, xl = c2.split16((xin * sx).permute(0, 2, 3, 1))
+        xp = torch.zeros([n, geo.hx, geo.wx, 3 * cip], dtype=torch.float16, device=first.device)      # [xh | xl | xh] per pixel
+        inner = xp[:, 2:2 + h, 2:2 + w]
+        inner[..., :ci], inner[..., cip:cip + ci], inner[..., 2 * cip:2 * cip + ci] = xh, xl, xh
+        wh, wl = c2.split16(weight.float() * sw)
+        wp = torch.cat([c2.pack_weight(t, torch.float16, cip, cop) for t in (wh, wh, wl)], dim=3)       # [3, 3, cop, 3 cip]
+        y = c2.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), out_dtype=torch.float32)     # [n, ho, wo, cop] float32, scaled by sx sw
+        y = y * (1.0 / (sx * sw))
+        yv = y[..., :co].permute(0, 3, 1, 2)
+        out = (yv if demod is None else yv * demod.float()[:, :, None, None]).contiguous()
+        ctx.save_for_backward(first, second, mod, demod, xp, y, weight, sx, sw)
+        ctx.geo = geo
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        c2 = conv2d_frames
+        first, second, mod, demod, xp, y, weight, sx, sw = ctx.saved_tensors
+        geo = ctx.geo
+        assert not ctx.needs_input_grad[1], 'modulated_conv2d: no gradient for the conditioning frames on the fused path'
+        n, c_first = first.shape[:2]
+        co, ci = weight.shape[:2]
+        cip, cop = xp.shape[3] // 3, y.shape[3]
+        d_out = d_out.float()
+        d_demod = None
+        if demod is not None and ctx.needs_input_grad[4]:
+            d_demod = (d_out * y[..., :co].permute(0, 3, 1, 2)).sum(dim=(2, 3))
+        g = d_out if demod is None else d_out * demod.float()[:, :, None, None]
+        # gradients span many octaves and float16 has a narrow exponent: scale by a power of two (exact), undo on the results
+        s = c2.pow2_scale(g)
+        gh, gl = c2.split16((g * s).permute(0, 2, 3, 1))
+        dyp = torch.zeros([n, geo.hd, geo.wd, 3 * cop], dtype=torch.float16, device=first.device)       # [gh | gl | gh] per pixel at (q, q)
+        inner = dyp[:, geo.q:geo.q + geo.ho, geo.q:geo.q + geo.wo]
+        inner[..., :co], inner[..., cop:cop + co], inner[..., 2 * cop:2 * cop + co] = gh, gl, gh
+        d_weight = None
+        if ctx.needs_input_grad[2]:
+            # [xh | xl] against [gh | gl]: the four blocks of the [2 cop, 2 cip] result are the four partial products
+            gw = c2.conv2d_wgrad(xp, dyp, x_channels=2 * cip, dy_channels=2 * cop)
+            gw = gw[:, :, :cop, :cip] + gw[:, :, :cop, cip:] + gw[:, :, cop:, :cip] + gw[:, :, cop:, cip:]
+            d_weight = (gw[:, :, :co, :ci].permute(2, 3, 0, 1) * (1.0 / (s * sx))).to(weight.dtype)
+        d_first = d_mod = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
+            wh, wl = c2.split16(weight.float() * sw)
+            wd = torch.cat([c2.pack_weight_dgrad(t, torch.float16, cip, cop) for t in (wh, wh, wl)], dim=3)   # [3, 3, cip, 3 cop]
+            dx = c2.conv2d_valid(dyp, wd, geo.h, geo.w, out_dtype=torch.float32)[..., :ci].permute(0, 3, 1, 2) * (1.0 / (s * sw))   # d (x * mod), NCHW view
+            if ctx.needs_input_grad[3]:
+                xcat = (first if second is None else torch.cat((first, second), dim=1)).float()
+                d_mod = (dx * xcat).sum(dim=(2, 3))
+            if ctx.needs_input_grad[0]:
+                d_first = (dx[:, :c_first] * mod.float()[:, :c_first, None, None]).to(first.dtype).contiguous()
+        return d_first, None, d_weight, d_mod, d_demod, None
+
+
+SPLIT_F32 = os.environ.get('LVG_SRES_SPLIT_F32', '1') != '0'      # float32 3 x 3 layers on the hand-written kernels through split operands (0: the library convolution)
+
+
+def split_conv_supported(first, weight):
+    return (HAND_CONV and SPLIT_F32 and first.device.type == 'cuda' and first.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3))
+
+
 def hand_conv_supported(first, weight):
     return (HAND_CONV and first.device.type == 'cuda' and first.dtype in (torch.float16, torch.bfloat16) and tuple(weight.shape[2:]) == (3, 3))
 
@@ -234,6 +313,8 @@ def modulated_conv2d(x, cond, weight, mod, demod, padding=0):
     """x [N, C1, H, W] or None, cond [N, C2, H, W] (same dtype), weight [Co, C1 + C2, k, k] (any float dtype),
     mod float32 [N, C1 + C2], demod float32 [N, Co] or None. Returns NCHW [N, Co, H', W'] in x's dtype."""
     first, second = (cond, None) if x is None else (x, cond)
+    if split_conv_supported(first, weight) and 0 <= padding <= 2:
+        return _ModConv2dSplit.apply(first, None if second is None else second.to(first.dtype), weight, mod, demod, padding)
     if not supported(x, cond):
         return _ref(x, cond, weight, mod, demod, padding)
     dtype = first.dtype

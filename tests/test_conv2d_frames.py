@@ -240,3 +240,88 @@ def test_weight_gradient_is_the_adjoint_of_the_forward_full_size_gpu(shape):
     sigma = 2.0 ** -12 * float(terms.square().sum().sqrt())
     record_measured(f'sres_wgrad_adjoint_{ci}x{co}', lhs=lhs, rhs=rhs, diff=abs(lhs - rhs), sigma=sigma)
     assert abs(lhs - rhs) <= 5 * sigma, (lhs, rhs, sigma)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# float32-accurate contraction from split 16-bit operands
+
+def test_split16_keeps_22_bits_cpu():
+    g = torch.Generator().manual_seed(1)
+    t = torch.randn(4096, generator=g) * torch.logspace(-2, 2, 4096)
+    hi, lo = c2.split16(t)
+    err = ((hi.double() + lo.double()) - t.double()).abs()
+    # 11 + 11 mantissa bits (two roundings) while the low part is a normal float16, i.e. |t| >= 2^-3; an absolute 2^-25 below that
+    assert bool((err <= torch.maximum(t.double().abs() * 2.0 ** -21, torch.tensor(2.0 ** -24, dtype=torch.float64))).all())
+    s = c2.pow2_scale(torch.tensor([3e-7, -1.5e-6]))
+    assert float(torch.log2(s)) == float(torch.floor(torch.log2(s))) and 512 <= 1.5e-6 * float(s) <= 1024
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_split_node_plumbing_matches_reference_cpu(name):
+    """The float32 node (split operands, stacked channels) on CPU tensors through the plain-PyTorch composition: output and the three
+    gradients of the reference's modulated_conv2d."""
+    g = load_golden('modconv2d')
+    x, weight, style, gain, dy = inputs(name)
+    n, ci, co, h, w_, k, pad = CASES[name]
+    c_first = ci // 2
+    x, weight, style = x.requires_grad_(True), weight.requires_grad_(True), style.requires_grad_(True)
+    first, second = x[:, :c_first], x[:, c_first:].detach()
+    wn, mod, demod = _torch_modulation(weight, style, gain)
+    y = ml._ModConv2dSplit.apply(first, second, wn, mod, demod, pad)
+    np.testing.assert_allclose(y.detach().numpy(), g[name + '_y'], rtol=2e-4, atol=2e-5)
+    gx, gw, gs = torch.autograd.grad(y, [x, weight, style], dy)
+    np.testing.assert_allclose(gx[:, :c_first].numpy(), g[name + '_gx'][:, :c_first], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gw.numpy(), g[name + '_gw'], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(gs.numpy(), g[name + '_gs'], rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', list(CASES))
+def test_split_node_is_float32_accurate_gpu(oracle, name):
+    """float32 inputs through the split-operand contraction on the 16-bit matrix cores vs the float64 oracle: errors at the float32
+    level (the north-star tolerance is 1e-3; the gate here is 2e-5 of the tensor's scale), forward and all gradients."""
+    x, weight, style, gain, dy = inputs(name)
+    n, ci, co, h, w_, k, pad = CASES[name]
+    xd, wd, sd, dyd = [t.double().numpy() for t in (x, weight, style, dy)]
+    wn, mod, demod = _modulation(wd, sd, float(gain))
+    y_ref = oracle.conv2d(xd * mod[:, :, None, None], wn, padding=pad) * demod[:, :, None, None]
+    gx_ref = oracle.conv2d_dgrad(dyd * demod[:, :, None, None], wn, h, w_, padding=pad) * mod[:, :, None, None]
+    gwn_ref = oracle.conv2d_wgrad(xd * mod[:, :, None, None], dyd * demod[:, :, None, None], 3, 3, padding=pad)
+    first = x.cuda().requires_grad_(True)
+    wt = torch.tensor(wn, dtype=torch.float32, device='cuda').requires_grad_(True)
+    y = ml.modulated_conv2d(first, None, wt, torch.tensor(mod, dtype=torch.float32, device='cuda'), torch.tensor(demod, dtype=torch.float32, device='cuda'), padding=pad)
+    before = c2.stats['launches']
+    gx, gw = torch.autograd.grad(y, [first, wt], dy.cuda() * 1e-4)          # small gradients: exercises the power-of-two scaling
+    assert c2.stats['launches'] - before == 2
+    for got, ref, scale in ((y, y_ref, 1.0), (gx, gx_ref, 1e-4), (gw, gwn_ref, 1e-4)):
+        err = np.abs(got.detach().double().cpu().numpy() - ref * scale).max() / (np.abs(ref).max() * scale)
+        record_measured(f'sres_split_f32_{name}_{tuple(ref.shape)}', rel_max=err)
+        assert err < 2e-5, err
+
+
+@pytest.mark.gpu
+def test_split_node_vs_library_float32_layer_gpu(monkeypatch):
+    """L1 of the generator (539 -> 512 channels, 36 x 29 planes, float32): the split-operand route and the library's float32
+    convolution against float64 on the same operands -- the hand-written route is not further from float64 than the library."""
+    torch.manual_seed(0)
+    n, ci, co, h, w = 2, 539, 512, 29, 36
+    first = torch.randn(n, 512, h, w, device='cuda').requires_grad_(True)
+    second = torch.randn(n, 27, h, w, device='cuda')
+    weight = torch.randn(co, ci, 3, 3, device='cuda').requires_grad_(True)
+    mod = (1 + 0.3 * torch.randn(n, ci, device='cuda')).requires_grad_(True)
+    demod = (0.02 * (0.5 + torch.rand(n, co, device='cuda'))).requires_grad_(True)
+    dy = torch.randn(n, co, h + 2, w + 2, device='cuda') * 1e-3
+
+    def run(flag, dt):
+        monkeypatch.setattr(ml, 'SPLIT_F32', flag)
+        args = [t.detach().to(dt).requires_grad_(True) for t in (first, weight, mod, demod)]
+        y = ml.modulated_conv2d(args[0], second.to(dt), args[1], args[2], args[3], padding=2)
+        return [y.detach().double()] + [t.double() for t in torch.autograd.grad(y, args, dy.to(dt))]
+    truth = run(False, torch.float64)
+    hand, lib = run(True, torch.float32), run(False, torch.float32)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    errs = {}
+    for k_, h_, l_, t_ in zip(('y', 'd_x', 'd_weight', 'd_mod', 'd_demod'), hand, lib, truth):
+        errs[k_ + '_hand'], errs[k_ + '_lib'] = rel(h_, t_), rel(l_, t_)
+        assert errs[k_ + '_hand'] < 2e-5 and errs[k_ + '_hand'] <= 4 * errs[k_ + '_lib'] + 2e-6, (k_, errs)
+    record_measured('sres_L1_split_f32_vs_f64_rel_max', **errs)

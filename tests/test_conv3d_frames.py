@@ -315,3 +315,65 @@ def test_weight_gradient_is_the_adjoint_of_the_forward_full_size_gpu(shape):
         dy, x, weight[:, :, kt // 2].contiguous(memory_format=torch.channels_last), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     centre = gw[:, :, kt // 2]
     assert float((centre - ref.float()).norm() / ref.float().norm()) < 1e-2       # the centre temporal tap is a plain 2-D weight gradient
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pixel pairs: channel counts that are multiples of 32 but not of 64 on the hand-written kernels (lres._pairable)
+
+@pytest.mark.parametrize('k', [3, 1])
+def test_pixel_pair_weight_is_the_same_convolution_cpu(k):
+    """conv(x, w) == unpair(conv(pair(x), pair_weight(w))) with 'same' zero padding, and unpair_weight_grad is the adjoint of pair_weight."""
+    import torch.nn.functional as F
+    from lvg.models import lres
+    g = torch.Generator().manual_seed(21)
+    f, ci, co, h, w = 3, 32, 96, 5, 12
+    x = torch.randn(f, ci, h, w, generator=g).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(co, ci, 1, k, k, generator=g)
+    ref = F.conv2d(x, wt[:, :, 0], padding=k // 2)
+    w2 = lres.pair_weight(wt)
+    y2 = F.conv2d(lres._pair_view(x), w2[:, :, 0], padding=k // 2).contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(lres._unpair_view(y2).numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert float((w2 == 0).float().mean()) >= 0.5 - 1e-6                    # half of the blocks of every tap are structurally zero
+    g2 = torch.randn(w2.shape, generator=g)
+    lhs = float((w2.double() * g2.double()).sum())
+    rhs = float((wt.double() * lres.unpair_weight_grad(g2, co, ci).double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))                      # (the fold adds in float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(32, 32, 3), (32, 64, 3), (32, 64, 1)])
+def test_pixel_pair_layers_match_library_route_gpu(monkeypatch, shape):
+    """The first discriminator block's layers (32 -> 32, 32 -> 64 channels; bf16) through the pixel-pair views on the hand-written
+    kernels against the library route of the same op: forward with the fused epilogue, input / weight / bias gradients."""
+    from lvg.models import lres
+    ci, co, k = shape
+    g = torch.Generator().manual_seed(4)
+    n, t, h, w = 2, 3, 16, 64
+    x0 = torch.randn(t * n, ci, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    wt0 = (torch.randn(co, ci, 1, k, k, generator=g) / math.sqrt(ci * k * k)).to(torch.bfloat16).cuda()
+    b0 = (0.3 * torch.randn(co, generator=g)).to(torch.bfloat16).cuda()
+    dy = torch.randn(t * n, co, h, w, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    monkeypatch.setattr(lres, 'HAND_CONV_MIN_TILES', 1)
+
+    def run(flag, dtype=torch.bfloat16):
+        monkeypatch.setattr(lres, 'HAND_PAIR', flag)
+        x, wt, b = x0.to(dtype).requires_grad_(True), wt0.to(dtype).requires_grad_(True), b0.to(dtype).requires_grad_(True)
+        before = cf.stats['launches']
+        if k == 1:
+            y = lres.pointwise_conv(x, wt)
+        else:
+            y = lres.temporal_conv_epilogue(x, wt, n, (1, 1), b=b, act='lrelu', clamp=256.0)
+        grads = torch.autograd.grad(y, [x, wt] + ([b] if k == 3 else []), dy.to(dtype))
+        return cf.stats['launches'] - before, [y.detach().float()] + [t_.float() for t_ in grads]
+    launches, hand = run(True)
+    assert launches >= 2                                                    # forward + data gradient ran on the hand-written kernel
+    launches0, lib = run(False)
+    assert launches0 == 0
+    _, truth = run(False, torch.float32)                                    # the same bf16-rounded operands in float32 arithmetic
+    rel = lambda a, b_: float((a - b_).norm() / b_.norm().clamp_min(1e-12))
+    # Both 16-bit routes differ from float32 mostly through leaky-ReLU sign flips of pre-activations within one bf16 rounding of zero
+    # (~0.2 % of the elements, a factor 5 in the gradient each): the hand-written route may not be further from float32 than the library
+    # route (beyond noise), and both stay inside the bf16 band.
+    for i, (h_, l_, t_) in enumerate(zip(hand, lib, truth)):
+        eh, el = rel(h_, t_), rel(l_, t_)
+        assert eh <= 1.25 * el + 2e-3 and eh < 3e-2, (i, eh, el)
