@@ -40,6 +40,7 @@ from .lres import FullyConnectedLayer, _linear_filter
 
 # 16-bit layers of the generator: dense convolution on channels-last (MFMA implicit-GEMM) kernels between the fused
 # prologue / epilogue of torch_utils.ops.modconv2d_layout. LVG_SRES_CHANNELS_LAST=0 keeps the NCHW convolution.
+SIDE_STREAM_TERMS = os.environ.get('LVG_SRES_SIDE_STREAM_TERMS', '1') == '1'     # weight / style side of the generator layers on a second stream
 CHANNELS_LAST = os.environ.get('LVG_SRES_CHANNELS_LAST', '1') == '1'
 
 SQRT_HALF = math.sqrt(0.5)
@@ -218,11 +219,32 @@ class SynthesisLayer(nn.Module):
         hi = total - lo
         self.padding = [int(lo[0]), int(hi[0]), int(lo[1]), int(hi[1])]
 
+    def hand_path(self, device: torch.device, force_fp32: bool = False) -> Optional[str]:
+        """Which hand-written route this layer's modulated convolution takes on `device`: 'fused16' (16-bit layers: layout prologue /
+        epilogue around the 2-D implicit-GEMM kernels), 'split32' (float32 3 x 3 layers: split operands on the same kernels), or None."""
+        if device.type != 'cuda':
+            return None
+        low_precision = self.use_fp16 and not force_fp32
+        if low_precision and CHANNELS_LAST and self.compute_dtype in (torch.float16, torch.bfloat16):
+            return 'fused16'
+        if not low_precision and self.conv_kernel == 3 and modconv2d_layout.HAND_CONV and modconv2d_layout.SPLIT_F32:
+            return 'split32'
+        return None
+
+    def terms(self, w: torch.Tensor, low_precision: bool):
+        """Everything of the modulated convolution that does not depend on the activations (weight normalisation, style, demodulation;
+        modulation_terms2d without the input gain): SynthesisNetwork issues it for all layers ahead of time on a second stream."""
+        style = self.affine(w)
+        if self.is_torgb:
+            style = style * (1 / math.sqrt(self.in_channels * self.conv_kernel ** 2))
+        return modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=None, low_precision=low_precision)
+
     def forward(self, x: Optional[torch.Tensor], w: torch.Tensor, force_fp32: bool = False, update_emas: bool = False,
-                cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cond: Optional[torch.Tensor] = None, terms=None) -> torch.Tensor:
         """x: the layer input [N, in_channels, H, W] as in the reference (previous output and conditioning frames
         concatenated), or -- with `cond` given -- the previous layer's output alone (None for the first layer): the
-        concatenation then happens inside the fused prologue of the channels-last path."""
+        concatenation then happens inside the fused prologue of the channels-last path. `terms`: this layer's `terms(...)`
+        computed ahead of time (else computed here)."""
         low_precision = self.use_fp16 and not force_fp32 and (cond if x is None else x).device.type == 'cuda'
         dtype = self.compute_dtype if low_precision else torch.float32
         fused = cond is not None and low_precision and CHANNELS_LAST and dtype in (torch.float16, torch.bfloat16)
@@ -246,18 +268,18 @@ class SynthesisLayer(nn.Module):
             self.magnitude_ema.copy_(mag.lerp(self.magnitude_ema, self.magnitude_ema_beta))
         input_gain = self.magnitude_ema.rsqrt()
 
-        style = self.affine(w)
-        if self.is_torgb:
-            style = style * (1 / math.sqrt(self.in_channels * self.conv_kernel ** 2))
         if fused:
-            weight, mod, demod = modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=input_gain, low_precision=True)
-            x = modconv2d_layout.modulated_conv2d(None if x is None else x.to(dtype), cond.to(dtype), weight, mod, demod, padding=self.conv_kernel - 1)
+            weight, mod, demod = terms if terms is not None else self.terms(w, low_precision=True)
+            x = modconv2d_layout.modulated_conv2d(None if x is None else x.to(dtype), cond.to(dtype), weight, mod * input_gain, demod, padding=self.conv_kernel - 1)
         elif dtype == torch.float32 and modconv2d_layout.split_conv_supported(x, self.weight):
             # float32 3 x 3 layers on the GPU: the contraction on the hand-written MFMA kernels with float32 accuracy (operands split into
             # float16 high / low parts, float32 accumulation and output: modconv2d_layout._ModConv2dSplit) instead of the library convolution
-            weight, mod, demod = modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=input_gain, low_precision=False)
-            x = modconv2d_layout.modulated_conv2d(x.float(), None, weight, mod, demod, padding=self.conv_kernel - 1)
+            weight, mod, demod = terms if terms is not None else self.terms(w, low_precision=False)
+            x = modconv2d_layout.modulated_conv2d(x.float(), None, weight, mod * input_gain, demod, padding=self.conv_kernel - 1)
         else:
+            style = self.affine(w)
+            if self.is_torgb:
+                style = style * (1 / math.sqrt(self.in_channels * self.conv_kernel ** 2))
             x = modulated_conv2d(x.to(dtype), self.weight, style, demodulate=not self.is_torgb,
                                  padding=self.conv_kernel - 1, input_gain=input_gain)
         if not x.is_contiguous():          # a 1x1 conv may hand back channels-last strides; the fused kernel tiles NCHW planes
@@ -330,12 +352,48 @@ class SynthesisNetwork(nn.Module):
     def layers(self) -> List[SynthesisLayer]:
         return [getattr(self, name) for name in self.layer_names]
 
+    def _terms_ahead(self, ws, device: torch.device, force_fp32: bool):
+        """Issue the weight / style side of every layer on a hand-written route (SynthesisLayer.terms: ~10 small launches per layer
+        forward, twice that backward, on 10 MB weight tensors) on a SECOND stream ahead of the layers: it does not depend on the
+        activations, so it runs beside the convolutions instead of between them (autograd replays the backward of these nodes on the
+        same stream). Returns get(i): the terms of layer i with the current stream waiting for them, or None."""
+        if not (SIDE_STREAM_TERMS and device.type == 'cuda'):
+            return lambda i: None
+        main = torch.cuda.current_stream(device)
+        side = getattr(self, '_terms_stream', None)
+        if side is None or side.device != device:
+            side = self._terms_stream = torch.cuda.Stream(device)
+        side.wait_stream(main)
+        ready = []
+        with torch.cuda.stream(side):
+            for layer, w in zip(self.layers(), ws):
+                path = layer.hand_path(device, force_fp32)
+                if path is None:
+                    ready.append(None)
+                    continue
+                out = layer.terms(w, low_precision=(path == 'fused16'))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ready.append((out, ev))
+
+        def get(i):
+            if ready[i] is None:
+                return None
+            out, ev = ready[i]
+            main.wait_event(ev)
+            for tensor in out:
+                if tensor is not None:
+                    tensor.record_stream(main)
+            return out
+        return get
+
     def forward(self, ws: torch.Tensor, conds: List[torch.Tensor], **layer_kwargs) -> torch.Tensor:
         assert ws.shape[1:] == (self.num_ws, self.w_dim)
         ws = ws.float().unbind(dim=1)
         x = self.input(ws[0].size(0)) if self.fourfeats else None
-        for layer, w, cond in zip(self.layers(), ws, conds):
-            x = layer(x, w, cond=cond, **layer_kwargs)
+        ahead = self._terms_ahead(ws, conds[0].device, bool(layer_kwargs.get('force_fp32', False)))
+        for i, (layer, w, cond) in enumerate(zip(self.layers(), ws, conds)):
+            x = layer(x, w, cond=cond, terms=ahead(i), **layer_kwargs)
         if self.output_scale != 1:
             x = x * self.output_scale
         return x.float()
