@@ -122,6 +122,14 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { st
 #define LVG_CONV2D_STATIC 1
 #endif
 constexpr bool kStaticTaps = LVG_CONV2D_STATIC != 0;   // T2D: K loop unrolled over the 9 taps of a band with compile-time tap geometry (0: the generic loop; A/B builds)
+#ifndef LVG_CONV3D_STATIC
+#define LVG_CONV3D_STATIC 1
+#endif
+constexpr bool kStatic3D = LVG_CONV3D_STATIC != 0;     // time-major kernel, 3 x 3 spatial taps: the same unrolled K loop (masks kept); 0: the generic loop (A/B builds)
+#ifndef LVG_CONV3D_STATIC_BN64
+#define LVG_CONV3D_STATIC_BN64 0
+#endif
+constexpr bool kStatic3DBn64 = LVG_CONV3D_STATIC_BN64 != 0;   // ... also on the 64-channel tiles (costs them registers: 116 -> 236, i.e. resident workgroups)
 #ifndef LVG_CONV2D_SPREAD
 #define LVG_CONV2D_SPREAD 0
 #endif
@@ -607,6 +615,155 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
                     __syncthreads();
                     curB ^= (uint32_t)bBytes;
                 });
+            }
+        }
+    }
+    else if (!T2D && kStatic3D && (BN == 128 || kStatic3DBn64) && NB == 2 && split && p.kh == 3 && p.kw == 3 && nAI <= NWA * 9 * ((BN == 128 || BM == 256) ? 3 : 4))
+    {
+        // ---- time-major frames, 3 x 3 spatial taps (any number of temporal taps): the static-tap loop of the 2-D kernel with the 'same'
+        // padding masks kept. Per (tap, pixel block) the band row and its swizzle phase are precomputed as ONE address word; a K-step
+        // selects between it (+ the band's offset) and the zero page by one bit test. The band waves keep the lane offsets of their
+        // pieces in registers (rebuilt when the temporal tap changes: the band of tap dt is the band shifted by whole frames).
+        // band pieces per band wave and K-step: at most SLOTS (3 where the accumulators leave fewer registers: frames up to 64 pixels wide
+        // need 25 pieces per band wave there, 33 on the 64-channel tiles)
+        constexpr int NTAP = 9, SLOTS = (BN == 128 || BM == 256) ? 3 : 4;
+        const int Wd = p.W;
+        uint32_t xA0[NTAP][PB];
+        #pragma unroll
+        for (int t = 0; t < NTAP; t++)
+            #pragma unroll
+            for (int pb = 0; pb < PB; pb++)
+            {
+                const uint32_t rb = (uint32_t)(jrow[pb] + (t / 3) * Wd + (t % 3));
+                xA0[t][pb] = (rb << 7) + (((uint32_t)hi ^ ((rb >> 1) & 7u)) << 4);       // row address + chunk of sub-step 0 (sub-step ks: ^ ks << 5)
+            }
+        uint32_t tm[PB];                                                       // this band's mask word: the spatial bits where the temporal tap is valid, else 0
+        auto set_tm = [&]() __attribute__((always_inline))
+        {
+            #pragma unroll
+            for (int pb = 0; pb < PB; pb++) tm[pb] = ((vmask[pb] >> tbit) & 1u) ? vmask[pb] : 0u;
+        };
+        auto mma_step3 = [&](auto tapc, uint32_t bandOff, uint32_t wOff) __attribute__((always_inline))
+        {
+            constexpr int TAP = decltype(tapc)::value;
+            uint32_t xB[PB];
+            #pragma unroll
+            for (int pb = 0; pb < PB; pb++)
+                xB[pb] = (tm[pb] & (1u << TAP)) ? xA0[TAP][pb] + bandOff : (xA0[TAP][pb] & 0xffu);     // masked lanes: zero page, same bank position
+            uint4 wf[2][NCB], xf[2][PB];
+            auto fetch = [&](int ks, int set) __attribute__((always_inline))
+            {
+                #pragma unroll
+                for (int cb = 0; cb < NCB; cb++)
+                    wf[set][cb] = *reinterpret_cast<const uint4*>(smem + (wAddr[cb][ks] + wOff));
+                #pragma unroll
+                for (int pb = 0; pb < PB; pb++)
+                    xf[set][pb] = *reinterpret_cast<const uint4*>(smem + (xB[pb] ^ (uint32_t)(ks << 5)));
+            };
+            if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(1);
+            fetch(0, 0);
+            #pragma unroll
+            for (int ks = 0; ks < kBK / 16; ks++)
+            {
+                if (ks + 1 < kBK / 16) fetch(ks + 1, (ks + 1) & 1);
+                #pragma unroll
+                for (int pb = 0; pb < PB; pb++)
+                    #pragma unroll
+                    for (int cb = 0; cb < NCB; cb++)
+                        acc[cb][pb] = Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
+            }
+            if constexpr (kPinOrder)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
+                #pragma unroll
+                for (int ks = 0; ks < kBK / 16 - 1; ks++)
+                {
+                    __builtin_amdgcn_sched_group_barrier(0x100, NCB + PB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x8, NCB * PB, 0);
+            }
+            if constexpr (kPrio == 1) __builtin_amdgcn_s_setprio(0);
+        };
+        const uint32_t ldsB0 = ldsBase + bOff;
+        if (isB)
+        {
+            for (macro = 0; macro < nMacro; macro++)
+            {
+                const uint32_t bandOff = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
+                const bool more = macro + 1 < nMacro;
+                set_tm();
+                static_for<NTAP>([&](auto tapc) __attribute__((always_inline))
+                {
+                    constexpr int TAP = decltype(tapc)::value;
+                    const uint32_t stageOff = curB ^ (uint32_t)bBytes;
+                    #pragma unroll
+                    for (int i = 0; i < NBI; i++)
+                        dma16(wNext, bLaneOff[i], ldsB0 + stageOff + bPiece[i] * 1024);
+                    if constexpr (TAP == NTAP - 2)
+                    {
+                        if (more) wMacro += (kc + 1 == nchunk) ? macroJump : (uint64_t)kRowBytes;
+                        wNext = wMacro;
+                    }
+                    else wNext += tapStride;
+                    mma_step3(tapc, bandOff, curB);
+                    wait_vm_const<0>();
+                    __syncthreads();
+                    curB ^= (uint32_t)bBytes;
+                });
+                if (++kc == nchunk) { kc = 0; dt++; tbit++; }
+            }
+        }
+        else
+        {
+            const int wsub = NWA == 1 ? 0 : wave - NWB;
+            const int npw = (nAI + NWA - 1) / NWA;                               // pieces of a band per band wave
+            const int per = (npw + NTAP - 1) / NTAP;                             // ... per K-step (<= SLOTS)
+            const int last = (int)p.M - 1;
+            uint32_t aLane[NTAP * SLOTS];                                        // slot TAP * SLOTS + i: lane offset of piece ((TAP * per + i) * NWA + wsub) of the band of `tabDt`
+            int tabDt = -1;
+            auto build = [&](int bdt) __attribute__((always_inline))
+            {
+                const int g0 = (int)(m0 - p.reach + (int64_t)(bdt - pt) * p.tShift);
+                #pragma unroll
+                for (int sl = 0; sl < NTAP * SLOTS; sl++)
+                {
+                    const int piece = ((sl / SLOTS) * per + (sl % SLOTS)) * NWA + wsub;
+                    int g = g0 + piece * 8 + (lane >> 3);
+                    g = g < 0 ? 0 : (g > last ? last : g);
+                    const uint32_t chunk = aChunkOff ^ (uint32_t)(((piece * 8 + (lane >> 3)) >> 1) & 7);
+                    aLane[sl] = (uint32_t)g * xRowStride + chunk * 16;
+                }
+                tabDt = bdt;
+            };
+            for (macro = 0; macro < nMacro; macro++)
+            {
+                const uint32_t bandOff = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
+                const bool more = macro + 1 < nMacro;
+                const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;
+                const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
+                if (more && mdt != tabDt) build(mdt);
+                const unsigned char* const xNext = xb + (uint32_t)mkc * kRowBytes;
+                const uint32_t nextLds = ldsBase + (uint32_t)aOff + (uint32_t)(((macro + 1) & 1) * aBytes) + (uint32_t)(wsub * 1024);
+                set_tm();
+                static_for<NTAP>([&](auto tapc) __attribute__((always_inline))
+                {
+                    constexpr int TAP = decltype(tapc)::value;
+                    if (more)
+                    {
+                        #pragma unroll
+                        for (int i = 0; i < SLOTS; i++)
+                        {
+                            const int q = (TAP * per + i) * NWA + wsub;
+                            if (i < per && q < nAI) dma16(xNext, aLane[TAP * SLOTS + i], nextLds + (uint32_t)((TAP * per + i) * NWA * 1024));
+                        }
+                    }
+                    mma_step3(tapc, bandOff, curB);
+                    if constexpr (TAP == NTAP - 1) wait_vm_const<0>();
+                    __syncthreads();
+                    curB ^= (uint32_t)bBytes;
+                });
+                if (++kc == nchunk) { kc = 0; dt++; tbit++; }
             }
         }
     }
