@@ -133,12 +133,14 @@ class OpTimer:
         wrap(conv3d_frames, 'conv3d_frames_wgrad', lambda a: 'conv3d_wgrad',
              lambda args, out, kw: 2 * args[0].shape[0] * args[0].shape[2] * args[0].shape[3] * args[0].shape[1] * args[1].shape[1] * args[2] * args[3] * args[4])
         # conv2d_frames.conv2d_valid(x [N,Hi,Wi,Ci], wp [3,3,Co,Ci], ho, wo, ...): the 2-D implicit-GEMM convolution of the sres generator
-        # (forward and data-gradient launches); conv2d_wgrad(x, dy): its weight gradient. FLOPs as launched (channels padded to 64).
+        # (forward and data-gradient launches); conv2d_wgrad(x, dy): its weight gradient. ALGORITHMIC FLOPs (true channel counts and
+        # output size, handed over by the caller as `alg_flops`; the launches themselves work on channels zero-padded to multiples of 64,
+        # gradient frames padded to whole patches and -- float32 layers -- three partial products).
         from torch_utils.ops import conv2d_frames
         wrap(conv2d_frames, 'conv2d_valid', lambda a: 'conv2d_igemm',
-             lambda args, out, kw: 2 * args[0].shape[0] * args[2] * args[3] * args[1].shape[2] * args[1].shape[3] * 9)
+             lambda args, out, kw: kw.get('alg_flops') or 2 * args[0].shape[0] * args[2] * args[3] * args[1].shape[2] * args[1].shape[3] * 9)
         wrap(conv2d_frames, 'conv2d_wgrad', lambda a: 'conv2d_wgrad',
-             lambda args, out, kw: 2 * args[1].shape[0] * args[1].shape[1] * args[1].shape[2] * args[1].shape[3] * args[0].shape[3] * 9)
+             lambda args, out, kw: kw.get('alg_flops') or 2 * args[1].shape[0] * args[1].shape[1] * args[1].shape[2] * args[1].shape[3] * args[0].shape[3] * 9)
         self.flop_ops = {'conv3d_igemm', 'conv3d_igemm_1x1', 'conv3d_wgrad', 'conv2d_igemm', 'conv2d_wgrad'}
 
     def measure(self, reps=3):

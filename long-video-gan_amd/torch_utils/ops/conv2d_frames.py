@@ -72,11 +72,12 @@ def supported(x, wp):
     return x.numel() * 2 < 2 ** 32 and _init()
 
 
-def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None, out_dtype=None):
+def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None, out_dtype=None, alg_flops=None):
     """out[n, oy, ox, co] = pre[n, co] * sum x[n, oy + offset[0] + dh, ox + offset[1] + dw, ci] * wp[dh, dw, co, ci].
 
     x [N, Hi, Wi, Ci], wp [3, 3, Co, Ci] -> out [N, ho, wo, Co] (x's dtype, or float32 with out_dtype=torch.float32: the accumulators
-    unrounded); ho <= Hi - offset[0] - 2, wo <= Wi - offset[1] - 2."""
+    unrounded); ho <= Hi - offset[0] - 2, wo <= Wi - offset[1] - 2. `alg_flops`: the algorithmic work of the call (true channel counts:
+    the tensors here are zero-padded to multiples of 64), for the measurement tally; default = the work as launched."""
     out_dtype = x.dtype if out_dtype is None else out_dtype
     n, hi, wi, ci = x.shape
     co = wp.shape[2]
@@ -89,7 +90,7 @@ def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None, out_dtype=None):
             rc = _hip.lib().lvg_conv2d_frames(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), n, hi, wi, ho, wo, ci, co, 3, 3,
                                               offset[0], offset[1], ci, co, _hip.dtype_code(x.dtype), _hip.dtype_code(out_dtype), _hip.stream(x.device))
         _hip.check(rc, 'conv2d_frames')
-        stats['flops'] += 2 * n * ho * wo * co * ci * 9
+        stats['flops'] += 2 * n * ho * wo * co * ci * 9 if alg_flops is None else alg_flops
         stats['launches'] += 1
         return out
     v = x[:, offset[0]:offset[0] + ho + 2, offset[1]:offset[1] + wo + 2].permute(0, 3, 1, 2).float()
@@ -121,7 +122,7 @@ def wgrad_splits(n, hx, wx, hd, wd, ci, co):
     return int(_hip.lib().lvg_conv2d_frames_wgrad_splits(n, hx, wx, hd, wd, ci, co, 3, 3))
 
 
-def conv2d_wgrad(x, dy, x_channels=None, dy_channels=None):
+def conv2d_wgrad(x, dy, x_channels=None, dy_channels=None, alg_flops=None):
     """gw[dh, dw, co, ci] = sum_{n, a, b} dy[n, a, b, co] * x[n, a + dh, b + dw, ci]  (float32 [3, 3, Co, Ci]).
 
     x [N, Hx, Wx, Ci], dy [N, Hd, Wd, Co] contiguous with Hd % 4 == 0, Wd % 16 == 0, Hx >= Hd + 2, Wx >= Wd + 2.
@@ -140,7 +141,7 @@ def conv2d_wgrad(x, dy, x_channels=None, dy_channels=None):
             rc = _hip.lib().lvg_conv2d_frames_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), n, hx, wx, hd, wd, ci, co, 3, 3,
                                                     xs, ds, splits, _hip.dtype_code(x.dtype), _hip.stream(x.device))
         _hip.check(rc, 'conv2d_frames_wgrad')
-        stats['flops'] += 2 * n * hd * wd * co * ci * 9
+        stats['flops'] += 2 * n * hd * wd * co * ci * 9 if alg_flops is None else alg_flops
         stats['launches'] += 1
         return part.sum(0) if splits > 1 else part[0]                 # fixed summation order: reproducible
     xv = x[:, :hd + 2, :wd + 2, :ci].permute(0, 3, 1, 2).float()

@@ -189,10 +189,11 @@ class _ModConv2dHand(torch.autograd.Function):
         ci_pad, co_pad = conv2d_frames.round_up(ci, conv2d_frames.CH), conv2d_frames.round_up(co, conv2d_frames.CH)
         xp = torch.zeros([n, geo.hx, geo.wx, ci_pad], dtype=first.dtype, device=first.device)
         _nchw_to_nhwc_padded(first, second, mod, xp, (2, 2))
-        y = conv2d_frames.conv2d_valid(xp, conv2d_frames.pack_weight(weight, first.dtype, ci_pad, co_pad), geo.ho, geo.wo, offset=(geo.q, geo.q))
+        alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work of each of the three contractions
+        y = conv2d_frames.conv2d_valid(xp, conv2d_frames.pack_weight(weight, first.dtype, ci_pad, co_pad), geo.ho, geo.wo, offset=(geo.q, geo.q), alg_flops=alg)
         out, _ = _frames_to_nchw(y, demod, co)
         ctx.save_for_backward(first, second, mod, demod, xp, y, weight)
-        ctx.geo = geo
+        ctx.geo, ctx.alg = geo, alg
         return out
 
     @staticmethod
@@ -211,11 +212,11 @@ class _ModConv2dHand(torch.autograd.Function):
         d_demod = partial.sum(dim=1) if need_demod else None
         d_weight = None
         if need_weight:
-            gw = conv2d_frames.conv2d_wgrad(xp, dyp)                                   # [3, 3, co_pad, ci_pad] float32
+            gw = conv2d_frames.conv2d_wgrad(xp, dyp, alg_flops=ctx.alg)                # [3, 3, co_pad, ci_pad] float32
             d_weight = gw[:, :, :co, :ci].permute(2, 3, 0, 1).to(weight.dtype)
         d_first = d_mod = None
         if need_first or need_mod:
-            dxp = conv2d_frames.conv2d_valid(dyp, conv2d_frames.pack_weight_dgrad(weight, first.dtype, ci_pad, co_pad), geo.h, geo.w)
+            dxp = conv2d_frames.conv2d_valid(dyp, conv2d_frames.pack_weight_dgrad(weight, first.dtype, ci_pad, co_pad), geo.h, geo.w, alg_flops=ctx.alg)
             d_first, partial = _frames_to_nchw(dxp, mod[:, :c_first].contiguous(), c_first, oth_a=first if need_mod else None, oth_b=second if need_mod else None)
             d_mod = partial.sum(dim=1) if need_mod else None
         return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None
@@ -245,12 +246,13 @@ class _ModConv2dSplit(torch.autograd.Function):
         inner[..., :ci], inner[..., cip:cip + ci], inner[..., 2 * cip:2 * cip + ci] = xh, xl, xh
         wh, wl = c2.split16(weight.float() * sw)
         wp = torch.cat([c2.pack_weight(t, torch.float16, cip, cop) for t in (wh, wh, wl)], dim=3)       # [3, 3, cop, 3 cip]
-        y = c2.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), out_dtype=torch.float32)     # [n, ho, wo, cop] float32, scaled by sx sw
+        alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work (the three partial products are this implementation's cost, not the operation's)
+        y = c2.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), out_dtype=torch.float32, alg_flops=alg)     # [n, ho, wo, cop] float32, scaled by sx sw
         y = y * (1.0 / (sx * sw))
         yv = y[..., :co].permute(0, 3, 1, 2)
         out = (yv if demod is None else yv * demod.float()[:, :, None, None]).contiguous()
         ctx.save_for_backward(first, second, mod, demod, xp, y, weight, sx, sw)
-        ctx.geo = geo
+        ctx.geo, ctx.alg = geo, alg
         return out
 
     @staticmethod
@@ -277,14 +279,14 @@ class _ModConv2dSplit(torch.autograd.Function):
         d_weight = None
         if ctx.needs_input_grad[2]:
             # [xh | xl] against [gh | gl]: the four blocks of the [2 cop, 2 cip] result are the four partial products
-            gw = c2.conv2d_wgrad(xp, dyp, x_channels=2 * cip, dy_channels=2 * cop)
+            gw = c2.conv2d_wgrad(xp, dyp, x_channels=2 * cip, dy_channels=2 * cop, alg_flops=ctx.alg)
             gw = gw[:, :, :cop, :cip] + gw[:, :, :cop, cip:] + gw[:, :, cop:, :cip] + gw[:, :, cop:, cip:]
             d_weight = (gw[:, :, :co, :ci].permute(2, 3, 0, 1) * (1.0 / (s * sx))).to(weight.dtype)
         d_first = d_mod = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
             wh, wl = c2.split16(weight.float() * sw)
             wd = torch.cat([c2.pack_weight_dgrad(t, torch.float16, cip, cop) for t in (wh, wh, wl)], dim=3)   # [3, 3, cip, 3 cop]
-            dx = c2.conv2d_valid(dyp, wd, geo.h, geo.w, out_dtype=torch.float32)[..., :ci].permute(0, 3, 1, 2) * (1.0 / (s * sw))   # d (x * mod), NCHW view
+            dx = c2.conv2d_valid(dyp, wd, geo.h, geo.w, out_dtype=torch.float32, alg_flops=ctx.alg)[..., :ci].permute(0, 3, 1, 2) * (1.0 / (s * sw))   # d (x * mod), NCHW view
             if ctx.needs_input_grad[3]:
                 xcat = (first if second is None else torch.cat((first, second), dim=1)).float()
                 d_mod = (dx * xcat).sum(dim=(2, 3))
