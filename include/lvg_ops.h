@@ -226,6 +226,15 @@ int lvg_tapconv_epilogue_slots(int64_t frames, int channels, int pixels, int dty
  * Returns LVG_ERR_UNSUPPORTED when no kernel exists for the shape (ci % 64, co % 64, kt <= 7, kh * kw <= 25, odd kernel
  * sizes, frames*h*w < 2^31): the caller then takes the library convolution + lvg_tapconv_epilogue.
  */
+/* lvg_conv3d_frames with a choice of output type: out_dtype = dtype (the call below), or LVG_F32 -- out, ysum, b and res are then float32
+ * tensors and the float32 accumulators are stored unrounded: the output side of a float32-accurate contraction from operands split into
+ * 16-bit high / low parts stacked along ci (long-video-gan_amd/torch_utils/ops/conv3d_frames.py, `split32`). The reference runs these
+ * convolutions in float32 with TF32 off (train_lres.py:267-269). lvg_conv3d_frames_workgroups_f32out: its workgroup count. */
+int lvg_conv3d_frames_ex(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
+                         void* out, void* ysum, float* msq_partial,
+                         int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
+                         int64_t x_pixel_stride, int dtype, int out_dtype, int act, float alpha, float gain, float clamp, void* stream);
+int64_t lvg_conv3d_frames_workgroups_f32out(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw);
 int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
                       void* out, void* ysum, float* msq_partial,
                       int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,

@@ -63,7 +63,7 @@ int env_int(const char* name, int dflt)
 // workgroups de-synchronise their barriers; 256-pixel tiles on 8 waves ran 20 % slower there). Wide frames
 // (W >= 32: the halo is half a 128-pixel tile) with >= 128 output channels take 256-pixel tiles.
 // LVG_CONV_BM / _BN / _NB override (A/B measurements).
-int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl)
+int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl, bool outF32 = false)
 {
     const int reach = (kh / 2) * W + kw / 2;
     const int ntap = kh * kw;
@@ -85,6 +85,7 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
     if (fbm == 128 || fbm == 256) bm = fbm;
     int nb = 2;
     if (fnb == 2 || fnb == 3) nb = fnb;
+    if (outF32) { bm = 128; nb = 2; }                                  // (the float32-output instantiations)
     fill(bm, bn, nb);
     if (pl.ldsBytes > 160 * 1024 && nb == 3) fill(bm, bn, 2);
     if (pl.ldsBytes > 160 * 1024 && bm == 256) fill(128, bn, 2);
@@ -103,10 +104,10 @@ bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int 
     return xstride >= ci && xstride % 8 == 0 && (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * xstride * 2 < ((int64_t)1 << 32);
 }
 
-template <class T, int BM, int BN, int PB, int NB>
+template <class T, int BM, int BN, int PB, int NB, bool OUTF = false>
 int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB, false, OUTF>;
     if (pl.ldsBytes > 64 * 1024)
     {
         // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
@@ -129,6 +130,13 @@ int launch_ring(const ConvArgs& a, const Plan& pl, hipStream_t s)
     return pl.bn == 128 ? launch<T, 128, 128, 2, NB>(a, pl, s) : launch<T, 128, 64, 2, NB>(a, pl, s);
 }
 
+// float32 output (the float32-accurate contraction from split operands): 128-pixel tiles, ring of 2 only
+template <class T>
+int launch_f32out(const ConvArgs& a, const Plan& pl, hipStream_t s)
+{
+    return pl.bn == 128 ? launch<T, 128, 128, 2, 2, true>(a, pl, s) : launch<T, 128, 64, 2, 2, true>(a, pl, s);
+}
+
 template <class T>
 int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
 {
@@ -146,12 +154,36 @@ extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, in
     return pl.mTiles * (co / pl.bn);
 }
 
+// ... of lvg_conv3d_frames_ex with out_dtype = LVG_F32
+extern "C" int64_t lvg_conv3d_frames_workgroups_f32out(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
+{
+    Plan pl;
+    if (frames <= 0 || h <= 0 || w <= 0 || !shape_ok(frames, h, w, ci, co, kt, kh, kw, ci)) return 0;
+    if (make_plan(frames * h * w, w, ci, co, kt, kh, kw, pl, true) != 0) return 0;
+    return pl.mTiles * (co / pl.bn);
+}
+
+extern "C" int lvg_conv3d_frames_ex(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
+                                    void* out, void* ysum, float* msq_partial,
+                                    int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
+                                    int64_t x_pixel_stride, int dtype, int out_dtype, int act, float alpha, float gain, float clamp, void* stream);
+
 extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
                                  void* out, void* ysum, float* msq_partial,
                                  int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
                                  int64_t x_pixel_stride, int dtype, int act, float alpha, float gain, float clamp, void* stream)
 {
-    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv3d_frames: float16 / bfloat16 only (dtype %d)", dtype);
+    return lvg_conv3d_frames_ex(x, w, pre, b, res, post, out, ysum, msq_partial, frames, h, wd, ci, co, kt, kh, kw, frame_shift, x_pixel_stride,
+                                dtype, dtype, act, alpha, gain, clamp, stream);
+}
+
+extern "C" int lvg_conv3d_frames_ex(const void* x, const void* w, const float* pre, const void* b, const void* res, const float* post,
+                                    void* out, void* ysum, float* msq_partial,
+                                    int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw, int64_t frame_shift,
+                                    int64_t x_pixel_stride, int dtype, int out_dtype, int act, float alpha, float gain, float clamp, void* stream)
+{
+    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv3d_frames: float16 / bfloat16 operands only (dtype %d)", dtype);
+    LVG_REQUIRE(out_dtype == dtype || out_dtype == LVG_F32, "conv3d_frames: the output is the operand type or float32 (out_dtype %d)", out_dtype);
     LVG_REQUIRE(frames > 0 && h > 0 && wd > 0, "conv3d_frames: empty input");
     LVG_REQUIRE((kt & 1) && (kh & 1) && (kw & 1) && kt >= 1 && kh >= 1 && kw >= 1, "conv3d_frames: odd kernel sizes only");
     LVG_REQUIRE(act == LVG_ACT_LINEAR || act == LVG_ACT_RELU || act == LVG_ACT_LRELU, "conv3d_frames: linear / relu / lrelu only");
@@ -166,7 +198,7 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
         return LVG_ERR_UNSUPPORTED;
     }
     Plan pl;
-    if (make_plan(frames * h * wd, wd, ci, co, kt, kh, kw, pl) != 0)
+    if (make_plan(frames * h * wd, wd, ci, co, kt, kh, kw, pl, out_dtype == LVG_F32) != 0)
     {
         lvg_set_error("conv3d_frames: frame width %d needs a band the tile cannot hold: no kernel", wd);
         return LVG_ERR_UNSUPPORTED;
@@ -188,5 +220,6 @@ extern "C" int lvg_conv3d_frames(const void* x, const void* w, const float* pre,
     a.gain = gain;
     a.clamp = clamp;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == LVG_F32) return dtype == LVG_BF16 ? launch_f32out<bf16_t>(a, pl, s) : launch_f32out<f16_t>(a, pl, s);
     return dtype == LVG_BF16 ? launch_tile<bf16_t>(a, pl, s) : launch_tile<f16_t>(a, pl, s);
 }

@@ -922,6 +922,14 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
                 float pre4[4] = {1.f, 1.f, 1.f, 1.f}, post4[4] = {1.f, 1.f, 1.f, 1.f}, add4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (p.pre)  { const float4 v = *reinterpret_cast<const float4*>(p.pre + f * p.Co + co);  pre4[0] = v.x; pre4[1] = v.y; pre4[2] = v.z; pre4[3] = v.w; }
                 if (p.post) { const float4 v = *reinterpret_cast<const float4*>(p.post + f * p.Co + co); post4[0] = v.x; post4[1] = v.y; post4[2] = v.z; post4[3] = v.w; }
+                if constexpr (OUTF)
+                {
+                    // float32 output: bias and residual are float32 tensors too
+                    if (bias) { const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + co); add4[0] += v.x; add4[1] += v.y; add4[2] += v.z; add4[3] += v.w; }
+                    if (res)  { const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + m * p.Co + co); add4[0] += v.x; add4[1] += v.y; add4[2] += v.z; add4[3] += v.w; }
+                }
+                else
+                {
                 if (bias)
                 {
                     uint2 raw = *reinterpret_cast<const uint2*>(bias + co);
@@ -937,6 +945,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
                     __builtin_memcpy(t4, &raw, 8);
                     #pragma unroll
                     for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
+                }
                 }
                 T o4[4], y4[4];
                 float sqq = 0.f;
@@ -967,12 +976,15 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
                             const float u = fmaf(a, pre4[e], add4[e]);
                             float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
                             if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
-                            o[e] = g * post4[e];
+                            o[e] = g * post4[e];                 // (the magnitude statistic was accumulated by the common code above)
                         }
                         fv = make_float4(o[0], o[1], o[2], o[3]);
                     }
                     const int64_t ostr = T2D ? (int64_t)ConvArgs2DStride(p) : (int64_t)p.Co;
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * ostr + co) = fv;
+                    if (p.ysum)
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ysum) + m * ostr + co) =
+                            make_float4(acc[cb][pb][qd * 4], acc[cb][pb][qd * 4 + 1], acc[cb][pb][qd * 4 + 2], acc[cb][pb][qd * 4 + 3]);
                 }
                 else if constexpr (kLdsStore)
                     *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;

@@ -446,9 +446,27 @@ def _dup(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else torch.cat((t, t), dim=-1)
 
 
+# float32 tensors on the hand-written kernels through split operands (conv3d_frames.conv3d_frames_split32): float32 accuracy on the 16-bit
+# matrix cores at six (weight gradient: nine) times the multiplications -- the route of the float32 parity tests and of default-precision
+# training (the reference trains lres in float32 with TF32 off); LVG_SPLIT_F32=0 restores the library's float32 convolution.
+SPLIT_F32 = os.environ.get('LVG_SPLIT_F32', '1') == '1'
+
+
+def _split32_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) -> bool:
+    if not (HAND_CONV and SPLIT_F32 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    if tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2) or tuple(weight.shape[2:]) == (1, 1, 1):
+        return False
+    return conv3d_frames.split32_supported(x, weight)
+
+
 def _hand_conv_shape_ok(x: torch.Tensor, co: int, ci: int, weight: torch.Tensor, padding_hw) -> bool:
     """Would the hand-written kernel take the DATA GRADIENT of conv(x, weight): a convolution of a [frames, Co, H, W] gradient
     with the mirrored [Ci, Co, ...] weight (decided on shapes: the gradient tensor does not exist yet)."""
+    if x.is_cuda and x.dtype == torch.float32:
+        kt, kh, kw = weight.shape[2:]
+        return (HAND_CONV and SPLIT_F32 and tuple(padding_hw) == (kh // 2, kw // 2)
+                and conv3d_frames.split32_shape_ok(x.shape[0], x.shape[2], x.shape[3], co, ci, kt, kh, kw))
     if not (HAND_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)) or tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
         return False
     f, _, h, w = x.shape
@@ -459,6 +477,10 @@ def _hand_conv_shape_ok(x: torch.Tensor, co: int, ci: int, weight: torch.Tensor,
 
 
 def _hand_wgrad_shape_ok(x: torch.Tensor, co: int, weight: torch.Tensor, padding_hw) -> bool:
+    if x.is_cuda and x.dtype == torch.float32:
+        kt, kh, kw = weight.shape[2:]
+        return (HAND_CONV and SPLIT_F32 and tuple(padding_hw) == (kh // 2, kw // 2) and x.shape[1] % 64 == 0 and co % 64 == 0
+                and conv3d_frames.wgrad_splits(x.shape[0], x.shape[2], x.shape[3], 3 * x.shape[1], 3 * co, kt, kh, kw) > 0)
     if not (HAND_CONV and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)) or tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
         return False
     f, ci, h, w = x.shape
@@ -543,6 +565,10 @@ class _TapConvEpilogue(torch.autograd.Function):
                                                                  want_msq=want_msq, keep_sum=not plain)
             out = _unpair_view(out)
             ysum = None if ysum is None else _unpair_view(ysum)
+        elif _split32_takes(x, weight, padding_hw):
+            # float32 tensors: the same kernel on split 16-bit operands, float32 accumulators stored unrounded
+            out, ysum, msq = conv3d_frames.conv3d_frames_split32(x, weight, n, pre, b, res, post, act=act, clamp=clamp,
+                                                                 want_msq=want_msq, keep_sum=not plain)
         elif _hand_conv_takes(x, weight, padding_hw):
             # contraction, temporal sum and epilogue in ONE hand-written MFMA kernel (csrc/conv3d_igemm.hip)
             out, ysum, msq = conv3d_frames.conv3d_frames_forward(_cl(x), weight, n, pre, b, res, post, act=act, clamp=clamp,
@@ -595,11 +621,15 @@ class _TapConvEpilogue(torch.autograd.Function):
         if hand_d:
             # data gradient on the hand-written kernel: the same convolution with the taps mirrored and the channel roles swapped
             wt = wt_packed
-            if wt is not None and tuple(wt.shape) == (kt, kh, kw, ci, co) and wt.dtype == dy.dtype:
+            if dy.dtype == torch.float32:
+                gx = conv3d_frames.conv3d_frames_split32_dgrad(dy, weight, n)
+            elif wt is not None and tuple(wt.shape) == (kt, kh, kw, ci, co) and wt.dtype == dy.dtype:
                 gx = conv3d_frames.conv3d_frames_forward(dy, wt.permute(3, 4, 0, 1, 2), n, keep_sum=False, packed=wt)[0]
             else:
                 gx = conv3d_frames.conv3d_frames_forward(dy, weight.flip(2, 3, 4).transpose(0, 1), n, keep_sum=False)[0]
-        if hand_w:
+        if hand_w and dy.dtype == torch.float32:
+            gw = conv3d_frames.conv3d_frames_split32_wgrad(xc, dy, kt, kh, kw, n)
+        elif hand_w:
             gw = conv3d_frames.conv3d_frames_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
         if stacked and POINTWISE_WGRAD_GEMM and kt == kh == kw == 1 and not (need[0] and not hand_d) and conv3d_frames._pixel_stride(xc) == ci:
             # weight gradient of a 1 x 1 convolution = one GEMM over the pixel matrices (views of the channels-last tensors): no zero-fill /
@@ -628,7 +658,7 @@ def temporal_conv_epilogue(x: torch.Tensor, weight: torch.Tensor, n: int, paddin
     `clamp(act(y * pre + b + res) * gain) * post` (pre / post float32 [(T N), C], res like the output).
     Returns `out` or `(out, mean_square)`. With TAP_STACK the kt taps are one convolution and their sum is
     taken inside the epilogue kernel; otherwise kt convolutions are accumulated and the epilogue runs on the sum."""
-    fused = weight.shape[2] > 1 or (_hand_conv_takes(x, weight, padding_hw) and tuple(weight.shape[2:]) != (1, 1, 1))
+    fused = weight.shape[2] > 1 or ((_hand_conv_takes(x, weight, padding_hw) or _split32_takes(x, weight, padding_hw)) and tuple(weight.shape[2:]) != (1, 1, 1))
     if TAP_STACK and not SECOND_ORDER and fused and (res is None or (act == 'linear' and clamp is None and post is None)):
         out, msq = _TapConvEpilogue.apply(x, weight, pre, b, res, post, n, tuple(padding_hw), act, clamp, bool(want_msq))
         return (out, msq) if want_msq else out

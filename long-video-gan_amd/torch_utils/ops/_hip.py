@@ -38,6 +38,8 @@ _SIGNATURES = {
     'lvg_tapconv_epilogue': [_vp] * 8 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_conv3d_frames': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_conv3d_frames_workgroups': [_i64] + [_i32] * 7,
+    'lvg_conv3d_frames_workgroups_f32out': [_i64] + [_i32] * 7,
+    'lvg_conv3d_frames_ex': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_conv3d_frames_wgrad': [_vp] * 4 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     'lvg_conv3d_frames_wgrad_splits': [_i64] + [_i32] * 7,
     'lvg_weight_prep': [_vp] * 4 + [_i32, _i32, _i32, _f32, _i32, _i32, _vp],
@@ -70,7 +72,7 @@ def lib():
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_bias_act_grad_bias_slots', 'lvg_conv2d_frames_workgroups') else ctypes.c_int
+            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_conv3d_frames_workgroups_f32out', 'lvg_bias_act_grad_bias_slots', 'lvg_conv2d_frames_workgroups') else ctypes.c_int
         _lib = handle
     return _lib
 

@@ -108,6 +108,101 @@ def conv3d_frames_forward(x, weight, shift, pre=None, b=None, res=None, post=Non
 
 
 # ----------------------------------------------------------------------------------------------------
+# float32 tensors on the same kernels with float32 accuracy: operands split into THREE bfloat16 parts.
+#   t = t1 + t2 + t3 exactly (8 + 8 + 8 mantissa bits, the exponent range of float32), and
+#   x . w ~= x1 w1 + x1 w2 + x2 w1 + x1 w3 + x2 w2 + x3 w1            (the dropped terms are below 2^-24 of the product)
+# runs as ONE contraction over six times the channels, [x1 | x1 | x2 | x1 | x2 | x3] against [w1 | w2 | w1 | w3 | w2 | w1], with float32
+# accumulators stored unrounded (lvg_conv3d_frames_ex, out_dtype float32). The reference runs the lres networks in float32 with TF32
+# off (train_lres.py:267-269): this is the route that keeps that precision on the 16-bit matrix cores. It costs six (weight gradient:
+# nine) times the multiplications -- a parity / default-precision route, not the benchmark's. (Two float16 parts with a power-of-two
+# scale are cheaper -- the sres generator's float32 layers use that -- but lose the elements ~2^13 below a tensor's maximum, which the
+# gradients of a 21-layer generator do contain: 0.9 % error in the gradient of the network input against 1e-5 for this form.)
+
+_X6, _W6 = (0, 0, 1, 0, 1, 2), (0, 1, 0, 2, 1, 0)
+
+
+def split_bf16x3(t):
+    """float32 -> three bfloat16 tensors whose sum is t to 24 bits."""
+    t = t.float()
+    b1 = t.bfloat16()
+    r = t - b1.float()
+    b2 = r.bfloat16()
+    b3 = (r - b2.float()).bfloat16()
+    return b1, b2, b3
+
+
+def split32_shape_ok(frames, h, w, ci, co, kt, kh, kw):
+    """Is there a float32-output kernel for a convolution with ci input / co output channels (before the six-fold stacking)?"""
+    if ci % 64 or co % 64 or not (kt & 1 and kh & 1 and kw & 1):
+        return False
+    if frames * h * w * 6 * ci * 2 >= 2 ** 32:
+        return False
+    return _init() and int(_hip.lib().lvg_conv3d_frames_workgroups_f32out(frames, h, w, 6 * ci, co, kt, kh, kw)) > 0
+
+
+def split32_supported(x, weight):
+    if x.device.type != 'cuda' or x.dtype != torch.float32 or x.dim() != 4 or weight.dim() != 5 or weight.shape[1] != x.shape[1]:
+        return False
+    f, ci, h, w = x.shape
+    return split32_shape_ok(f, h, w, ci, weight.shape[0], *weight.shape[2:])
+
+
+def conv3d_frames_split32(x, weight, shift, pre=None, b=None, res=None, post=None, act='linear', alpha=None, gain=None,
+                          clamp=None, want_msq=False, keep_sum=True):
+    """`conv3d_frames_forward` for float32 tensors: x [(T N), Ci, H, W] float32 (any layout), weight [Co, Ci, kt, kh, kw] float32 ->
+    (out, ysum | None, mean_square | None), float32 channels-last."""
+    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+    f, ci, h, w = x.shape
+    co, _, kt, kh, kw = weight.shape
+    assert split32_supported(x, weight), 'conv3d_frames_split32: no kernel for this shape'
+    xs, ws = split_bf16x3(x), split_bf16x3(weight)
+    x6 = torch.cat([xs[i] for i in _X6], dim=1).contiguous(memory_format=torch.channels_last)      # [f, 6 ci, h, w] bfloat16
+    w6 = pack_weight(torch.cat([ws[i] for i in _W6], dim=1))                                       # [kt, kh, kw, co, 6 ci]
+    out = torch.empty((f, co, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    ysum = torch.empty_like(out) if keep_sum else None
+    part = torch.empty(int(_hip.lib().lvg_conv3d_frames_workgroups_f32out(f, h, w, 6 * ci, co, kt, kh, kw)), dtype=torch.float32, device=x.device) if want_msq else None
+    if res is not None:
+        res = res.float().contiguous(memory_format=torch.channels_last)
+    pre = None if pre is None else pre.float().contiguous()
+    b = None if b is None else b.float().contiguous()
+    post = None if post is None else post.float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = _hip.lib().lvg_conv3d_frames_ex(
+            x6.data_ptr(), w6.data_ptr(), _hip.ptr(pre), _hip.ptr(b), _hip.ptr(res), _hip.ptr(post), out.data_ptr(), _hip.ptr(ysum), _hip.ptr(part),
+            f, h, w, 6 * ci, co, kt, kh, kw, shift, 6 * ci, _hip.dtype_code(torch.bfloat16), _hip.dtype_code(torch.float32), spec.cuda_idx, alpha, gain, clamp,
+            _hip.stream(x.device))
+    _hip.check(rc, 'conv3d_frames_ex')
+    stats['flops'] += 2 * f * h * w * co * ci * kt * kh * kw             # algorithmic (the six partial products are this route's cost)
+    stats['launches'] += 1
+    return out, ysum, (part.sum() / float(out.numel()) if want_msq else None)
+
+
+def conv3d_frames_split32_dgrad(dy, weight, shift):
+    """Data gradient of the convolution for float32 tensors: dy [(T N), Co, H, W], weight [Co, Ci, kt, kh, kw] -> [(T N), Ci, H, W] float32."""
+    wt = weight.flip(2, 3, 4).transpose(0, 1)                            # taps mirrored, channel roles exchanged
+    return conv3d_frames_split32(dy, wt, shift, keep_sum=False)[0]
+
+
+def conv3d_frames_split32_wgrad(x, dy, kt, kh, kw, shift):
+    """Weight gradient [Co, Ci, kt, kh, kw] float32 from float32 x [(T N), Ci, H, W], dy [(T N), Co, H, W]: [x1 | x2 | x3] against
+    [g1 | g2 | g3] on the 16-bit weight-gradient kernel; of the nine blocks of its [3 Co, 3 Ci] result the six significant ones are added."""
+    ci, co = x.shape[1], dy.shape[1]
+    x3 = torch.cat(split_bf16x3(x), dim=1).contiguous(memory_format=torch.channels_last)
+    g3 = torch.cat(split_bf16x3(dy), dim=1).contiguous(memory_format=torch.channels_last)
+    flops0 = stats['flops']
+    gw = conv3d_frames_wgrad(x3, g3, kt, kh, kw, shift)                  # [3 co, 3 ci, kt, kh, kw]
+    stats['flops'] = flops0 + 2 * x.shape[0] * x.shape[2] * x.shape[3] * co * ci * kt * kh * kw
+    blk = lambda i, j: gw[i * co:(i + 1) * co, j * ci:(j + 1) * ci]
+    return ((blk(2, 0) + blk(1, 1) + blk(0, 2)) + (blk(1, 0) + blk(0, 1))) + blk(0, 0)      # small terms first
+
+
+def split32_wgrad_supported(x, dy, kt, kh, kw):
+    if x.device.type != 'cuda' or x.dtype != torch.float32 or dy.dtype != torch.float32 or x.shape[2:] != dy.shape[2:] or x.shape[0] != dy.shape[0]:
+        return False
+    return _init() and wgrad_splits(x.shape[0], x.shape[2], x.shape[3], 3 * x.shape[1], 3 * dy.shape[1], kt, kh, kw) > 0
+
+
+# ----------------------------------------------------------------------------------------------------
 # Weight gradient (csrc/conv3d_wgrad.hip).
 
 _zero_pages = {}

@@ -377,3 +377,36 @@ def test_pixel_pair_layers_match_library_route_gpu(monkeypatch, shape):
     for i, (h_, l_, t_) in enumerate(zip(hand, lib, truth)):
         eh, el = rel(h_, t_), rel(l_, t_)
         assert eh <= 1.25 * el + 2e-3 and eh < 3e-2, (i, eh, el)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# float32 tensors through split 16-bit operands (conv3d_frames.conv3d_frames_split32)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(5, 2, 64, 64, 6, 7, 3, 3, 3, False), (3, 2, 64, 128, 5, 16, 1, 3, 3, True), (4, 1, 128, 64, 8, 8, 5, 3, 3, False)])
+def test_split32_matches_oracle_at_float32_accuracy_gpu(oracle, case):
+    """float32 x / weight / bias / residual through the 16-bit kernel on split operands vs the float64 oracle: forward with the fused
+    epilogue, saved sum, magnitude statistic; data and weight gradients (gradients scaled to 1e-4 to exercise the power-of-two
+    scaling). Gate: 2e-5 of the tensor scale (measured ~1e-6; the north-star tolerance is 1e-3)."""
+    t, n, ci, co, h, w, kt, kh, kw, with_res = case
+    x, weight, pre, b, res, post = _case(7, t, n, ci, co, h, w, kt, kh, kw, torch.float32, 'cuda', with_res)
+    assert cf.split32_supported(x, weight)
+    act, clamp = ('linear', None) if with_res else ('lrelu', 1.5)
+    out, ysum, msq = cf.conv3d_frames_split32(x, weight, n, pre, b, res, post, act=act, clamp=clamp, want_msq=True)
+    o_out, o_acc, o_msq = _oracle_all(oracle, x, weight, n, pre, b, res, post, act, clamp)
+    errs = {}
+    for name, got, ref in (('out', out, o_out), ('ysum', ysum, o_acc)):
+        errs[name] = float(np.abs(_np(got) - ref).max() / np.abs(ref).max())
+        assert errs[name] < 2e-5, (name, errs)
+    assert abs(float(msq) - o_msq) <= 1e-5 * o_msq
+    g = torch.Generator().manual_seed(3)
+    dy = (torch.randn(t * n, co, h, w, generator=g) * 1e-4).cuda().contiguous(memory_format=torch.channels_last)
+    gx = cf.conv3d_frames_split32_dgrad(dy, weight, n)
+    gx_ref = oracle.conv3d_frames(_np(dy), _np(weight.flip(2, 3, 4).transpose(0, 1)), shift=n)
+    errs['gx'] = float(np.abs(_np(gx) - gx_ref).max() / np.abs(gx_ref).max())
+    if w in (8, 16, 32, 64):
+        gw = cf.conv3d_frames_split32_wgrad(x, dy, kt, kh, kw, n)
+        gw_ref = oracle.conv3d_frames_wgrad(_np(x), _np(dy), kt, kh, kw, shift=n)
+        errs['gw'] = float(np.abs(_np(gw) - gw_ref).max() / np.abs(gw_ref).max())
+    record_measured(f'lres_split32_{kt}x{kh}x{kw}_{ci}to{co}', **errs)
+    assert max(errs.values()) < 2e-5, errs

@@ -54,6 +54,17 @@ def _run(device, rtol_grad):
         got = param.grad.detach().cpu().numpy()
         scale = np.abs(want).max() + 1e-12
         assert np.abs(got - want).max() <= rtol_grad * scale, (key, float(np.abs(got - want).max()), float(scale))
+    # ... and against the reference run in float64 (tests/golden/make_golden_models_f64.py), where the reference's own float32 run sits
+    # at 5e-7 .. 1e-5 of each gradient's scale. This repo's networks order the float32 arithmetic differently (modulation on the activations,
+    # demodulation on the output, fused epilogues) and sit at 1e-6 .. 5e-4 on the CPU (PyTorch kernels; measured values are recorded); the
+    # GPU routes (split-operand contraction on the hand-written kernels + library for the shapes it does not take) share the gate of 1e-3
+    g64 = load_golden('lres_models_f64')
+    worst = {}
+    for key, param in pairs.items():
+        want = g64[key]
+        worst[key] = float(np.abs(param.grad.detach().double().cpu().numpy() - want).max() / np.abs(want).max())
+    record_measured(f'lres_T16_f32_grads_vs_reference_f64_{device}', **worst)
+    assert max(worst.values()) < 1e-3, worst
 
 
 def test_state_dict_keys_match_reference_layout():
