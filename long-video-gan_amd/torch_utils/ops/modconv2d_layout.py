@@ -222,70 +222,114 @@ class _ModConv2dHand(torch.autograd.Function):
         return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None
 
 
+# Split forms of a float32 operand (conv2d_frames.split16 / conv3d_frames.split_bf16x3) and the partial products kept:
+#   'f16x2'  : two float16 parts (11 + 11 bits) after an exact power-of-two scaling to a maximum of ~2^10; products hh, lh, hl: THREE
+#              times the channels. Elements ~2^13 below the tensor's maximum lose their low part (float16's narrow exponent).
+#   'bf16x3' : three bfloat16 parts (8 + 8 + 8 bits, float32's exponent range, no scaling); products 11, 12, 21, 13, 22, 31: SIX times
+#              the channels. Exact to ~2^-24 whatever the dynamic range.
+# Measured on a real generator update (tools/diag_sres_split.py, profiles/r03_sres_split_operands.log): the operands of these three layers
+# -- activations, weights, arriving gradients with max / median up to 2^16 -- are represented by two float16 parts to 4.4e-8 in L2 (elements
+# below 2^-13 of the maximum carry < 4e-6 of the energy), so the cheaper form is the default here; the 21-layer lres generator needs the
+# three-part form (conv3d_frames.py).
+SPLIT_MODE = os.environ.get('LVG_SRES_SPLIT_MODE', 'f16x2')
+_SPLIT_FORMS = {'f16x2': (torch.float16, 2, (0, 1, 0), (0, 0, 1)), 'bf16x3': (torch.bfloat16, 3, (0, 0, 1, 0, 1, 2), (0, 1, 0, 2, 1, 0))}
+
+
+def _split_parts(t, mode):
+    """-> (parts, scale): t * scale = sum(parts) to float32 accuracy; scale is a 0-d tensor (1 for bfloat16 parts)."""
+    if mode == 'f16x2':
+        s = conv2d_frames.pow2_scale(t)
+        return list(conv2d_frames.split16(t.float() * s)), s
+    from .conv3d_frames import split_bf16x3
+    return list(split_bf16x3(t)), torch.ones((), device=t.device)
+
+
 class _ModConv2dSplit(torch.autograd.Function):
     """The modulated 3 x 3 convolution of the FLOAT32 layers on the hand-written 16-bit MFMA kernels with float32 accuracy: every
-    operand is split into a float16 high and low part (conv2d_frames.split16) and the three significant partial products run as one
-    contraction over stacked channels, accumulated and stored in float32. The reference runs these layers in float32 with TF32 off
-    (train_sres.py:304-306); the split keeps ~22 mantissa bits per operand. Layout / modulation / splitting are plain tensor ops here
-    (the float32 layers are the three smallest of the network: 38 x 31 pixels)."""
+    operand is split into 16-bit parts (_SPLIT_FORMS) and the significant partial products run as ONE contraction over stacked
+    channels, accumulated and stored in float32. The reference runs these layers in float32 with TF32 off (train_sres.py:304-306).
+    Layout / modulation / splitting are plain tensor ops here (the float32 layers are the three smallest of the network: 38 x 31 pixels)."""
 
     @staticmethod
     def forward(ctx, first, second, weight, mod, demod, padding):
         c2 = conv2d_frames
+        dt, nparts, xpat, wpat = _SPLIT_FORMS[SPLIT_MODE]
         n, c_first, h, w = first.shape
         co, ci = weight.shape[:2]
         geo = c2.Geometry(h, w, padding)
         cip, cop = c2.round_up(ci, c2.CH), c2.round_up(co, c2.CH)
         xin = (first if second is None else torch.cat((first, second), dim=1)).float() * mod.float()[:, :, None, None]
-        # float16 parts keep 11 bits each only for values within ~2^13 of the tensor's maximum (narrow exponent): bring every operand's
-        # maximum to ~2^10 by an exact power of two, undone on the float32 result
-        sx, sw = c2.pow2_scale(xin), c2.pow2_scale(weight)
-        xh, xl = c2.split16((xin * sx).permute(0, 2, 3, 1))
-        xp = torch.zeros([n, geo.hx, geo.wx, 3 * cip], dtype=torch.float16, device=first.device)      # [xh | xl | xh] per pixel
+        xs, sx = _split_parts(xin.permute(0, 2, 3, 1), SPLIT_MODE)
+        ws, sw = _split_parts(weight, SPLIT_MODE)
+        k = len(xpat)
+        xp = torch.zeros([n, geo.hx, geo.wx, k * cip], dtype=dt, device=first.device)      # the stacked parts per pixel
         inner = xp[:, 2:2 + h, 2:2 + w]
-        inner[..., :ci], inner[..., cip:cip + ci], inner[..., 2 * cip:2 * cip + ci] = xh, xl, xh
-        wh, wl = c2.split16(weight.float() * sw)
-        wp = torch.cat([c2.pack_weight(t, torch.float16, cip, cop) for t in (wh, wh, wl)], dim=3)       # [3, 3, cop, 3 cip]
-        alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work (the three partial products are this implementation's cost, not the operation's)
+        for j, pi in enumerate(xpat):
+            inner[..., j * cip:j * cip + ci] = xs[pi]
+        wp = torch.cat([c2.pack_weight(ws[pi], dt, cip, cop) for pi in wpat], dim=3)        # [3, 3, cop, k cip]
+        alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work (the partial products are this implementation's cost, not the operation's)
         y = c2.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), out_dtype=torch.float32, alg_flops=alg)     # [n, ho, wo, cop] float32, scaled by sx sw
         y = y * (1.0 / (sx * sw))
         yv = y[..., :co].permute(0, 3, 1, 2)
         out = (yv if demod is None else yv * demod.float()[:, :, None, None]).contiguous()
-        ctx.save_for_backward(first, second, mod, demod, xp, y, weight, sx, sw)
-        ctx.geo, ctx.alg = geo, alg
+        # the weight gradient needs each part of x ONCE: they are the first occurrences in the stacked frame when the pattern starts 0, .. (f16x2:
+        # blocks 0, 1; bf16x3: blocks 0, 2, 5 -- kept as a separate compact frame there)
+        xw = xp if SPLIT_MODE == 'f16x2' else None
+        if xw is None:
+            xw = torch.zeros([n, geo.hx, geo.wx, nparts * cip], dtype=dt, device=first.device)
+            innerw = xw[:, 2:2 + h, 2:2 + w]
+            for pi in range(nparts):
+                innerw[..., pi * cip:pi * cip + ci] = xs[pi]
+        ctx.save_for_backward(first, second, mod, demod, xw, y, weight, sx, sw)
+        ctx.geo, ctx.alg, ctx.mode, ctx.cip = geo, alg, SPLIT_MODE, cip
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
         c2 = conv2d_frames
-        first, second, mod, demod, xp, y, weight, sx, sw = ctx.saved_tensors
-        geo = ctx.geo
+        first, second, mod, demod, xw, y, weight, sx, sw = ctx.saved_tensors
+        geo, mode, cip = ctx.geo, ctx.mode, ctx.cip
+        dt, nparts, xpat, wpat = _SPLIT_FORMS[mode]
         assert not ctx.needs_input_grad[1], 'modulated_conv2d: no gradient for the conditioning frames on the fused path'
         n, c_first = first.shape[:2]
         co, ci = weight.shape[:2]
-        cip, cop = xp.shape[3] // 3, y.shape[3]
+        cop = y.shape[3]
         d_out = d_out.float()
         d_demod = None
         if demod is not None and ctx.needs_input_grad[4]:
             d_demod = (d_out * y[..., :co].permute(0, 3, 1, 2)).sum(dim=(2, 3))
         g = d_out if demod is None else d_out * demod.float()[:, :, None, None]
-        # gradients span many octaves and float16 has a narrow exponent: scale by a power of two (exact), undo on the results
-        s = c2.pow2_scale(g)
-        gh, gl = c2.split16((g * s).permute(0, 2, 3, 1))
-        dyp = torch.zeros([n, geo.hd, geo.wd, 3 * cop], dtype=torch.float16, device=first.device)       # [gh | gl | gh] per pixel at (q, q)
+        gs, s = _split_parts(g.permute(0, 2, 3, 1), mode)
+        k = len(xpat)
+        dyp = torch.zeros([n, geo.hd, geo.wd, k * cop], dtype=dt, device=first.device)       # stacked parts of the gradient per pixel at (q, q)
         inner = dyp[:, geo.q:geo.q + geo.ho, geo.q:geo.q + geo.wo]
-        inner[..., :co], inner[..., cop:cop + co], inner[..., 2 * cop:2 * cop + co] = gh, gl, gh
+        for j, pi in enumerate(xpat):
+            inner[..., j * cop:j * cop + co] = gs[pi]
         d_weight = None
         if ctx.needs_input_grad[2]:
-            # [xh | xl] against [gh | gl]: the four blocks of the [2 cop, 2 cip] result are the four partial products
-            gw = c2.conv2d_wgrad(xp, dyp, x_channels=2 * cip, dy_channels=2 * cop, alg_flops=ctx.alg)
-            gw = gw[:, :, :cop, :cip] + gw[:, :, :cop, cip:] + gw[:, :, cop:, :cip] + gw[:, :, cop:, cip:]
-            d_weight = (gw[:, :, :co, :ci].permute(2, 3, 0, 1) * (1.0 / (s * sx))).to(weight.dtype)
+            # each part of x against each part of the gradient: the blocks (i, j) of the [nparts cop, nparts cip] result with i + j < nparts
+            # are the significant partial products (f16x2: all four are added, the low-low one is below the rounding)
+            if mode == 'f16x2':
+                gyp = dyp
+            else:
+                gyp = torch.zeros([n, geo.hd, geo.wd, nparts * cop], dtype=dt, device=first.device)
+                innerg = gyp[:, geo.q:geo.q + geo.ho, geo.q:geo.q + geo.wo]
+                for pi in range(nparts):
+                    innerg[..., pi * cop:pi * cop + co] = gs[pi]
+            gw = c2.conv2d_wgrad(xw, gyp, x_channels=nparts * cip, dy_channels=nparts * cop, alg_flops=ctx.alg)
+            acc = None
+            for total in range(nparts if mode != 'f16x2' else nparts + 1, -1, -1):                   # small terms first
+                for i in range(nparts):
+                    j = total - i
+                    if 0 <= j < nparts and (mode == 'f16x2' or i + j < nparts):
+                        blk = gw[:, :, i * cop:(i + 1) * cop, j * cip:(j + 1) * cip]
+                        acc = blk if acc is None else acc + blk
+            d_weight = (acc[:, :, :co, :ci].permute(2, 3, 0, 1) * (1.0 / (s * sx))).to(weight.dtype)
         d_first = d_mod = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
-            wh, wl = c2.split16(weight.float() * sw)
-            wd = torch.cat([c2.pack_weight_dgrad(t, torch.float16, cip, cop) for t in (wh, wh, wl)], dim=3)   # [3, 3, cip, 3 cop]
+            ws, _ = _split_parts(weight, mode)
+            wd = torch.cat([c2.pack_weight_dgrad(ws[pi], dt, cip, cop) for pi in wpat], dim=3)       # [3, 3, cip, k cop]
             dx = c2.conv2d_valid(dyp, wd, geo.h, geo.w, out_dtype=torch.float32, alg_flops=ctx.alg)[..., :ci].permute(0, 3, 1, 2) * (1.0 / (s * sw))   # d (x * mod), NCHW view
             if ctx.needs_input_grad[3]:
                 xcat = (first if second is None else torch.cat((first, second), dim=1)).float()
