@@ -289,11 +289,17 @@ def main():
         F.softplus(-logits).mean().backward()
         pending_emas[:] = [pending, lres.stack_pending(pending) if pending else None]
 
+    sync_events = []               # (start, end) HIP events around the gradient exchange of the timed steps
+
     def update():
         if not args.forward_only:
             if pending_emas and pending_emas[0]:
                 lres.finish_magnitude_sync(*pending_emas)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             sync.finish()          # all-reduce (mean) over ranks, nan_to_num -- no-op collective at N=1
+            e1.record()
+            sync_events.append((e0, e1))
             opt.step()
 
     def step():
@@ -333,6 +339,7 @@ def main():
             torch.cuda.synchronize()
     barrier()
 
+    sync_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if graph is not None:
@@ -342,6 +349,8 @@ def main():
             step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # the gradient exchange runs after the captured step, not under it: its device time is exposed time of the step
+    exposed_sync_ms = sum(a.elapsed_time(b) for a, b in sync_events) / max(len(sync_events), 1) if sync_events else 0.0
 
     # Roofline of the custom ops: record the launches of ONE more step of the same workload, then time
     # each of them back to back with HIP events on the launch stream (see OpTimer).
@@ -357,6 +366,9 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    _flush_c_stdio()                       # every rank: library banners out before rank 0's JSON line
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -399,6 +411,8 @@ def main():
             'ops': {k: (dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), tflops=round(v['gbps'] / 1e3, 1)) if k in flop_ops else
                         dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1))) for k, v in ops.items()},
             'step_ms_in_custom_ops': round(sum(v['total_ms'] for v in ops.values()) / roofline_steps, 3),
+            'grad_sync': {'bytes': int(sync.flat.numel() * 4), 'exposed_ms_per_step': round(exposed_sync_ms, 3), 'collective': 'RCCL all-reduce (mean) of the flat float32 gradient in 128 MB buckets + scale + nan_to_num, after the hipGraph replay (not overlapped)' if world > 1 else 'no collective at N = 1: scale + nan_to_num pass only',
+                          'backend': dist.get_backend() if dist.is_initialized() else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = _cpu_baseline(forward_only=args.forward_only)
@@ -420,9 +434,21 @@ def main():
                     result[name] = leg()
                 except Exception as err:  # pylint: disable=broad-except
                     result[name] = {'error': f'{type(err).__name__}: {err}'[:300]}
+        _flush_c_stdio()
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator comes up; on a pipe or file it is buffered until the process exits,
+    i.e. it would land AFTER this script's JSON line. Flush it out now (every rank), so the JSON stays the last line of the output."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # pylint: disable=broad-except
+        pass
+    sys.stdout.flush()
 
 
 def _free_port():
@@ -458,6 +484,8 @@ def _launch_selftest(args, world, rank, local_rank):
     dist.all_reduce(t)
     dist.barrier()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    _flush_c_stdio()
+    dist.barrier()
     if rank == 0:
         print(json.dumps({'launch_selftest': True, 'n_gpus': world, 'backend': dist.get_backend(), 'rank_sum': float(t.item())}), flush=True)
     dist.destroy_process_group()
@@ -471,6 +499,9 @@ def _train_lres_workload(args, world, rank, dev, dtype):
     RCCL from an autograd hook while the rest of the last backward still runs). Eager launches (the collectives
     cannot be captured into a hipGraph on this stack). One JSON line on rank 0, frames/s over all ranks."""
     res = _train_lres_run(world, rank, dev, dtype, args.frames, args.steps, args.warmup, dtype_name=args.dtype)
+    _flush_c_stdio()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(res), flush=True)
 
