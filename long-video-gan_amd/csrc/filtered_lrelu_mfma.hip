@@ -40,6 +40,18 @@
 #else
 #define LVG_MARK(name)
 #endif
+// Analysis builds only (-DLVG_TIMING; tools/flrelu_check prints the table): shader-clock cycles each wave spends per region of the
+// tile loop, read with s_memtime at the region boundaries and left in g_flreluTiming[(workgroup * 4 + wave) * 16 + region].
+#ifdef LVG_TIMING
+__device__ uint32_t g_flreluTiming[4096 * 16];
+#define LVG_TICK(idx) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); tAcc[idx] += now_ - tLast; tLast = now_; }
+extern "C" int lvg_flrelu_timing_read(uint32_t* host, int count)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_flreluTiming), (size_t)count * 4, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define LVG_TICK(idx)
+#endif
 
 // Tuning switches (A/B measured with tools/flrelu_check):
 #ifndef LVG_ABL
@@ -177,6 +189,16 @@ __device__ __forceinline__ half8 pack_chunk(const f32x16& c, int h)
 __device__ __forceinline__ uint32_t h2_bits(half2v v) { uint32_t u; __builtin_memcpy(&u, &v, 4); return u; }
 __device__ __forceinline__ half2v bits_h2(uint32_t u) { half2v v; __builtin_memcpy(&v, &u, 4); return v; }
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One 16-bit element at a wave-uniform address through the scalar cache (the aligned dword that holds it).
+__device__ __forceinline__ uint32_t scalar_load_u16(const uint16_t* ptr)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)ptr;
+    const uint64_t a4 = a & ~(uint64_t)3;
+    uint32_t wd;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wd) : "s"(a4) : "memory");
+    return (a & 2) ? (wd >> 16) : (wd & 0xffffu);
+}
 
 // Two stored elements (element 0 in the low half of the dword) + bias -> f16 pair. bfloat16 values beyond the
 // f16 range saturate instead of turning into inf (inf * a zero tap of the banded matrix would be NaN).
@@ -399,6 +421,7 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
     uint32_t raw[NPASS];                                                    // prefetched pairs of the NEXT tile (storage bits)
     uint32_t mraw[5];                                                       // READ mode: prefetched (aligned) mask dwords of the next tile
     int mshiftN = 0, mvalidN = 0;                                           // ... their byte shift (uniform) and this thread's count of valid bytes
+    uint32_t mokN = 0;                                                      // ... bit j: dword j lies inside the mask plane
     float biasN = 0.0f;
     // Stage D: this wave's output block and this lane's column.
     const int dBy = w / G::OBX, dBx = w - dBy * G::OBX;
@@ -423,7 +446,9 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
         // compiler cannot hoist ten 64-bit lane addresses out of the tile loop (it did: +20 VGPRs and spills)
         const char* xpl = (const char*)((const T*)p.x + ((LVG_ABL & 32) ? 0 : ((int64_t)tc.nb * p.xs[0] + (int64_t)tc.ch * p.xs[1])));
         const int bi = tc.plane - planeBeg;
-        const uint32_t bb = bi < 64 ? biasL[bi] : (uint32_t)((const uint16_t*)p.b)[tc.ch];
+        // (planes beyond the 64 of the LDS table: a SCALAR load. A vector load here would put a vector-memory wait between the
+        // prefetch loads below and their use a tile later -- the counter is in-order -- and stall every tile for a full memory latency)
+        const uint32_t bb = bi < 64 ? biasL[bi] : scalar_load_u16((const uint16_t*)p.b + tc.ch);
         { T bt; const uint16_t b16 = (uint16_t)bb; __builtin_memcpy(&bt, &b16, 2); biasN = (float)to_acc(bt); }
         negbN = (bb ^ 0x8000u) * 0x10001u;                                    // (-bias, -bias): + bias = 0 outside the image
         const int rLo = max(0, -inY0);
@@ -460,13 +485,16 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
             const uint32_t rowOff = (uint32_t)(sy * p.sWBytes);
             mshiftN = signByte0 & 3;
             mvalidN = p.swLimit - b0;                                        // bytes of this thread's 16 that carry pixels (may be <= 0 or >= 16)
+            // unconditional loads like the pixels': dwords outside the plane are fetched from the plane's first dword and zeroed
+            // when the tile is written (no execution-mask branches, no vector-memory waits here)
+            mokN = 0;
             #pragma unroll
             for (int j = 0; j < 5; j++)
             {
                 const int bx = a0 + 4 * j;
-                uint32_t v = 0;
-                if (rowOk && bx >= 0 && bx + 4 <= p.sWBytes) v = *reinterpret_cast<const uint32_t*>(spl + (rowOff + (uint32_t)bx));
-                mraw[j] = v;
+                const bool ok = rowOk && bx >= 0 && bx + 4 <= p.sWBytes;
+                mokN |= ok ? (1u << j) : 0u;
+                mraw[j] = *reinterpret_cast<const uint32_t*>(spl + (ok ? rowOff + (uint32_t)bx : 0u));
             }
         }
     };
@@ -516,7 +544,8 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
             #pragma unroll
             for (int d = 0; d < 4; d++)
             {
-                uint32_t v = __builtin_amdgcn_alignbyte(mraw[d + 1], mraw[d], (uint32_t)mshiftN);
+                const uint32_t lo = (mokN >> d) & 1u ? mraw[d] : 0u, hi = (mokN >> (d + 1)) & 1u ? mraw[d + 1] : 0u;
+                uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)mshiftN);
                 const int nv = mvalidN - 4 * d;                              // bytes at and beyond swLimit carry no pixels
                 if (nv < 4) v = nv <= 0 ? 0u : (v & ((1u << (8 * nv)) - 1u));
                 m[d] = v;
@@ -543,8 +572,10 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
     };
 
     // Stage D of one tile: Y^T[ox][oy] = W^T * D_y^T from WL (all waves' rows), one 32 x 32 output block per wave.
-    // Lanes = 32 output rows, registers 4q .. 4q + 3 = four consecutive ox -> 8-byte stores. `store` = false computes
-    // without writing (first trip of the pipelined loop: WL holds nothing yet).
+    // Lanes = 32 output rows, registers 4q .. 4q + 3 = four consecutive ox -> 8-byte stores (16-byte stores after a half-wave
+    // exchange, and 16 rows x 64 contiguous bytes per instruction through an LDS transpose, both measured SLOWER:
+    // profiles/r03_flrelu_store_ab.log -- the stores are not issue-bound). `store` = false computes without writing (first trip
+    // of the pipelined loop: WL holds nothing yet).
     auto stage_d = [&](const TileCoord& tc, bool store)
     {
         if (w < G::OBX * G::OBY && !(LVG_ABL & 8))
@@ -596,13 +627,19 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
     TileCoord prv = cur;
 
     LVG_MARK("loop");
+#ifdef LVG_TIMING
+    uint32_t tAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tLast = (uint32_t)__builtin_readcyclecounter();
+#endif
     for (int tile = tileBeg; tile < tileEnd; tile++)
     {
+        LVG_TICK(0);
         const int tileX = cur.tileX, tileY = cur.tileY, ch = cur.ch, nb = cur.nb;
         const int outX0 = tileX * TW, outY0 = tileY * TH;
 
         LVG_MARK("barrier1");
         __syncthreads();                                                    // barrier X: XL (ML, table) of this tile and WL of the previous tile visible
+        LVG_TICK(1);
 
         // tmax[slotR] = max |x + bias| of the tile now in XL (written before barrier X); the other slot is cleared here for
         // the tile written after barrier Y
@@ -619,6 +656,7 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
             if (!(LVG_ABL & 1)) issue_loads(nxt);
         }
 
+        LVG_TICK(2);
         // ---- stage A: T'[ic][v] for this wave's 32 rows v ------------------------------------------------
         LVG_MARK("stageA");
         half8 tpk[G::IN_BLK][2];
@@ -649,8 +687,10 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
 
         // ---- stage D of the PREVIOUS tile: independent of everything above, so its LDS-read -> 5-MFMA chain -> store
         //      latency overlaps with stage A / B of this tile instead of sitting alone between two barriers ----------
+        LVG_TICK(3);
         LVG_MARK("stageD");
         stage_d(prv, tile > tileBeg);
+        LVG_TICK(4);
 
         // ---- stages B, activation, C over the four 32-column blocks of u, software-pipelined: the MFMAs of block
         //      b + 1 are issued before the (vector-pipe) activation of block b, stage C of block b after it --------
@@ -693,8 +733,10 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
             }
             if (b < 3) accU = LVG_MFMA_PIPELINE ? accUn : stage_b(b + 1, tpk);
         }
+        LVG_TICK(5);
         LVG_MARK("barrier2");
         __syncthreads();                                                    // barrier Y: every wave is done reading XL and WL (and writing ML in WRITE mode)
+        LVG_TICK(6);
 
         // W[ox][v] -> WL[v][ox]: registers 4q .. 4q + 3 are four consecutive ox
         LVG_MARK("wwrite");
@@ -710,6 +752,7 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
                     *reinterpret_cast<half4*>(WL + (32 * w + n) * G::SW + 32 * bo + 8 * q + 4 * g) = h;
             }
 
+        LVG_TICK(7);
         // ---- WRITE mode: mask tile -> global, only the part this tile owns --------------------------------
         LVG_MARK("maskout");
         if (MODE == LVG_SIGNS_WRITE)
@@ -779,6 +822,7 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
             }
         }
 
+        LVG_TICK(8);
         // ---- the prefetched next tile -> XL (ML); stage A of this tile is behind barrier Y -----------------
         LVG_MARK("xwrite");
         slotW = ((tile - tileBeg) & 1) ^ 1;
@@ -786,7 +830,16 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
 
         prv = cur;
         cur = nxt;
+        LVG_TICK(9);
     }
+#ifdef LVG_TIMING
+    if (lane == 0)
+    {
+        uint32_t* o = g_flreluTiming + ((blockIdx.x & 1023) * 4 + w) * 16;
+        for (int i = 0; i < 12; i++) o[i] = tAcc[i];
+        o[12] = (uint32_t)(tileEnd - tileBeg);
+    }
+#endif
     // stage D of the last tile
     if (tileBeg < tileEnd)
     {

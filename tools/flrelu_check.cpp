@@ -24,6 +24,7 @@ typedef int (*orc_fn)(const double*, const double*, const double*, const double*
                       int, int, int, int, int, int, int, int, int, int, int, int, int, int, double, double, double, int, int, int, int);
 
 static flrelu_fn g_flrelu; static setimpl_fn g_setimpl; static err_fn g_err; static orc_fn g_orc;
+typedef int (*timing_fn)(uint32_t*, int); static timing_fn g_timing;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -239,6 +240,25 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
         printf("%-10s %s %-5s impl=%s  %8.1f us  %7.1f GB/s  (%.3f of 8 TB/s; algorithmic bytes %.1f MB)\n", cs.name, dtype == 1 ? "f16 " : "bf16",
                mode == 1 ? "fwd+s" : mode == 0 ? "fwd" : "bwd", impl == 2 ? "MFMA" : "VALU", best * 1e3, bytes / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 8e12, bytes / 1e6);
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (g_timing && impl == 2)      // -DLVG_TIMING build of the library: cycles per region, mean over waves, per tile
+        {
+            std::vector<uint32_t> t(4096 * 16);
+            if (g_timing(t.data(), 4096 * 16) == 0)
+            {
+                static const char* names[10] = {"loop-top", "barrier1", "prefetch", "stageA", "stageD", "stageBC", "barrier2", "wwrite", "maskout", "xwrite"};
+                double sum[12] = {0}; double tiles = 0; int waves = 0;
+                for (int wv = 0; wv < 4096; wv++)
+                {
+                    if (!t[wv * 16 + 12]) continue;
+                    waves++; tiles += t[wv * 16 + 12];
+                    for (int r = 0; r < 10; r++) sum[r] += t[wv * 16 + r];
+                }
+                double tot = 0; for (int r = 0; r < 10; r++) tot += sum[r];
+                printf("  timing: %d waves, %.1f tiles each; cycles per tile per wave:", waves, tiles / waves);
+                for (int r = 0; r < 10; r++) printf(" %s %.0f", names[r], sum[r] / tiles);
+                printf(" | total %.0f\n", tot / tiles);
+            }
+        }
     }
 }
 
@@ -254,6 +274,7 @@ int main(int argc, char** argv)
     g_flrelu = (flrelu_fn)dlsym(lib, "lvg_filtered_lrelu"); g_setimpl = (setimpl_fn)dlsym(lib, "lvg_filtered_lrelu_set_impl");
     g_err = (err_fn)dlsym(lib, "lvg_last_error"); g_orc = (orc_fn)dlsym(orc, "orc_filtered_lrelu");
     if (!g_flrelu || !g_setimpl || !g_err || !g_orc) { printf("missing symbol\n"); return 2; }
+    g_timing = (timing_fn)dlsym(lib, "lvg_flrelu_timing_read");
     int fails = 0;
     if (what == "check" || what == "all")
     {
