@@ -290,11 +290,12 @@ int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float
 int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, const void* oth_a, const void* oth_b, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_src, int c_dst, int c_a, int c_b, int dtype, void* stream);
 /* lvg_modconv2d_nchw_to_nhwc writing into the interior of a LARGER channels-last frame: source planes src_h x src_w go to
- * dst [n][dst_h][dst_w][c_dst] at (off_y, off_x). The border is not written: the caller zero-fills dst once (the explicit zero
- * padding of lvg_conv2d_frames / lvg_conv2d_frames_wgrad). oth / partial as above (dense frames of src_h * src_w pixels). */
+ * dst [n][dst_h][dst_w][c_dst] at (off_y, off_x) (the explicit zero padding of lvg_conv2d_frames / lvg_conv2d_frames_wgrad).
+ * zero_border != 0: the border pixels are zero-filled by the call (dst may be uninitialised memory); 0: the border is not written
+ * (the caller zero-filled dst). oth / partial as above (dense frames of src_h * src_w pixels). */
 int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                       int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
-                                      int dst_h, int dst_w, int off_y, int off_x, int dtype, void* stream);
+                                      int dst_h, int dst_w, int off_y, int off_x, int zero_border, int dtype, void* stream);
 
 /*
  * Dense 3 x 3 contraction of the super-resolution networks as a hand-written implicit GEMM (csrc/conv2d_igemm.hip) and its
@@ -356,6 +357,23 @@ int lvg_weight_prep_backward(const float* w, const float* amax, const void* g, c
 /* wp [taps, co, ci] (16-bit elements) -> wt [taps, ci, co] with the tap order reversed: the weight of the data-gradient
  * convolution (mirrored taps, channel roles swapped: what lvg_conv3d_frames takes as `w` when it is run on dy). */
 int lvg_weight_dgrad_pack(const void* wp, void* wt, int taps, int co, int ci, void* stream);
+
+/*
+ * Weight side of the 2-D modulated convolution of the super-resolution generator (reference model/generator_sres.py:50-58 and :63,
+ * `weight.to(x.dtype)`) in one pass per direction (csrc/weight_prep.hip):
+ *   forward:  w [co, ci, taps] f32 -> w' = w * rsqrt(mean over (ci, taps) of w^2) * scale;
+ *             wp [taps, co_pad, ci_pad] = w' in `dtype`, padding zero-filled (the weight lvg_conv2d_frames consumes);
+ *             wt [taps, ci_pad, co_pad] = wp with the taps mirrored and the channel roles exchanged (the data-gradient weight), or NULL;
+ *             w2 [co, ci] f32 = sum over the taps of w'^2;  stat [co] f32 = rsqrt(mean w^2) (kept for the backward pass)
+ *   backward: g = gradient of wp's elements, FLOAT32 [taps, co_pad, ci_pad] (what lvg_conv2d_frames_wgrad produces) or NULL,
+ *             g_w2 [co, ci] f32 or NULL (at least one of the two) -> dw [co, ci, taps] f32. Linear in (g, g_w2): the two
+ *             contributions may be taken in separate calls and added.
+ * ci * taps * 8 bytes must fit in LDS (150 KiB).
+ */
+int lvg_weight_prep2d(const float* w, void* wp, void* wt, float* w2, float* stat, int co, int ci, int taps, int co_pad, int ci_pad,
+                      float scale, int dtype, void* stream);
+int lvg_weight_prep2d_backward(const float* w, const float* stat, const float* g, const float* g_w2, float* dw,
+                               int co, int ci, int taps, int co_pad, int ci_pad, float scale, void* stream);
 
 /*
  * Style side of a modulated convolution (csrc/style_prep.hip): the per-sample max normalisation of the styles and the

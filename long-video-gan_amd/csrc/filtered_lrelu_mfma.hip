@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kThreads, (MG<UP, DOWN, FU, FD, TW, TH, MODE>::WAVE
     for (int tile = tileBeg; tile < tileEnd; tile++)
     {
         LVG_TICK(0);
-        const int tileX = cur.tileX, tileY = cur.tileY, ch = cur.ch, nb = cur.nb;
+        const int tileX = cur.tileX, tileY = cur.tileY;
         const int outX0 = tileX * TW, outY0 = tileY * TH;
 
         LVG_MARK("barrier1");

@@ -52,6 +52,7 @@ struct LayoutArgs
     // p = y * srcW + x goes to pixel (y + offY) * dstW + (x + offX) of a frame of dstHW pixels; srcW == 0: same frame (pixel p).
     // The border is NOT written here (the caller zero-fills the tensor once).
     int srcW, dstW, dstHW, offY, offX;
+    float invW;                            // 1 / srcW (0: divide)
 };
 
 template <class T> __device__ __forceinline__ float ld1(const T* p) { return (float)to_acc(*p); }
@@ -65,11 +66,35 @@ __device__ __forceinline__ const T* nchw_ptr(const void* a, const void* b, int c
     return nullptr;
 }
 
-template <class T>
+// 4 (rows) x 16 (columns) block of a row-major 16-bit LDS matrix through the gfx950 transpose read: the 16 lanes of a group supply
+// the addresses of row (s >> 2), columns 4 (s & 3) .. + 3, and lane s receives column s of the four rows.
+template <class T> __device__ __forceinline__ void lds_tr4(const T* p, T* out4)
+{
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) short4v* lds_ptr;
+    const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    __builtin_memcpy(out4, &v, 8);
+}
+
+// pixel p = y * w + x of a plane -> (y, x) without an integer division (exact for p < 2^22; the caller passes invW = 0 beyond)
+__device__ __forceinline__ void split_pixel(int p, int w, float invW, int& y, int& x)
+{
+    if (invW == 0.0f) { y = p / w; x = p - y * w; return; }
+    y = (int)((float)p * invW);
+    x = p - y * w;
+    if (x < 0) { y--; x += w; } else if (x >= w) { y++; x -= w; }
+}
+
+// One workgroup = 64 channels x 64 pixels. Phase 1: channel rows of the NCHW source -> LDS (16-byte vectors, 8 lanes per row).
+// Phase 2: each 16-lane group takes 16 pixels x 8 channels out of LDS with two transpose reads (lane = pixel, its 8 channels =
+// the 16-byte unit of the NHWC destination); the four groups of a wave write 64 contiguous bytes of 16 pixels per instruction.
+template <class T, bool RED>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
 {
-    __shared__ __attribute__((aligned(16))) T tile[kTile * kLdsStride];     // [c][p], values BEFORE scaling
-    __shared__ float red[32 * kTile];
+    __shared__ __attribute__((aligned(16))) T tile[kTile * kLdsStride];     // [c][p], values BEFORE scaling; pitch 72: the four rows of a
+                                                                            // transpose read start 36 dwords apart = disjoint banks
+    __shared__ __attribute__((aligned(16))) float sc[kTile];
+    __shared__ float red[RED ? kTile * 65 : 1];                             // [c][p] products for the fixed-order sum
     const int tid = threadIdx.x;
     const int p0 = blockIdx.x * kTile, c0 = blockIdx.y * kTile;
     const int64_t n = blockIdx.z;
@@ -93,59 +118,94 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
                 for (int e = 0; e < 8; e++) if (p + e < a.hw) val.v[e] = row[p + e];
             }
         }
-        store_vec16<T>(tile + c * kLdsStride + swz(c, 8 * seg), val);
+        store_vec16<T>(tile + c * kLdsStride + 8 * seg, val);
     }
+    if (tid < kTile) sc[tid] = (a.scale && c0 + tid < cSrc) ? a.scale[n * cSrc + c0 + tid] : 1.0f;
     __syncthreads();
-    // phase 2: 8 threads x 8 channels per pixel
-    float dot[8];
-    #pragma unroll
-    for (int j = 0; j < 8; j++) dot[j] = 0.0f;
-    #pragma unroll
-    for (int v = 0; v < 2; v++)
+    // phase 2: wave = 16 pixels, lane group g and trip `it` = channels 8 (4 it + g) .. + 7
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, s = lane & 15;
+    const int pl = 16 * wv + s, p = p0 + pl;
+    int64_t dp = n * a.hw + p;
+    if (a.srcW > 0)
     {
-        const int idx = tid + 256 * v, pl = idx >> 3, cg = idx & 7;
-        const int p = p0 + pl, cc = c0 + 8 * cg;
-        if (p < a.hw && cc < a.cNhwc)
+        int y, x;
+        split_pixel(p, a.srcW, a.invW, y, x);
+        dp = n * a.dstHW + (int64_t)(y + a.offY) * a.dstW + (x + a.offX);
+    }
+    #pragma unroll
+    for (int it = 0; it < 2; it++)
+    {
+        const int cg = 4 * it + g, cc = c0 + 8 * cg;
+        Vec16<T> xin;
+        const T* q = tile + (8 * cg + (s >> 2)) * kLdsStride + 16 * wv + 4 * (s & 3);
+        lds_tr4<T>(q, xin.v);
+        lds_tr4<T>(q + 4 * kLdsStride, xin.v + 4);
+        float x[8];
+        #pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = (float)to_acc(xin.v[j]);
+        const bool live = p < a.hw && cc < a.cNhwc;
+        if (live)
         {
-            float x[8];
-            #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = (float)to_acc(tile[(8 * cg + j) * kLdsStride + swz(8 * cg + j, pl)]);
+            const float4 s0 = *reinterpret_cast<const float4*>(sc + 8 * cg), s1 = *reinterpret_cast<const float4*>(sc + 8 * cg + 4);
+            const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
             Vec16<T> out;
             #pragma unroll
-            for (int j = 0; j < 8; j++)
-            {
-                const float s = (a.scale && cc + j < cSrc) ? a.scale[n * cSrc + cc + j] : 1.0f;
-                out.v[j] = from_acc<T>(x[j] * s);
-            }
-            int64_t dp = n * a.hw + p;
-            if (a.srcW > 0)
-            {
-                const int y = p / a.srcW, x = p - y * a.srcW;
-                dp = n * a.dstHW + (int64_t)(y + a.offY) * a.dstW + (x + a.offX);
-            }
+            for (int j = 0; j < 8; j++) out.v[j] = from_acc<T>(x[j] * sv[j]);
             store_vec16<T>((T*)a.dst + dp * (int64_t)a.cNhwc + cc, out);
-            if (a.partial && cc < a.cOth)
+        }
+        if (RED)
+        {
+            float d[8];
+            #pragma unroll
+            for (int j = 0; j < 8; j++) d[j] = 0.0f;
+            if (live && cc < a.cOth)
             {
                 const Vec16<T> o = load_vec16<T>((const T*)a.othA + (n * a.hw + p) * (int64_t)a.cOth + cc);
                 #pragma unroll
-                for (int j = 0; j < 8; j++) dot[j] += x[j] * (float)to_acc(o.v[j]);
+                for (int j = 0; j < 8; j++) d[j] = x[j] * (float)to_acc(o.v[j]);
             }
+            #pragma unroll
+            for (int j = 0; j < 8; j++) red[(8 * cg + j) * 65 + pl] = d[j];
         }
     }
-    if (a.partial)
+    if (RED)
     {
-        // this thread: channels 8 cg .. 8 cg + 7, pixels (tid >> 3) and (tid >> 3) + 32 -> red[pixel slot][channel]
-        const int cg = tid & 7, slot = tid >> 3;
-        #pragma unroll
-        for (int j = 0; j < 8; j++) red[slot * kTile + 8 * cg + j] = dot[j];
         __syncthreads();
         if (tid < kTile && c0 + tid < cSrc)
         {
-            float s = 0.0f;
-            for (int k = 0; k < 32; k++) s += red[k * kTile + tid];            // fixed order
-            a.partial[(n * gridDim.x + blockIdx.x) * (int64_t)cSrc + c0 + tid] = s;
+            float t = 0.0f;
+            for (int k = 0; k < kTile; k++) t += red[tid * 65 + k];                // fixed order
+            a.partial[(n * gridDim.x + blockIdx.x) * (int64_t)cSrc + c0 + tid] = t;
         }
     }
+}
+
+// The border of the larger frames lvg_modconv2d_nchw_to_nhwc_padded writes into (everything but the src_h x src_w interior at
+// (off_y, off_x)): one thread per 16 bytes.
+template <class T>
+__global__ __launch_bounds__(256) void frame_border_zero_kernel(T* dst, int64_t total, int chunks, int border, int dstW, int dstHW, int offY, int offX,
+                                                                int srcH, int srcW, int cNhwc)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % chunks);
+    const int64_t r = idx / chunks;
+    int k = (int)(r % border);
+    const int64_t f = r / border;
+    const int top = offY * dstW, bot = dstHW - (offY + srcH) * dstW, side = dstW - srcW;
+    int pix;
+    if (k < top) pix = k;
+    else if (k - top < bot) pix = (offY + srcH) * dstW + (k - top);
+    else
+    {
+        k -= top + bot;
+        const int row = k / side, j = k - row * side;
+        pix = (offY + row) * dstW + (j < offX ? j : srcW + j);
+    }
+    Vec16<T> z;
+    #pragma unroll
+    for (int e = 0; e < 8; e++) z.v[e] = from_acc<T>(0.0f);
+    store_vec16<T>(dst + (f * dstHW + pix) * (int64_t)cNhwc + 8 * ch, z);
 }
 
 template <class T>
@@ -241,31 +301,32 @@ int check_common(const char* what, int64_t n, int64_t hw, int dtype)
 
 static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream,
-                               int src_w, int dst_h, int dst_w, int off_y, int off_x);
+                               int src_w, int dst_h, int dst_w, int off_y, int off_x, int zero_border);
 
 extern "C" int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                           int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream)
 {
-    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, hw, c_a, c_b, c_dst, c_oth, dtype, stream, 0, 0, 0, 0, 0);
+    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, hw, c_a, c_b, c_dst, c_oth, dtype, stream, 0, 0, 0, 0, 0, 0);
 }
 
 // The same pass writing into the interior of a larger channels-last frame [n][dst_h][dst_w][c_dst] at (off_y, off_x): source planes are
-// src_h x src_w (hw = src_h * src_w). The caller zero-fills `dst` beforehand (border pixels and nothing else keep that zero). `oth` /
-// `partial` (the reduction partner, dense frames of hw pixels) as in lvg_modconv2d_nchw_to_nhwc.
+// src_h x src_w (hw = src_h * src_w). zero_border != 0: the border pixels are zero-filled here (every byte of dst is then written:
+// the caller may pass uninitialised memory); 0: the border is not touched (the caller zero-filled dst). `oth` / `partial` (the
+// reduction partner, dense frames of hw pixels) as in lvg_modconv2d_nchw_to_nhwc.
 extern "C" int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                                  int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
-                                                 int dst_h, int dst_w, int off_y, int off_x, int dtype, void* stream)
+                                                 int dst_h, int dst_w, int off_y, int off_x, int zero_border, int dtype, void* stream)
 {
     LVG_REQUIRE(src_h >= 1 && src_w >= 1 && off_y >= 0 && off_x >= 0 && dst_h >= src_h + off_y && dst_w >= src_w + off_x,
                 "modconv2d_nchw_to_nhwc_padded: the source plane must fit inside the destination frame");
     LVG_REQUIRE((int64_t)dst_h * dst_w <= 0x3fffffffLL, "modconv2d_nchw_to_nhwc_padded: destination frame too large");
     return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, (int64_t)src_h * src_w, c_a, c_b, c_dst, c_oth, dtype, stream,
-                               src_w, dst_h, dst_w, off_y, off_x);
+                               src_w, dst_h, dst_w, off_y, off_x, zero_border);
 }
 
 static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream,
-                               int src_w, int dst_h, int dst_w, int off_y, int off_x)
+                               int src_w, int dst_h, int dst_w, int off_y, int off_x, int zero_border)
 {
     if (int rc = check_common("modconv2d_nchw_to_nhwc", n, hw, dtype)) return rc;
     LVG_REQUIRE(src_a && dst && c_a >= 1 && c_b >= 0 && (c_b == 0 || src_b), "modconv2d_nchw_to_nhwc: bad sources");
@@ -279,8 +340,22 @@ static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float
     a.srcW = src_w; a.dstW = dst_w; a.dstHW = dst_h * dst_w; a.offY = off_y; a.offX = off_x;
     a.vecP = (hw % 8 == 0) && lvg_aligned16(src_a) && (!src_b || lvg_aligned16(src_b));
     dim3 grid((unsigned)lvg_ceil_div(hw, kTile), (unsigned)lvg_ceil_div(c_dst, kTile), (unsigned)n);
-    if (dtype == LVG_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else                  hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    a.invW = (src_w > 0 && hw < (1 << 22)) ? 1.0f / (float)src_w : 0.0f;
+    if (zero_border)
+    {
+        const int border = dst_h * dst_w - (int)hw;
+        const int chunks = c_dst / 8;
+        const int64_t total = (int64_t)n * border * chunks;
+        if (total > 0)
+        {
+            const unsigned blocks = (unsigned)lvg_ceil_div(total, 256);
+            const int src_h = (int)(hw / src_w);
+            if (dtype == LVG_F16) hipLaunchKernelGGL(frame_border_zero_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (f16_t*)dst, total, chunks, border, dst_w, dst_h * dst_w, off_y, off_x, src_h, src_w, c_dst);
+            else                  hipLaunchKernelGGL(frame_border_zero_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, total, chunks, border, dst_w, dst_h * dst_w, off_y, off_x, src_h, src_w, c_dst);
+        }
+    }
+    if (dtype == LVG_F16) { if (partial) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a); else hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a); }
+    else                  { if (partial) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a); else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a); }
     return lvg_check_launch("modconv2d_nchw_to_nhwc");
 }
 

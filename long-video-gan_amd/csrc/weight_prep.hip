@@ -161,6 +161,99 @@ __global__ __launch_bounds__(kPrepThreads) void weight_prep_backward_kernel(Prep
     }
 }
 
+// ---- RMS-normalised weights of the 2-D modulated convolution (reference model/generator_sres.py:50-58) ------------------------------
+//     w' = w * rsqrt(mean over (ci, taps) of w^2) * scale          scale = 1 / sqrt(fan_in) on the 16-bit layers
+//     w2[co, ci] = sum over the taps of w'^2                        (the weight half of the demodulation term)
+//     wp = w' in the compute dtype, [taps][co_pad][ci_pad] with zero-filled padding: what lvg_conv2d_frames consumes
+// One workgroup per (padded) output channel, the channel's weights in LDS between the statistic and the output sweep.
+struct Prep2dArgs
+{
+    const float* w;        // [Co][Ci][taps]
+    void*        wp;       // [taps][coPad][ciPad] 16-bit
+    float*       w2;       // [Co][Ci]
+    float*       stat;     // [Co]: rsqrt(mean w^2)
+    const float* g;        // backward: gradient of wp's elements, float32 [taps][coPad][ciPad], or NULL
+    const float* gw2;      // backward: gradient of w2 [Co][Ci], or NULL
+    float*       dw;       // backward: [Co][Ci][taps]
+    int          Co, Ci, taps, coPad, ciPad;
+    float        scale;
+};
+
+template <class T>
+__global__ __launch_bounds__(kPrepThreads) void weight_prep2d_kernel(Prep2dArgs p)
+{
+    extern __shared__ float lds[];
+    __shared__ float red[kPrepThreads / 64];
+    const int co = blockIdx.x;
+    T* wp = static_cast<T*>(p.wp);
+    if (co >= p.Co)                                                   // padding rows
+    {
+        for (int t = 0; t < p.taps; t++)
+            for (int ci = threadIdx.x; ci < p.ciPad; ci += kPrepThreads) wp[((int64_t)t * p.coPad + co) * p.ciPad + ci] = from_acc<T>(0.0f);
+        return;
+    }
+    const int n = p.Ci * p.taps;
+    const float* w = p.w + (int64_t)co * n;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += kPrepThreads)
+    {
+        const float v = w[i];
+        lds[i] = v;
+        ss = fmaf(v, v, ss);
+    }
+    ss = block_sum(ss, red);                                          // (also publishes lds)
+    const float a = 1.0f / sqrtf(ss / (float)n);
+    if (threadIdx.x == 0) p.stat[co] = a;
+    for (int ci = threadIdx.x; ci < p.ciPad; ci += kPrepThreads)
+    {
+        float sq = 0.f;
+        for (int t = 0; t < p.taps; t++)
+        {
+            float v = 0.f;
+            if (ci < p.Ci)
+            {
+                v = __fmul_rn(__fmul_rn(lds[ci * p.taps + t], a), p.scale);
+                asm volatile("" : "+v"(v));       // keep the float32 product (no fused multiply + conversion: one rounding each, as the tensor expressions)
+                sq = fmaf(v, v, sq);
+            }
+            wp[((int64_t)t * p.coPad + co) * p.ciPad + ci] = from_acc<T>(v);
+        }
+        if (ci < p.Ci) p.w2[(int64_t)co * p.Ci + ci] = sq;
+    }
+}
+
+// d w from G = g + 2 w' g_w2 (either part may be absent):  d w_k = scale a G_k - (scale a^3 / n) (sum_i G_i w_i) w_k,  a = rsqrt(mean w^2)
+__global__ __launch_bounds__(kPrepThreads) void weight_prep2d_backward_kernel(Prep2dArgs p)
+{
+    extern __shared__ float lds[];                                   // [0, n): the channel's weights; [n, 2n): its combined gradient
+    __shared__ float red[kPrepThreads / 64];
+    const int co = blockIdx.x;
+    const int n = p.Ci * p.taps;
+    float* wbuf = lds;
+    float* gbuf = lds + n;
+    const float* w = p.w + (int64_t)co * n;
+    for (int i = threadIdx.x; i < n; i += kPrepThreads) wbuf[i] = w[i];
+    __syncthreads();
+    const float a = p.stat[co];
+    float dot = 0.f;
+    for (int ci = threadIdx.x; ci < p.Ci; ci += kPrepThreads)
+    {
+        const float gq = p.gw2 ? 2.f * p.gw2[(int64_t)co * p.Ci + ci] * a * p.scale : 0.f;
+        for (int t = 0; t < p.taps; t++)
+        {
+            const int i = ci * p.taps + t;
+            const float wv = wbuf[i];
+            const float G = (p.g ? p.g[((int64_t)t * p.coPad + co) * p.ciPad + ci] : 0.f) + gq * wv;
+            gbuf[i] = G;
+            dot = fmaf(G, wv, dot);
+        }
+    }
+    dot = block_sum(dot, red);
+    const float k1 = p.scale * a, k2 = p.scale * a * a * a * dot / (float)n;
+    float* dw = p.dw + (int64_t)co * n;
+    for (int i = threadIdx.x; i < n; i += kPrepThreads) dw[i] = k1 * gbuf[i] - k2 * wbuf[i];      // coalesced
+}
+
 // wp [taps][Co][Ci] -> wt [taps][Ci][Co] with the tap order reversed: the weight of the data-gradient convolution (mirrored taps,
 // channel roles swapped) in the layout conv3d_igemm.hip consumes. 64 x 64 tiles through LDS, 16-bit elements moved as raw words.
 __global__ __launch_bounds__(256) void weight_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t* __restrict__ wt, int taps, int Co, int Ci)
@@ -242,4 +335,51 @@ extern "C" int lvg_weight_prep_backward(const float* w, const float* amax, const
         return lvg_check_launch("weight_prep_backward");
     };
     return dtype == LVG_BF16 ? launch(weight_prep_backward_kernel<bf16_t>) : launch(weight_prep_backward_kernel<f16_t>);
+}
+
+extern "C" int lvg_weight_prep2d(const float* w, void* wp, void* wt, float* w2, float* stat, int co, int ci, int taps, int co_pad, int ci_pad,
+                                 float scale, int dtype, void* stream)
+{
+    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "weight_prep2d: float16 / bfloat16 output only (dtype %d)", dtype);
+    LVG_REQUIRE(co > 0 && ci > 0 && taps > 0 && taps <= 65535 && co_pad >= co && ci_pad >= ci && w && wp && w2 && stat, "weight_prep2d: empty input");
+    const size_t lds = (size_t)ci * taps * sizeof(float);
+    LVG_REQUIRE(lds <= 150 * 1024, "weight_prep2d: %d x %d elements per output channel: no kernel", ci, taps);
+    Prep2dArgs a = {};
+    a.w = w; a.wp = wp; a.w2 = w2; a.stat = stat; a.Co = co; a.Ci = ci; a.taps = taps; a.coPad = co_pad; a.ciPad = ci_pad; a.scale = scale;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto kern) -> int
+    {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            lvg_set_error("weight_prep2d: cannot opt in to %zu bytes of LDS", lds);
+            return LVG_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3(co_pad), dim3(kPrepThreads), lds, s, a);
+        return lvg_check_launch("weight_prep2d");
+    };
+    if (int rc = dtype == LVG_BF16 ? launch(weight_prep2d_kernel<bf16_t>) : launch(weight_prep2d_kernel<f16_t>)) return rc;
+    if (wt) return lvg_weight_dgrad_pack(wp, wt, taps, co_pad, ci_pad, stream);
+    return LVG_OK;
+}
+
+extern "C" int lvg_weight_prep2d_backward(const float* w, const float* stat, const float* g, const float* g_w2, float* dw,
+                                          int co, int ci, int taps, int co_pad, int ci_pad, float scale, void* stream)
+{
+    LVG_REQUIRE(co > 0 && ci > 0 && taps > 0 && co_pad >= co && ci_pad >= ci && w && stat && dw && (g || g_w2), "weight_prep2d_backward: empty input");
+    const size_t lds = 2 * (size_t)ci * taps * sizeof(float);
+    LVG_REQUIRE(lds <= 150 * 1024, "weight_prep2d_backward: %d x %d elements per output channel: no kernel", ci, taps);
+    Prep2dArgs a = {};
+    a.w = w; a.stat = const_cast<float*>(stat); a.g = g; a.gw2 = g_w2; a.dw = dw;
+    a.Co = co; a.Ci = ci; a.taps = taps; a.coPad = co_pad; a.ciPad = ci_pad; a.scale = scale;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(weight_prep2d_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        lvg_set_error("weight_prep2d_backward: cannot opt in to %zu bytes of LDS", lds);
+        return LVG_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(weight_prep2d_backward_kernel, dim3(co), dim3(kPrepThreads), lds, static_cast<hipStream_t>(stream), a);
+    return lvg_check_launch("weight_prep2d_backward");
 }

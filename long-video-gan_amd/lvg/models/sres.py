@@ -34,7 +34,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import torch_utils.distributed as dist_utils
-from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, modconv2d_layout, upfirdn2d
+from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, modconv2d_layout, upfirdn2d, weight_prep
 
 from .lres import FullyConnectedLayer, _linear_filter
 
@@ -42,6 +42,7 @@ from .lres import FullyConnectedLayer, _linear_filter
 # prologue / epilogue of torch_utils.ops.modconv2d_layout. LVG_SRES_CHANNELS_LAST=0 keeps the NCHW convolution.
 SIDE_STREAM_TERMS = os.environ.get('LVG_SRES_SIDE_STREAM_TERMS', '1') == '1'     # weight / style side of the generator layers on a second stream
 CHANNELS_LAST = os.environ.get('LVG_SRES_CHANNELS_LAST', '1') == '1'
+WEIGHT_PREP = os.environ.get('LVG_SRES_WEIGHT_PREP', '1') == '1'             # weight side of the 16-bit 3 x 3 layers in one launch each way (lvg_weight_prep2d)
 
 SQRT_HALF = math.sqrt(0.5)
 
@@ -237,6 +238,14 @@ class SynthesisLayer(nn.Module):
         style = self.affine(w)
         if self.is_torgb:
             style = style * (1 / math.sqrt(self.in_channels * self.conv_kernel ** 2))
+        if (WEIGHT_PREP and low_precision and not self.is_torgb and self.conv_kernel == 3 and modconv2d_layout.HAND_CONV and CHANNELS_LAST
+                and weight_prep.supported2d(self.weight, self.compute_dtype)):
+            # the weight side (normalisation, 1 / sqrt(fan_in), energy, cast, packing for both convolutions) in one launch each way
+            fan_in = self.in_channels * self.conv_kernel ** 2
+            prepared = weight_prep.prepare2d(self.weight, 1.0 / math.sqrt(fan_in), self.compute_dtype)
+            style = style * style.square().mean().rsqrt()
+            demod = torch.matmul(style.square(), prepared.energy.t()).add(1e-8 / fan_in).rsqrt()
+            return prepared, style, demod
         return modulation_terms2d(self.weight, style, demodulate=not self.is_torgb, input_gain=None, low_precision=low_precision)
 
     def forward(self, x: Optional[torch.Tensor], w: torch.Tensor, force_fp32: bool = False, update_emas: bool = False,
@@ -381,9 +390,10 @@ class SynthesisNetwork(nn.Module):
                 return None
             out, ev = ready[i]
             main.wait_event(ev)
-            for tensor in out:
-                if tensor is not None:
-                    tensor.record_stream(main)
+            for item in out:
+                for tensor in (item.tensors() if isinstance(item, weight_prep.Prepared2d) else (item,)):
+                    if tensor is not None:
+                        tensor.record_stream(main)
             return out
         return get
 

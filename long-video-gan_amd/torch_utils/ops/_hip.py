@@ -51,11 +51,13 @@ _SIGNATURES = {
     'lvg_video_from_uint8': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nchw_to_nhwc': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nhwc_to_nchw': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
-    'lvg_modconv2d_nchw_to_nhwc_padded': [_vp] * 6 + [_i64] + [_i32] * 11 + [_vp],
+    'lvg_modconv2d_nchw_to_nhwc_padded': [_vp] * 6 + [_i64] + [_i32] * 12 + [_vp],
     'lvg_conv2d_frames_workgroups': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames': [_vp] * 4 + [_i64] + [_i32] * 10 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_conv2d_frames_wgrad_splits': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames_wgrad': [_vp] * 3 + [_i64] + [_i32] * 8 + [_i64, _i64, _i32, _i32, _vp],
+    'lvg_weight_prep2d': [_vp] * 5 + [_i32] * 5 + [_f32, _i32, _vp],
+    'lvg_weight_prep2d_backward': [_vp] * 5 + [_i32] * 5 + [_f32, _vp],
     'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
     'lvg_tapconv_epilogue_backward': [_vp] * 10 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
 }

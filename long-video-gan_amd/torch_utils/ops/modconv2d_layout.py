@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import _hip
 from . import conv2d_frames
+from . import weight_prep
 
 HAND_CONV = os.environ.get('LVG_SRES_HAND_CONV', '1') != '0'     # 3 x 3 layers on csrc/conv2d_igemm.hip / conv2d_wgrad.hip (0: the library convolution)
 
@@ -57,9 +58,10 @@ def _nchw_to_nhwc(src_a, src_b, scale, c_dst, oth=None):
     return dst, partial
 
 
-def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None):
-    """cat(src_a, src_b) * scale -> the interior of the (zero-filled) frames dst [N, Hd, Wd, C] at `offset`; -> partial or None
-    (partial[n, tile, c] = sum over the 64 pixels of tile of src[n, c, p] * oth[n, p, c], oth [N, H, W, c_oth] dense frames)."""
+def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None, zero_border=False):
+    """cat(src_a, src_b) * scale -> the interior of the frames dst [N, Hd, Wd, C] at `offset`; -> partial or None
+    (partial[n, tile, c] = sum over the 64 pixels of tile of src[n, c, p] * oth[n, p, c], oth [N, H, W, c_oth] dense frames).
+    zero_border: the border pixels of dst are zero-filled by the call (dst may be torch.empty); else dst comes zero-filled."""
     n, c_a, h, w = src_a.shape
     c_b = 0 if src_b is None else src_b.shape[1]
     _, hd, wd, c_dst = dst.shape
@@ -67,6 +69,8 @@ def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None):
     if src_a.device.type != 'cuda':
         src = src_a if src_b is None else torch.cat((src_a, src_b), dim=1)
         val = src.float() if scale is None else src.float() * scale[:, :, None, None]
+        if zero_border:
+            dst.zero_()
         dst[:, offset[0]:offset[0] + h, offset[1]:offset[1] + w, :c_a + c_b] = val.permute(0, 2, 3, 1).to(dst.dtype)
         if oth is None:
             return None
@@ -79,7 +83,7 @@ def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None):
         rc = _hip.lib().lvg_modconv2d_nchw_to_nhwc_padded(
             src_a.data_ptr(), None if src_b is None else src_b.data_ptr(), None if scale is None else scale.data_ptr(),
             None if oth is None else oth.data_ptr(), dst.data_ptr(), None if partial is None else partial.data_ptr(),
-            n, h, w, c_a, c_b, c_dst, 0 if oth is None else oth.shape[3], hd, wd, offset[0], offset[1],
+            n, h, w, c_a, c_b, c_dst, 0 if oth is None else oth.shape[3], hd, wd, offset[0], offset[1], 1 if zero_border else 0,
             _hip.dtype_code(src_a.dtype), _hip.stream(src_a.device))
     _hip.check(rc, 'modconv2d_nchw_to_nhwc_padded')
     return partial
@@ -178,7 +182,10 @@ class _ModConv2dHand(torch.autograd.Function):
     One autograd node: every intermediate frame has the geometry the kernels want (conv2d_frames.Geometry)."""
 
     @staticmethod
-    def forward(ctx, first, second, weight, mod, demod, padding):
+    def forward(ctx, first, second, weight, mod, demod, padding, prepared=None):
+        """`weight` [Co, Ci, 3, 3]: the weight the convolution runs with (cast to the activations' dtype here) -- or, with `prepared`
+        (weight_prep.Prepared2d: normalised, cast and packed by lvg_weight_prep2d), the float32 MASTER weight, whose gradient then
+        includes the normalisation."""
         first, mod = first.contiguous(), mod.float().contiguous()
         second = None if second is None else second.contiguous()
         demod = None if demod is None else demod.float().contiguous()
@@ -187,13 +194,18 @@ class _ModConv2dHand(torch.autograd.Function):
         assert ci == c_first + (0 if second is None else second.shape[1]) and tuple(weight.shape[2:]) == (3, 3)
         geo = conv2d_frames.Geometry(h, w, padding)
         ci_pad, co_pad = conv2d_frames.round_up(ci, conv2d_frames.CH), conv2d_frames.round_up(co, conv2d_frames.CH)
-        xp = torch.zeros([n, geo.hx, geo.wx, ci_pad], dtype=first.dtype, device=first.device)
-        _nchw_to_nhwc_padded(first, second, mod, xp, (2, 2))
+        xp = torch.empty([n, geo.hx, geo.wx, ci_pad], dtype=first.dtype, device=first.device)
+        _nchw_to_nhwc_padded(first, second, mod, xp, (2, 2), zero_border=True)
         alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work of each of the three contractions
-        y = conv2d_frames.conv2d_valid(xp, conv2d_frames.pack_weight(weight, first.dtype, ci_pad, co_pad), geo.ho, geo.wo, offset=(geo.q, geo.q), alg_flops=alg)
+        if prepared is not None:
+            assert prepared.wp.shape == (3, 3, co_pad, ci_pad) and prepared.wp.dtype == first.dtype
+            wp = prepared.wp
+        else:
+            wp = conv2d_frames.pack_weight(weight, first.dtype, ci_pad, co_pad)
+        y = conv2d_frames.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), alg_flops=alg)
         out, _ = _frames_to_nchw(y, demod, co)
         ctx.save_for_backward(first, second, mod, demod, xp, y, weight)
-        ctx.geo, ctx.alg = geo, alg
+        ctx.geo, ctx.alg, ctx.prepared = geo, alg, prepared
         return out
 
     @staticmethod
@@ -207,19 +219,22 @@ class _ModConv2dHand(torch.autograd.Function):
         ci_pad, co_pad = xp.shape[3], y.shape[3]
         need_first, need_weight, need_mod, need_demod = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3], demod is not None and ctx.needs_input_grad[4]
         # gradient frames: d_out * demod at (q, q) of the zero-filled patch-aligned frame; d demod = sum d_out * y from the same pass
-        dyp = torch.zeros([n, geo.hd, geo.wd, co_pad], dtype=first.dtype, device=first.device)
-        partial = _nchw_to_nhwc_padded(d_out.contiguous(), None, demod, dyp, (geo.q, geo.q), oth=y if need_demod else None)
+        dyp = torch.empty([n, geo.hd, geo.wd, co_pad], dtype=first.dtype, device=first.device)
+        partial = _nchw_to_nhwc_padded(d_out.contiguous(), None, demod, dyp, (geo.q, geo.q), oth=y if need_demod else None, zero_border=True)
         d_demod = partial.sum(dim=1) if need_demod else None
         d_weight = None
+        prepared = ctx.prepared
         if need_weight:
             gw = conv2d_frames.conv2d_wgrad(xp, dyp, alg_flops=ctx.alg)                # [3, 3, co_pad, ci_pad] float32
-            d_weight = gw[:, :, :co, :ci].permute(2, 3, 0, 1).to(weight.dtype)
+            d_weight = prepared.grad_from_conv(gw) if prepared is not None else gw[:, :, :co, :ci].permute(2, 3, 0, 1).to(weight.dtype)
         d_first = d_mod = None
         if need_first or need_mod:
-            dxp = conv2d_frames.conv2d_valid(dyp, conv2d_frames.pack_weight_dgrad(weight, first.dtype, ci_pad, co_pad), geo.h, geo.w, alg_flops=ctx.alg)
+            wt = prepared.wt if prepared is not None and prepared.wt is not None else \
+                conv2d_frames.pack_weight_dgrad(weight if prepared is None else prepared.wp[:, :, :co, :ci].permute(2, 3, 0, 1), first.dtype, ci_pad, co_pad)
+            dxp = conv2d_frames.conv2d_valid(dyp, wt, geo.h, geo.w, alg_flops=ctx.alg)
             d_first, partial = _frames_to_nchw(dxp, mod[:, :c_first].contiguous(), c_first, oth_a=first if need_mod else None, oth_b=second if need_mod else None)
             d_mod = partial.sum(dim=1) if need_mod else None
-        return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None
+        return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None, None
 
 
 # Split forms of a float32 operand (conv2d_frames.split16 / conv3d_frames.split_bf16x3) and the partial products kept:
@@ -356,9 +371,15 @@ def supported(x, cond):
 
 
 def modulated_conv2d(x, cond, weight, mod, demod, padding=0):
-    """x [N, C1, H, W] or None, cond [N, C2, H, W] (same dtype), weight [Co, C1 + C2, k, k] (any float dtype),
+    """x [N, C1, H, W] or None, cond [N, C2, H, W] (same dtype), weight [Co, C1 + C2, k, k] (any float dtype) or a
+    weight_prep.Prepared2d (3 x 3 weights normalised / cast / packed by one launch: hand-written route only),
     mod float32 [N, C1 + C2], demod float32 [N, Co] or None. Returns NCHW [N, Co, H', W'] in x's dtype."""
     first, second = (cond, None) if x is None else (x, cond)
+    if isinstance(weight, weight_prep.Prepared2d):
+        assert supported(x, cond) and hand_conv_supported(first, weight.weight) and 0 <= padding <= 2, 'prepared weights: hand-written route only'
+        if second is not None and second.dtype != first.dtype:
+            second = second.to(first.dtype)
+        return _ModConv2dHand.apply(first, second, weight.weight, mod, demod, padding, weight)
     if split_conv_supported(first, weight) and 0 <= padding <= 2:
         return _ModConv2dSplit.apply(first, None if second is None else second.to(first.dtype), weight, mod, demod, padding)
     if not supported(x, cond):

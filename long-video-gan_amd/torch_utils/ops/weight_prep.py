@@ -119,3 +119,90 @@ def weight_prep(weight, scale, normalize, dtype, want_w2=True):
             w16._lvg_dgrad = dgrad_pack(w16.detach())
         return w16, w2
     return _ref(weight, scale, normalize, dtype, want_w2)
+
+
+# ---- 2-D modulated convolution of the super-resolution generator (RMS normalisation; csrc/weight_prep.hip, lvg_weight_prep2d) ----------
+
+def _ref2d(weight, scale):
+    """(w', energy): w' = w * rsqrt(mean w^2 per output channel) * scale, energy[co, ci] = sum over the taps of w'^2
+    (reference model/generator_sres.py:50-58, with the 1 / sqrt(fan_in) of the 16-bit layers folded in as `scale`)."""
+    w = weight * weight.square().mean(dim=(1, 2, 3), keepdim=True).rsqrt()
+    w = w * scale
+    return w, w.square().sum(dim=(2, 3))
+
+
+class Prepared2d:
+    """Weight of one 3 x 3 modulated convolution prepared for the hand-written kernels: `weight` the float32 master [Co, Ci, 3, 3], `wp`
+    [3, 3, co_pad, ci_pad] / `wt` [3, 3, ci_pad, co_pad] (or None) the normalised 16-bit weight for the forward / data-gradient
+    convolution, `stat` [Co] the normalisation factor, `energy` [Co, Ci] float32 (differentiable w.r.t. `weight`), `scale`."""
+
+    def __init__(self, weight, wp, wt, stat, energy, scale):
+        self.weight, self.wp, self.wt, self.stat, self.energy, self.scale = weight, wp, wt, stat, energy, scale
+
+    def tensors(self):
+        return (self.wp, self.wt, self.stat, self.energy)
+
+    def grad_from_conv(self, gw):
+        """d weight through the convolution: gw = gradient of wp's elements, float32 [3, 3, co_pad, ci_pad] (lvg_conv2d_frames_wgrad)."""
+        return _prep2d_backward(self.weight.detach(), self.stat, gw, None, self.scale, self.wp.shape[2], self.wp.shape[3])
+
+
+def _prep2d_backward(w, stat, g, g_w2, scale, co_pad, ci_pad):
+    co, ci = w.shape[:2]
+    taps = w.shape[2] * w.shape[3]
+    w = w.contiguous()
+    dw = torch.empty_like(w)
+    g = None if g is None else g.contiguous()
+    g_w2 = None if g_w2 is None else g_w2.contiguous().float()
+    assert g is None or (g.dtype == torch.float32 and g.shape == (w.shape[2], w.shape[3], co_pad, ci_pad))
+    with torch.cuda.device(w.device):
+        rc = _hip.lib().lvg_weight_prep2d_backward(w.data_ptr(), stat.data_ptr(), _hip.ptr(g), _hip.ptr(g_w2), dw.data_ptr(), co, ci, taps, co_pad, ci_pad,
+                                                   scale, _hip.stream(w.device))
+    _hip.check(rc, 'weight_prep2d_backward')
+    return dw
+
+
+class _WeightPrep2d(torch.autograd.Function):
+    """weight -> energy (differentiable) with the packed 16-bit weights and the statistic as non-differentiable by-products of the same launch."""
+
+    @staticmethod
+    def forward(ctx, weight, scale, dtype, co_pad, ci_pad, want_dgrad):
+        w = weight.contiguous()
+        co, ci, kh, kw = w.shape
+        wp = torch.empty([kh, kw, co_pad, ci_pad], dtype=dtype, device=w.device)
+        wt = torch.empty([kh, kw, ci_pad, co_pad], dtype=dtype, device=w.device) if want_dgrad else None
+        energy = torch.empty([co, ci], dtype=torch.float32, device=w.device)
+        stat = torch.empty([co], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            rc = _hip.lib().lvg_weight_prep2d(w.data_ptr(), wp.data_ptr(), _hip.ptr(wt), energy.data_ptr(), stat.data_ptr(), co, ci, kh * kw, co_pad, ci_pad,
+                                              scale, _hip.dtype_code(dtype), _hip.stream(w.device))
+        _hip.check(rc, 'weight_prep2d')
+        ctx.save_for_backward(w, stat)
+        ctx.cfg = (scale, co_pad, ci_pad)
+        if wt is None:
+            wt = torch.empty([0], dtype=dtype, device=w.device)
+        ctx.mark_non_differentiable(wp, wt, stat)
+        return energy, wp, wt, stat
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_energy, _g_wp, _g_wt, _g_stat):
+        w, stat = ctx.saved_tensors
+        scale, co_pad, ci_pad = ctx.cfg
+        return _prep2d_backward(w, stat, None, g_energy, scale, co_pad, ci_pad), None, None, None, None, None
+
+
+def supported2d(weight, dtype):
+    if weight.device.type != 'cuda' or weight.dtype != torch.float32 or dtype not in (torch.float16, torch.bfloat16) or weight.ndim != 4:
+        return False
+    return weight.shape[1] * weight.shape[2] * weight.shape[3] * 8 <= 150 * 1024 and _init()
+
+
+def prepare2d(weight, scale, dtype, pad=64):
+    """-> Prepared2d of a float32 master weight [Co, Ci, kh, kw] on the GPU (one launch; plus the data-gradient packing while gradients
+    are recorded). The channel counts of the packed weights are rounded up to multiples of `pad`."""
+    co, ci = weight.shape[:2]
+    co_pad, ci_pad = (co + pad - 1) // pad * pad, (ci + pad - 1) // pad * pad
+    want_dgrad = torch.is_grad_enabled()
+    energy, wp, wt, stat = _WeightPrep2d.apply(weight, float(scale), dtype, co_pad, ci_pad, want_dgrad)
+    return Prepared2d(weight, wp, wt if want_dgrad else None, stat, energy, float(scale))

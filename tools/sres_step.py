@@ -17,12 +17,34 @@ if os.environ.get('LVG_SRES_CL'):
 tr = SuperResTrainer(device='cuda', compute_dtype=torch.float16, augment_real_sign_target=None, augment_p_init=0.0,
                      in_augment_strength=0.0, lr_cond_prob=1.0, overlap_grad_sync=False, with_ema=False, **kw)
 lr = torch.rand(segments, 3, tr.context_seq_length, 36, 64, device='cuda') * 2 - 1
+import torch.nn.functional as F
 for _ in range(2):
     tr.update_G(lr)
 torch.cuda.synchronize()
+graph = None
+if os.environ.get('LVG_SRES_STEP_GRAPH', '1') == '1':          # the compute part replayed from a hipGraph, as bench.py's sres leg does
+    def compute():
+        tr.G.requires_grad_(True)
+        tr.G_sync.zero()
+        logits = tr.run_D(tr.crop_to_seq_length(lr), tr.G(lr))
+        F.softplus(-logits).mean().backward()
+        tr.G.requires_grad_(False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        compute()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        compute()
+    graph.replay(); tr.G_sync.finish(); tr.G_opt.step()
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
-    tr.update_G(lr)
+    if graph is not None:
+        graph.replay(); tr.G_sync.finish(); tr.G_opt.step()
+    else:
+        tr.update_G(lr)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps(dict(window_ms=dt * 1e3, steps=steps, ms_per_step=dt * 1e3 / steps, frames_per_s=segments * 8 * steps / dt)))
+print(json.dumps(dict(window_ms=dt * 1e3, steps=steps, ms_per_step=dt * 1e3 / steps, frames_per_s=segments * 8 * steps / dt, mode='hipgraph' if graph is not None else 'eager')))
