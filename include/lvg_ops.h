@@ -358,6 +358,11 @@ int lvg_weight_prep_backward(const float* w, const float* amax, const void* g, c
  * convolution (mirrored taps, channel roles swapped: what lvg_conv3d_frames takes as `w` when it is run on dy). */
 int lvg_weight_dgrad_pack(const void* wp, void* wt, int taps, int co, int ci, void* stream);
 
+/* out[plane] = sum of the hw elements of plane `plane` of a contiguous [planes][hw] tensor (float32 accumulation, fixed order):
+ * the per-(sample, channel) part of the bias gradient dx.sum([0, 2, 3]) of filtered_lrelu's backward pass
+ * (reference torch_utils/ops/filtered_lrelu.py:254); the caller adds the samples of a channel. */
+int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream);
+
 /*
  * Weight side of the 2-D modulated convolution of the super-resolution generator (reference model/generator_sres.py:50-58 and :63,
  * `weight.to(x.dtype)`) in one pass per direction (csrc/weight_prep.hip):

@@ -504,3 +504,59 @@ extern "C" int lvg_bias_act_grad_bias(const void* dy, const void* xref, const vo
         default:       return launch_dtype<double>(p, act, true, s);
     }
 }
+
+// ---- plane sums of a contiguous NCHW tensor: out[plane] = sum over the plane's hw elements (float32) --------------------------------
+// The bias gradient of filtered_lrelu's backward pass is dx.sum([0, 2, 3]) in the reference (filtered_lrelu.py:254): a tensor
+// reduction over channel planes. One workgroup per plane, 16-byte loads, fixed summation order (reproducible); the caller adds the
+// N sums of a channel.
+namespace {
+
+template <class T>
+__global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int hw, int vec)
+{
+    __shared__ float red[4];
+    const T* row = x + (int64_t)blockIdx.x * hw;
+    float s = 0.f;
+    constexpr int V = Elem<T>::kVec;
+    if (vec)
+    {
+        const int nv = hw / V;
+        float s2 = 0.f;
+        int i = threadIdx.x;
+        for (; i + 256 < nv; i += 512)                                // two independent 16-byte loads in flight per trip
+        {
+            const Vec16<T> a = load_vec16<T>(row + (int64_t)i * V), b = load_vec16<T>(row + (int64_t)(i + 256) * V);
+            #pragma unroll
+            for (int e = 0; e < V; e++) { s += (float)to_acc(a.v[e]); s2 += (float)to_acc(b.v[e]); }
+        }
+        if (i < nv)
+        {
+            const Vec16<T> a = load_vec16<T>(row + (int64_t)i * V);
+            #pragma unroll
+            for (int e = 0; e < V; e++) s += (float)to_acc(a.v[e]);
+        }
+        s += s2;
+        for (int j = nv * V + threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
+    }
+    else
+        for (int j = threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+} // namespace
+
+extern "C" int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
+{
+    LVG_REQUIRE(x && out && planes >= 1 && planes <= 0x7fffffffLL && hw >= 1 && hw <= 0x7fffffffLL, "plane_sum: bad sizes");
+    LVG_REQUIRE(dtype == LVG_F32 || dtype == LVG_F16 || dtype == LVG_BF16, "plane_sum: float32 / float16 / bfloat16 only (dtype %d)", dtype);
+    const int esz = dtype == LVG_F32 ? 4 : 2;
+    const int vec = lvg_aligned16(x) && (hw * esz) % 16 == 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LVG_F32)       hipLaunchKernelGGL(plane_sum_kernel<float>, dim3((unsigned)planes), dim3(256), 0, s, (const float*)x, out, (int)hw, vec);
+    else if (dtype == LVG_F16)  hipLaunchKernelGGL(plane_sum_kernel<f16_t>, dim3((unsigned)planes), dim3(256), 0, s, (const f16_t*)x, out, (int)hw, vec);
+    else                        hipLaunchKernelGGL(plane_sum_kernel<bf16_t>, dim3((unsigned)planes), dim3(256), 0, s, (const bf16_t*)x, out, (int)hw, vec);
+    return lvg_check_launch("plane_sum");
+}

@@ -1212,6 +1212,156 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_stream_kernel(UpfirdnArgs 
     }
 }
 
+// NHWC x2 DOWN-sampler through LDS (16-byte vectors): one workgroup walks a chunk of output rows of one frame. Every input row is
+// fetched from global memory ONCE, with fully coalesced 16-byte loads two rows ahead of its use, and staged in LDS; a thread owns
+// NO output vectors (column, channel vector) of the row, takes their four x taps out of LDS and keeps the y window in registers.
+// (The streaming form above issues 4 global loads per input row and output vector -- every input vector twice, from L1 / L2 --
+// and needs 134 VGPRs: 3 waves per SIMD.)
+template <class T, int NV, int NO>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_down2_lds_kernel(UpfirdnArgs p)
+{
+    typedef VecIO<T, 16> IO;
+    typedef uint4 Raw;                                                   // a 16-byte vector as stored
+    constexpr int V = IO::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+    Raw* lds = reinterpret_cast<Raw*>(smemRaw);                         // [2][rowVecs]
+    const int tid = threadIdx.x;
+    const int cvecs = p.c / V;
+    const int rowVecs = p.iw * cvecs;
+    const int chunk = blockIdx.x % p.rowChunks, nb = blockIdx.x / p.rowChunks;
+    const int oyBeg = chunk * p.chunkRows;
+    const int oyEnd = (oyBeg + p.chunkRows < p.oh) ? oyBeg + p.chunkRows : p.oh;
+
+    float fx[4], fy[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        fx[k] = (k < p.fw) ? (p.fx ? p.fx[p.flip ? k : p.fw - 1 - k] : 1.0f) : 0.0f;
+        fy[k] = (k < p.fh) ? (p.fy ? p.fy[p.flip ? k : p.fh - 1 - k] : 1.0f) : 0.0f;
+    }
+    const T* xp = (const T*)p.x + (int64_t)nb * p.xs[0];
+    T* yp = (T*)p.y + (int64_t)nb * p.ys[0];
+    const int xs2 = (int)p.xs[2], ys2 = (int)p.ys[2];
+
+    // this thread's output vectors: LDS index of the first x tap, which taps are inside the row
+    int tap0[NO]; unsigned tapOk[NO]; int outOff[NO];
+    #pragma unroll
+    for (int j = 0; j < NO; j++)
+    {
+        const int ov = tid + 256 * j;
+        const int ox = ov / cvecs, cv = ov - ox * cvecs;
+        const int ix0 = 2 * ox - p.padx0;
+        tap0[j] = ix0 * cvecs + cv;
+        tapOk[j] = 0;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) if (ix0 + k >= 0 && ix0 + k < p.iw) tapOk[j] |= 1u << k;
+        outOff[j] = ov * V;
+    }
+    Raw pre[2][NV];
+    // No execution-mask branches in the loop: rows outside the image are fetched from a clamped row and zeroed by a select, x taps
+    // outside the row are read from a clamped LDS index and zeroed the same way (a zero WEIGHT would turn an Inf next door into NaN).
+    auto fetch = [&](int iy, Raw (&dst)[NV])                           // global -> registers
+    {
+        const bool rowOk = iy >= 0 && iy < p.ih;
+        const T* row = xp + (int64_t)(rowOk ? iy : 0) * xs2;
+        #pragma unroll
+        for (int i = 0; i < NV; i++)
+        {
+            const Raw r = *reinterpret_cast<const Raw*>(row + (int64_t)(tid + 256 * i) * V);
+            dst[i] = rowOk ? r : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stage = [&](int buf, const Raw (&src)[NV])                    // registers -> LDS
+    {
+        #pragma unroll
+        for (int i = 0; i < NV; i++) lds[buf * rowVecs + tid + 256 * i] = src[i];
+    };
+    auto hrow = [&](int buf, float (&h)[NO][V])                        // x taps of one staged row
+    {
+        #pragma unroll
+        for (int j = 0; j < NO; j++)
+        {
+            #pragma unroll
+            for (int i = 0; i < V; i++) h[j][i] = 0.0f;
+            #pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const bool ok = (tapOk[j] >> k) & 1u;
+                Raw r = lds[buf * rowVecs + (ok ? tap0[j] + k * cvecs : 0)];
+                r = ok ? r : make_uint4(0u, 0u, 0u, 0u);
+                typename IO::Raw t;
+                __builtin_memcpy(&t, &r, 16);
+                #pragma unroll
+                for (int i = 0; i < V; i++) h[j][i] = fmaf((float)to_acc(t.v[i]), fx[k], h[j][i]);
+            }
+        }
+    };
+    // rows come in pairs (a, a + 1): pair t = rows iy0 + 2 t, iy0 + 2 t + 1; pair 0 only fills the window, pair t >= 1 completes output row oyBeg + t - 1
+    const int iy0 = 2 * oyBeg - p.pady0;
+    const int pairs = oyEnd - oyBeg + 1;
+    float w[4][NO][V];
+    fetch(iy0, pre[0]); fetch(iy0 + 1, pre[1]);
+    for (int t = 0; t < pairs; t++)
+    {
+        const int a = iy0 + 2 * t;
+        stage(0, pre[0]); stage(1, pre[1]);
+        if (t + 1 < pairs) { fetch(a + 2, pre[0]); fetch(a + 3, pre[1]); }      // lands while this pair is filtered
+        __syncthreads();
+        hrow(0, w[2]); hrow(1, w[3]);
+        if (t > 0)
+        {
+            const int oy = oyBeg + t - 1;
+            #pragma unroll
+            for (int j = 0; j < NO; j++)
+            {
+                float acc[V];
+                #pragma unroll
+                for (int i = 0; i < V; i++)
+                {
+                    float s = 0.0f;
+                    #pragma unroll
+                    for (int k = 0; k < 4; k++) s = fmaf(w[k][j][i], fy[k], s);
+                    acc[i] = s;
+                }
+                IO::store(yp + (int64_t)oy * ys2 + outOff[j], acc, p.gain);
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j < NO; j++)
+            #pragma unroll
+            for (int i = 0; i < V; i++) { w[0][j][i] = w[2][j][i]; w[1][j][i] = w[3][j][i]; }
+        __syncthreads();                                                // the next pair overwrites both buffers
+    }
+}
+
+template <class T>
+int launch_nhwc_down2_lds(UpfirdnArgs& p, hipStream_t stream)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    const int cvecs = p.c / V;
+    const int64_t rowVecs = (int64_t)p.iw * cvecs, outVecs = (int64_t)p.ow * cvecs;
+    if (rowVecs > 1024 || outVecs > 512 || rowVecs % 256 || outVecs % 256) return LVG_ERR_UNSUPPORTED;      // whole rows per pass of the 256 threads
+    if (p.ys[3] != p.c || p.xs[3] != p.c || p.xs[2] != (int64_t)p.iw * p.c || p.ys[2] != (int64_t)p.ow * p.c) return LVG_ERR_UNSUPPORTED;   // dense rows
+    if ((int64_t)p.ih * p.xs[2] >= 0x7fffffffLL || (int64_t)p.oh * p.ys[2] >= 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    // row chunks: enough workgroups to fill the chip twice over, at least 8 output rows each (two halo rows per chunk)
+    int chunks = 1;
+    while ((int64_t)p.n * chunks < 2048 && (p.oh + chunks) / (chunks + 1) >= 8) chunks++;
+    p.chunkRows = (p.oh + chunks - 1) / chunks;
+    p.rowChunks = (p.oh + p.chunkRows - 1) / p.chunkRows;
+    const int64_t blocks = (int64_t)p.n * p.rowChunks;
+    if (blocks > 0x7fffffffLL) return LVG_ERR_UNSUPPORTED;
+    const size_t lds = 2 * (size_t)rowVecs * 16;
+    const int nv = (int)((rowVecs + 255) / 256), no = (int)((outVecs + 255) / 256);
+    #define LVG_DOWN2_LDS(NVv, NOv) hipLaunchKernelGGL((upfirdn2d_nhwc_down2_lds_kernel<T, NVv, NOv>), dim3((unsigned)blocks), dim3(256), lds, stream, p)
+    if (nv == 1 && no == 1)      LVG_DOWN2_LDS(1, 1);
+    else if (nv == 2 && no == 1) LVG_DOWN2_LDS(2, 1);
+    else if (nv == 4 && no == 1) LVG_DOWN2_LDS(4, 1);
+    else if (nv == 4 && no == 2) LVG_DOWN2_LDS(4, 2);
+    else return LVG_ERR_UNSUPPORTED;
+    #undef LVG_DOWN2_LDS
+    return lvg_check_launch("upfirdn2d_nhwc_down2_lds_kernel");
+}
+
 template <class T, int VB>
 int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
 {
@@ -1224,6 +1374,11 @@ int launch_nhwc_vb(UpfirdnArgs& p, hipStream_t stream)
         hipLaunchKernelGGL((upfirdn2d_nhwc_kernel<T, ux, uy, dx, dy, VB>), grid, block, 0, stream, p); return lvg_check_launch("upfirdn2d_nhwc_kernel"); }
     const bool up2 = p.upx == 2 && p.upy == 2 && p.downx == 1 && p.downy == 1;
     const bool down2 = p.upx == 1 && p.upy == 1 && p.downx == 2 && p.downy == 2;
+    if (down2 && VB == 16 && !getenv("LVG_UPFIRDN_NO_LDS"))
+    {
+        const int rc = launch_nhwc_down2_lds<T>(p, stream);
+        if (rc != LVG_ERR_UNSUPPORTED) return rc;
+    }
     if (up2 || down2)
     {
         // streaming form: enough lanes even for short frames thanks to row chunks of 16 output rows

@@ -6,6 +6,7 @@ roles of the filters swapped, reading that mask (:239-268), so gradients of any 
 Parameter combinations without a fused kernel take the generic path: upfirdn2d ->
 `lvg_filtered_lrelu_act` (in place, same mask format) -> upfirdn2d (:223-229)."""
 
+import os
 import warnings
 
 import numpy as np
@@ -193,6 +194,20 @@ def _act_inplace(y, si, sx, sy, gain, slope, clamp, write_signs):
     _hip.check(rc, 'filtered_lrelu_act_')
     return so
 
+def _bias_grad(dx):
+    """dx.sum([0, 2, 3]) (reference filtered_lrelu.py:254). Contiguous GPU tensors: one pass of plane sums (lvg_plane_sum, float32
+    accumulation, fixed order) and the sum over the samples, instead of the generic strided tensor reduction."""
+    if dx.is_cuda and dx.ndim == 4 and dx.is_contiguous() and dx.dtype in (torch.float32, torch.float16, torch.bfloat16) and dx.numel() > 0 \
+            and os.environ.get('LVG_FLRELU_PLANE_SUM', '1') == '1':
+        n, c, h, w = dx.shape
+        part = torch.empty([n, c], dtype=torch.float32, device=dx.device)
+        with torch.cuda.device(dx.device):
+            rc = _hip.lib().lvg_plane_sum(dx.data_ptr(), part.data_ptr(), n * c, h * w, _hip.dtype_code(dx.dtype), _hip.stream(dx.device))
+        _hip.check(rc, 'plane_sum')
+        return part.sum(0).to(dx.dtype)
+    return dx.sum([0, 2, 3])
+
+
 _filtered_lrelu_cuda_cache = dict()
 
 def _filtered_lrelu_cuda(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False):
@@ -279,7 +294,7 @@ def _filtered_lrelu_cuda(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cl
                 dx = _filtered_lrelu_cuda(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None, flip_filter=ff).apply(dy, fd, fu, None, si, sx, sy)
 
             if ctx.needs_input_grad[3]:
-                db = dx.sum([0, 2, 3])
+                db = _bias_grad(dx)
 
             return dx, None, None, db, None, None, None
 

@@ -188,3 +188,20 @@ def test_no_grad_writes_no_mask_and_torgb_1x1(oracle):
     y = filtered_lrelu.filtered_lrelu(x, None, None, b, up=1, down=1, gain=1, slope=1, clamp=256)
     assert y.grad_fn is None
     np.testing.assert_allclose(host(y), oracle.filtered_lrelu(host(x), None, None, host(b), gain=1, slope=1, clamp=256), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 5, 92, 148), (2, 7, 13, 9), (1, 1, 1, 1), (4, 64, 36, 64)])
+def test_bias_gradient_plane_sums(shape, dtype):
+    """filtered_lrelu's bias gradient dx.sum([0, 2, 3]) (reference filtered_lrelu.py:254) through lvg_plane_sum: float32 accumulation of
+    every plane, then the samples -- against the float64 sum of the same values."""
+    from torch_utils.ops import filtered_lrelu as fl
+    torch.manual_seed(5)
+    dx = torch.randn(shape, device='cuda').to(dtype)
+    got = fl._bias_grad(dx)
+    assert got.dtype == dtype and got.shape == (shape[1],)
+    want = dx.double().sum([0, 2, 3])
+    eps = {torch.float32: 2.0 ** -23, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
+    scale = dx.double().abs().sum([0, 2, 3])
+    assert ((got.double() - want).abs() <= eps * want.abs() + 2.0 ** -22 * scale + 1e-30).all()
