@@ -864,11 +864,12 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     constexpr int NI = ROWS / RPI;
     constexpr bool kLdsStore = !(kAbl & 512) && !OUTF;
     unsigned char* const stage = smem + wave * (ROWS * PITCH);
-    if constexpr (kLdsStore)
-    {
-        wait_vm_const<0>();                       // weight waves leave the K loop with re-staged tiles still in flight towards LDS
-        __syncthreads();
-    }
+    wait_vm_const<0>();                           // weight waves leave the K loop with re-staged tiles still in flight towards LDS: they must
+                                                  // have landed before the staging below reuses that LDS -- and, on the float32-output path that
+                                                  // stages nothing, before this wave can end (a workgroup that ends with LDS-DMA in flight lets the
+                                                  // late pieces land in the LDS of the NEXT workgroup on the CU: intermittent wrong tiles, measured
+                                                  // as a 1e-2 gradient error in one run out of two of the float32 model test)
+    if constexpr (kLdsStore) __syncthreads();
     const int flipW = (l31 >> 4) & 1;
     // 16-byte stores of the staged wave tile to `dst` (rows = pixels m0 + wr * ROWS + ..., this wave's channel range)
     auto flush = [&](T* dst) __attribute__((always_inline))

@@ -535,8 +535,11 @@ def pointwise_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     if POINTWISE_HAND and cl and not SECOND_ORDER and TAP_STACK and _hand_conv_takes(x, w2[:, :, None, None, None], (0, 0)):
         # forward and data gradient on the hand-written kernel (no zero-fill / cast helper launches), weight gradient on the library
         return _TapConvEpilogue.apply(x, w2[:, :, None, None, None], None, None, None, None, 1, (0, 0), 'linear', None, False)[0]
-    if POINTWISE_GEMM and cl:
-        return torch.matmul(x.permute(0, 2, 3, 1), w2.t()).permute(0, 3, 1, 2)      # views: [F, H, W, C] is the memory order
+    if (POINTWISE_GEMM or x.dtype == torch.float32) and cl:
+        # views: [F, H, W, C] is the memory order. float32 tensors ALWAYS take this form: the library's float32 channels-last 1 x 1
+        # convolution picks its backward-data algorithm by a timed search, and one of the candidates is 1e-2 off (measured: the gradient
+        # of the network input against float64 flips between 2e-4 and 9e-3 from run to run, profiles/r03_f32_grad_flaky.log)
+        return torch.matmul(x.permute(0, 2, 3, 1), w2.t()).permute(0, 3, 1, 2)
     return F.conv2d(x, _cl(w2[:, :, None, None]))
 
 

@@ -24,47 +24,114 @@ def _build(device):
     return G.to(device).requires_grad_(True), D.to(device).requires_grad_(True)
 
 
-def _run(device, rtol_grad):
-    g = load_golden('lres_models')
+def _pre_activation_spy(records):
+    """Patch of lres._TapConvEpilogue._backward that also records z = ysum * pre + b (+ res) of every activated call (the argument of the
+    leaky ReLU whose derivative the backward pass takes): returns the original to restore."""
+    from lvg.models import lres
+    orig = lres._TapConvEpilogue._backward
+
+    def spy(ctx, x, weight, ysum, pre, b, res, post, dout, wt_packed, need):
+        if ctx.cfg[2] != 'linear' and ysum is not None:
+            z = ysum.detach().double()
+            if pre is not None:
+                z = z * pre.detach().double().reshape(z.shape[0], -1, 1, 1)
+            if b is not None:
+                z = z + b.detach().double().reshape(1, -1, 1, 1)
+            if res is not None:
+                z = z + res.detach().double()
+            records.append(((tuple(x.shape), tuple(weight.shape)), z.cpu()))
+        return orig(ctx, x, weight, ysum, pre, b, res, post, dout, wt_packed, need)
+    lres._TapConvEpilogue._backward = staticmethod(spy)
+    return orig
+
+
+def _forward_backward(device, g, records=None):
+    """One generator + discriminator pass on the golden inputs -> (features' rms, video, logits, loss, the seven parameter gradients)."""
+    from lvg.models import lres
     G, D = _build(device)
+    orig = _pre_activation_spy(records) if records is not None else None
+    try:
+        noise = torch.tensor(g['noise'], device=device)
+        emb = G.temporal_emb.blur(noise)
+        ws = G.compute_latent_ws(emb, T)
+        feats = G.synthesize_video(G._temporal_input(ws), ws, T, return_features=True)
+        video = feats[-1]
+        rms = np.array([float(f.detach().float().square().mean().sqrt()) for f in feats])
+        logits = D(video)
+        loss = F.softplus(-logits).mean()
+        loss.backward()
+    finally:
+        if orig is not None:
+            lres._TapConvEpilogue._backward = staticmethod(orig)
+    pairs = dict(g_spatial_input=G.spatial_input, g_to_rgb_weight=G.to_rgb.weight, g_t0_bias_0=G.temporal_layers[0].bias_0,
+                 g_s3_weight_1=G.spatial_layers[3].weight_1, g_map_l1_bias=G.latent_mapping.layer_1.bias,
+                 d_b0_conv_vid_weight=D.blocks[0].conv_vid.weight, d_ep_linear_1_weight=D.epilogue.linear_1.weight)
+    grads = {k: p.grad.detach().double().cpu().numpy() for k, p in pairs.items()}
+    return (G, D), rms, video.detach().cpu().numpy(), logits.detach().cpu().numpy(), float(loss.detach()), grads
+
+
+def _gradient_errors(grads, golden):
+    return {k: float(np.abs(v - golden[k]).max() / (np.abs(golden[k]).max() + 1e-12)) for k, v in grads.items()}
+
+
+def _run(device, rtol_grad):
+    """Forward values and seven parameter gradients against the reference's float32 run (gate `rtol_grad` of each gradient's scale) and
+    against the reference run in float64 (tests/golden/make_golden_models_f64.py; gate 1e-3), where the reference's own float32 run sits at
+    5e-7 .. 1e-5. This repo's networks order the float32 arithmetic differently (modulation on the activations, demodulation on the output,
+    fused epilogues) and sit at 1e-6 .. 5e-4 on the CPU.
+
+    Leaky-ReLU kinks: this golden has pre-activations within 4e-8 .. 5e-7 (relative to the layer's maximum) of zero, one of them in the
+    104 k-element first block of the generator. Two correct float32 evaluations that round such an element to different sides of zero
+    differ by 9e-2 in that layer's gradients and 9e-3 in the gradient of the network input (measured between the library route and the
+    split-operand route on the hand-written kernels, profiles/r03_f32_kink_flips.log; the library's own timed algorithm search flips it from
+    run to run). So: the gates are checked as they stand; a GPU run that misses them passes only if (a) the library route of the same
+    device meets them and (b) every pre-activation whose sign differs between the two routes lies within 1e-6 of zero and at least one
+    does -- i.e. the deviation is the kink, not the arithmetic."""
+    g = load_golden('lres_models')
+    g64 = load_golden('lres_models_f64')
+    records = [] if device != 'cpu' else None
+    (G, D), rms, video, logits, loss, grads = _forward_backward(device, g, records)
     # analytic buffers (firwin designs, bilinear ramps) must be the same numbers as the reference's
     for prefix, net in (('G', G), ('D', D)):
         for name, buf in analytic_buffers(net).items():
             want = g[f'buf_{prefix}_{name}']
             got = np.array([float(buf.double().sum()), float(buf.double().abs().sum()), float(buf.numel())])
             np.testing.assert_allclose(got, want, rtol=1e-6, err_msg=name)
-    noise = torch.tensor(g['noise'], device=device)
-    emb = G.temporal_emb.blur(noise)
-    ws = G.compute_latent_ws(emb, T)
-    feats = G.synthesize_video(G._temporal_input(ws), ws, T, return_features=True)
-    video = feats[-1]
-    rms = np.array([float(f.detach().float().square().mean().sqrt()) for f in feats])
     np.testing.assert_allclose(rms, g['feat_rms'], rtol=1e-3)
-    np.testing.assert_allclose(video.detach().cpu().numpy(), g['video'], rtol=0, atol=1e-3)
-    logits = D(video)
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['logits'], rtol=1e-3, atol=1e-3)
-    loss = F.softplus(-logits).mean()
-    loss.backward()
-    assert abs(float(loss) - float(g['loss'])) < 1e-3
-    pairs = dict(g_spatial_input=G.spatial_input, g_to_rgb_weight=G.to_rgb.weight, g_t0_bias_0=G.temporal_layers[0].bias_0,
-                 g_s3_weight_1=G.spatial_layers[3].weight_1, g_map_l1_bias=G.latent_mapping.layer_1.bias,
-                 d_b0_conv_vid_weight=D.blocks[0].conv_vid.weight, d_ep_linear_1_weight=D.epilogue.linear_1.weight)
-    for key, param in pairs.items():
-        want = g[key]
-        got = param.grad.detach().cpu().numpy()
-        scale = np.abs(want).max() + 1e-12
-        assert np.abs(got - want).max() <= rtol_grad * scale, (key, float(np.abs(got - want).max()), float(scale))
-    # ... and against the reference run in float64 (tests/golden/make_golden_models_f64.py), where the reference's own float32 run sits
-    # at 5e-7 .. 1e-5 of each gradient's scale. This repo's networks order the float32 arithmetic differently (modulation on the activations,
-    # demodulation on the output, fused epilogues) and sit at 1e-6 .. 5e-4 on the CPU (PyTorch kernels; measured values are recorded); the
-    # GPU routes (split-operand contraction on the hand-written kernels + library for the shapes it does not take) share the gate of 1e-3
-    g64 = load_golden('lres_models_f64')
-    worst = {}
-    for key, param in pairs.items():
-        want = g64[key]
-        worst[key] = float(np.abs(param.grad.detach().double().cpu().numpy() - want).max() / np.abs(want).max())
-    record_measured(f'lres_T16_f32_grads_vs_reference_f64_{device}', **worst)
-    assert max(worst.values()) < 1e-3, worst
+    np.testing.assert_allclose(video, g['video'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(logits, g['logits'], rtol=1e-3, atol=1e-3)
+    assert abs(loss - float(g['loss'])) < 1e-3
+    vs32, vs64 = _gradient_errors(grads, g), _gradient_errors(grads, g64)
+    record_measured(f'lres_T16_f32_grads_vs_reference_f64_{device}', **vs64)
+    ok = max(vs32.values()) <= rtol_grad and max(vs64.values()) < 1e-3
+    if ok or device == 'cpu':
+        assert ok, (vs32, vs64)
+        return
+    from lvg.models import lres
+    assert lres.SPLIT_F32, (vs32, vs64)                    # the library route has nothing to be compared with
+    lres.SPLIT_F32 = False
+    try:
+        lib_records = []
+        _, _, _, _, _, lib_grads = _forward_backward(device, g, lib_records)
+    finally:
+        lres.SPLIT_F32 = True
+    lib32, lib64 = _gradient_errors(lib_grads, g), _gradient_errors(lib_grads, g64)
+    assert max(lib32.values()) <= rtol_grad and max(lib64.values()) < 1e-3, ('library route', lib32, lib64)
+    lib_z = {}
+    for key, z in lib_records:
+        lib_z.setdefault(key, []).append(z)
+    seen, flipped = {}, []
+    for key, z in records:
+        i = seen.get(key, 0)
+        seen[key] = i + 1
+        if key in lib_z and i < len(lib_z[key]):
+            zl = lib_z[key][i]
+            differs = zl.sign() != z.sign()
+            flipped += [float(v) for v in (zl[differs].abs() / zl.abs().max())]
+    record_measured(f'lres_T16_f32_kink_flips_{device}', flips=len(flipped), largest_relative_distance_from_zero=max(flipped, default=0.0),
+                    split_route_vs_f64=max(vs64.values()), library_route_vs_f64=max(lib64.values()))
+    assert flipped and max(flipped) < 1e-6, ('deviation not explained by leaky-ReLU kinks', flipped[:8], vs32, vs64)
+    assert max(vs32.values()) < 3e-2, (vs32, vs64)          # a flipped element of the 104 k-element block moves the deep gradients by ~1e-2; not more
 
 
 def test_state_dict_keys_match_reference_layout():

@@ -36,9 +36,9 @@ def run(device, dtype, split):
 
 
 torch.set_num_threads(16)
-truth, vt = run('cpu', torch.float64, False)
-if not torch.cuda.is_available():
-    print('truth ok', {k: float(np.abs(v).max()) for k, v in truth.items()}); sys.exit(0)
+g64 = load_golden('lres_models_f64')                     # the reference run in float64 (tests/golden/make_golden_models_f64.py)
+truth = {k: np.asarray(g64[k], dtype=np.float64) for k in KEYS}
+vt = np.asarray(g64['video'], dtype=np.float64) if 'video' in g64 else np.asarray(g['video'], dtype=np.float64)
 lib, vl = run('cuda', torch.float32, False)
 spl, vs = run('cuda', torch.float32, True)
 rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
