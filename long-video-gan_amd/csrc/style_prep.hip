@@ -81,8 +81,11 @@ __global__ __launch_bounds__(kThreads) void style_norm_kernel(StyleArgs p)
 //   1  gm    [R x Ci]  = g_mod + 2 mod (gq . w2)                    A(m,k) = gq[m][k]           B(k,n) = w2[k][n]
 //   2  dw2   [Co x Ci] = gq^T . mod^2                               A(m,k) = gq[k][m]           B(k,n) = mod[k][n]^2
 // with gq = d loss / d (sum + 1e-8) = -1/2 g_demod demod^3.
-constexpr int kBM = 64, kBN = 64, kBK = 16, kPad = 4;
+constexpr int kBM = 64, kBN = 64, kBK = 32, kPad = 4;
 
+// One workgroup per 64 x 64 tile; 32-deep K steps staged through LDS with the NEXT step's operands already in flight in registers
+// (these products are small -- 0.5 GFLOP, 64 .. 128 tiles on 256 CUs, one wave per SIMD -- so the exposed latency of a K step's
+// global loads, not arithmetic, was the time: 31 / 33 / 48 us per launch with unprefetched 16-deep steps).
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void style_gemm_kernel(StyleArgs p)
 {
@@ -98,45 +101,73 @@ __global__ __launch_bounds__(kThreads) void style_gemm_kernel(StyleArgs p)
     };
     auto sq4 = [](float4 v) { return make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w); };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // two float4 of each operand tile per thread and K step. "row form": 64 rows x 8 quads along k (source rows contiguous in k, stored
+    // transposed); "k form": 32 k rows x 16 quads along the tile's m / n (stored as they come)
+    auto fetch = [&](int k0, float4 (&ra)[2], float4 (&rb)[2])
+    {
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+            const int idx = tid + kThreads * i;
+            if (MODE == 2)
+            {
+                const int k = k0 + (idx >> 4), m = m0 + (idx & 15) * 4;                   // gq[k][m .. m + 3]
+                ra[i] = (k < K && m < M) ? gq4((int64_t)k * p.Co + m) : zero4;
+            }
+            else
+            {
+                const int m = m0 + (idx >> 3), k = k0 + (idx & 7) * 4;                    // row m, k .. k + 3
+                float4 v = zero4;
+                if (m < M && k < K) v = MODE == 0 ? sq4(*reinterpret_cast<const float4*>(p.mod + (int64_t)m * p.Ci + k)) : gq4((int64_t)m * p.Co + k);
+                ra[i] = v;
+            }
+            if (MODE == 0)
+            {
+                const int n = n0 + (idx >> 3), k = k0 + (idx & 7) * 4;                    // w2[n][k .. k + 3]
+                rb[i] = (n < N && k < K) ? *reinterpret_cast<const float4*>(p.w2 + (int64_t)n * p.Ci + k) : zero4;
+            }
+            else
+            {
+                const int k = k0 + (idx >> 4), n = n0 + (idx & 15) * 4;
+                float4 v = zero4;
+                if (k < K && n < N)
+                {
+                    v = *reinterpret_cast<const float4*>((MODE == 1 ? p.w2 : p.mod) + (int64_t)k * p.Ci + n);
+                    if (MODE == 2) v = sq4(v);
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto stage = [&](const float4 (&ra)[2], const float4 (&rb)[2])
+    {
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+            const int idx = tid + kThreads * i;
+            if (MODE == 2) *reinterpret_cast<float4*>(&As[idx >> 4][(idx & 15) * 4]) = ra[i];
+            else
+            {
+                const int r = idx >> 3, kq = (idx & 7) * 4;
+                As[kq + 0][r] = ra[i].x; As[kq + 1][r] = ra[i].y; As[kq + 2][r] = ra[i].z; As[kq + 3][r] = ra[i].w;
+            }
+            if (MODE == 0)
+            {
+                const int r = idx >> 3, kq = (idx & 7) * 4;
+                Bs[kq + 0][r] = rb[i].x; Bs[kq + 1][r] = rb[i].y; Bs[kq + 2][r] = rb[i].z; Bs[kq + 3][r] = rb[i].w;
+            }
+            else *reinterpret_cast<float4*>(&Bs[idx >> 4][(idx & 15) * 4]) = rb[i];
+        }
+    };
 
     float acc[4][4] = {};
+    float4 ra[2], rb[2];
+    fetch(0, ra, rb);
     for (int k0 = 0; k0 < K; k0 += kBK)
     {
-        // ---- A tile -> As[k][m]
-        if (MODE == 2)
-        {
-            const int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4;                       // gq[k][m .. m + 3]
-            const float4 v = (k < K && m < M) ? gq4((int64_t)k * p.Co + m) : zero4;
-            *reinterpret_cast<float4*>(&As[tid >> 4][(tid & 15) * 4]) = v;
-        }
-        else
-        {
-            const int m = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;                        // row m, k .. k + 3
-            float4 v = zero4;
-            if (m < M && k < K) v = MODE == 0 ? sq4(*reinterpret_cast<const float4*>(p.mod + (int64_t)m * p.Ci + k)) : gq4((int64_t)m * p.Co + k);
-            As[(tid & 3) * 4 + 0][tid >> 2] = v.x; As[(tid & 3) * 4 + 1][tid >> 2] = v.y;
-            As[(tid & 3) * 4 + 2][tid >> 2] = v.z; As[(tid & 3) * 4 + 3][tid >> 2] = v.w;
-        }
-        // ---- B tile -> Bs[k][n]
-        if (MODE == 0)
-        {
-            const int n = n0 + (tid >> 2), k = k0 + (tid & 3) * 4;                        // w2[n][k .. k + 3]
-            const float4 v = (n < N && k < K) ? *reinterpret_cast<const float4*>(p.w2 + (int64_t)n * p.Ci + k) : zero4;
-            Bs[(tid & 3) * 4 + 0][tid >> 2] = v.x; Bs[(tid & 3) * 4 + 1][tid >> 2] = v.y;
-            Bs[(tid & 3) * 4 + 2][tid >> 2] = v.z; Bs[(tid & 3) * 4 + 3][tid >> 2] = v.w;
-        }
-        else
-        {
-            const int k = k0 + (tid >> 4), n = n0 + (tid & 15) * 4;
-            float4 v = zero4;
-            if (k < K && n < N)
-            {
-                v = *reinterpret_cast<const float4*>((MODE == 1 ? p.w2 : p.mod) + (int64_t)k * p.Ci + n);
-                if (MODE == 2) v = sq4(v);
-            }
-            *reinterpret_cast<float4*>(&Bs[tid >> 4][(tid & 15) * 4]) = v;
-        }
+        stage(ra, rb);
         __syncthreads();
+        if (k0 + kBK < K) fetch(k0 + kBK, ra, rb);                                        // lands while this step is multiplied
         #pragma unroll
         for (int k = 0; k < kBK; k++)
         {
