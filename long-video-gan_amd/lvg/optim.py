@@ -77,8 +77,9 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self, ema_weight: Optional[float] = None) -> None:
-        """One Adam update of every parameter that has a gradient; with `ema_weight` (= 1 - ema_beta) the EMA copy of those
-        parameters moves towards the new values in the same pass."""
+        """One Adam update of every parameter that has a gradient; with `ema_weight` (= 1 - ema_beta) the EMA copy of EVERY
+        parameter moves towards the current values: in the same pass for the updated ones, by a lerp of their (unchanged) slices for
+        parameters without a gradient -- the reference's EMA lerps all parameters every step (video_gan_lres.py update_G_ema)."""
         # gather runs of consecutive parameters that (a) have a gradient, (b) share the update count, and (c) whose gradients
         # are consecutive slices of one flat buffer with the same spacing as the parameters
         runs, cur = [], None
@@ -86,6 +87,9 @@ class FlatAdam:
             g = p.grad
             if g is None:
                 cur = None
+                if self.ema_flat is not None and ema_weight is not None:
+                    lo = self.offsets[i]
+                    self.ema_flat[lo:lo + p.numel()].lerp_(self.flat[lo:lo + p.numel()], float(ema_weight))
                 continue
             assert g.dtype == torch.float32 and g.is_contiguous(), 'float32 contiguous gradients'
             self.steps[i] += 1

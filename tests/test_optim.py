@@ -38,8 +38,7 @@ def _run(device, steps=6):
         opt_ref.step()
         with torch.no_grad():
             for pe, p in zip(ema_ref.parameters(), ref.parameters()):
-                if p.grad is not None:
-                    pe.lerp_(p, 0.1)
+                pe.lerp_(p, 0.1)                  # the reference lerps EVERY parameter every step, also those without a gradient
         for a, b in zip(net.parameters(), ref.parameters()):
             torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
         for a, b in zip(ema.parameters(), ema_ref.parameters()):

@@ -126,6 +126,17 @@ def test_generate_video_lengths_and_bytes_cpu():
     assert torch.equal(video, video_io.video_to_uint8(ref))
 
 
+def test_pad_to_scale_streams_any_length_cpu():
+    """pad_to_scale: a clip whose length is not a multiple of the temporal scale is generated as the next multiple, streamed in
+    chunks and cropped: the frames of G(1, 64) from the same seeded generator, the first 40 of them."""
+    G = _tiny_lres()
+    with torch.no_grad():
+        pieces = list(generate.lres_video(G, 1, 40, torch.Generator().manual_seed(5), chunk=32, pad_to_scale=True))
+        ref = G(1, 64, generator_emb=torch.Generator().manual_seed(5))[:, :, :40]
+    assert [p.shape[2] for p in pieces] == [32, 8]
+    assert float((torch.cat(pieces, dim=2) - ref).abs().max()) < 1e-5
+
+
 @pytest.mark.gpu
 def test_generate_video_with_super_resolution_gpu():
     from lvg.models import lres, sres
