@@ -364,6 +364,22 @@ int lvg_weight_dgrad_pack(const void* wp, void* wt, int taps, int co, int ci, vo
 int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream);
 
 /*
+ * Fused stages of the ADA augmentation pipeline (csrc/ada_augment.hip; reference model/ada_augment.py).
+ *   lvg_ada_warp: the geometric stage (:271-304: reflect padding by `margins`, x2 up-sampling with the 12-tap low-pass, bilinear
+ *     resampling through the inverse affine map (affine_grid + grid_sample, zeros outside, align_corners = False), x2 down-sampling
+ *     with the flipped filter) in one launch. x, y [n][k][h][w] float32 (k = channels x frames of a sample), g_inv [n][3][3] the map in
+ *     centred pixel units BEFORE the padding / over-sampling adjustments of :287-296, margins int32[4] = (mx0, my0, mx1, my1) ON THE
+ *     DEVICE (the rule of :275-284; the reference reads them back to the host), taps [12] the normalised 1-D filter.
+ *   lvg_ada_colour: y = C[:3, :3] . x + C[:3, 3] (cmat [n][4][4] or NULL), + noise * sigma[n] (noise like x, or NULL), zero inside the
+ *     cutout rectangle |(px + 0.5) / w - cx| < sx / 2 and |(py + 0.5) / h - cy| < sy / 2 (cut [n][4] = cx, cy, sx, sy, or NULL) on
+ *     x [n][3][t][h][w] float32 (:376-381, :407-427). transpose bit 0: the backward pass (d x = C[:3, :3]^T . (d y where kept));
+ *     bit 1: without the offset column C[:3, 3] (the linear part alone: the backward of the backward).
+ */
+int lvg_ada_warp(const float* x, const float* g_inv, const int* margins, const float* taps, float* y, int n, int k, int h, int w, void* stream);
+int lvg_ada_colour(const float* x, const float* cmat, const float* noise, const float* sigma, const float* cut, float* y,
+                   int n, int t, int h, int w, int transpose, void* stream);
+
+/*
  * Weight side of the 2-D modulated convolution of the super-resolution generator (reference model/generator_sres.py:50-58 and :63,
  * `weight.to(x.dtype)`) in one pass per direction (csrc/weight_prep.hip):
  *   forward:  w [co, ci, taps] f32 -> w' = w * rsqrt(mean over (ci, taps) of w^2) * scale;

@@ -21,7 +21,7 @@ import scipy.signal
 import torch
 import torch.nn.functional as F
 
-from torch_utils.ops import conv2d_gradfix, grid_sample_gradfix, upfirdn2d
+from torch_utils.ops import ada_ops, conv2d_gradfix, grid_sample_gradfix, upfirdn2d
 
 # Orthogonal wavelet low-pass prototypes (Daubechies least-asymmetric, 6 and 2 vanishing moments).
 SYM6 = (0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
@@ -182,32 +182,51 @@ class AugmentPipe(torch.nn.Module):
             push(shift2(-t[:, 0] * width, -t[:, 1] * height))
         return g
 
-    def _warp(self, x: torch.Tensor, g_inv: torch.Tensor) -> torch.Tensor:
-        """x [N, K, H, W] resampled through the inverse map g_inv [N, 3, 3] (pixel units, centred)."""
-        n, k, height, width = x.shape
-        dev = x.device
+    def _warp_margins(self, g_inv: torch.Tensor, width: int, height: int) -> torch.Tensor:
+        """Reflect-padding margins (mx0, my0, mx1, my1) of the geometric stage: the reach of the transformed corners (+ filter support),
+        clamped to the image size -- an int32 tensor on g_inv's device (reference ada_augment.py:275-284; no host read here)."""
+        dev = g_inv.device
         cx, cy = (width - 1) / 2, (height - 1) / 2
-        # reflect-pad by the reach of the transformed corners (+ filter support), clamped to the image size
         corners = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dtype=torch.float32, device=dev)
         reach = (g_inv @ corners.t())[:, :2, :].permute(1, 0, 2).flatten(1)               # [xy, N*4]
         reach = torch.cat([-reach, reach]).max(dim=1).values                              # [x0, y0, x1, y1]
         pad_f = self.Hz_geom.shape[0] // 4
-        reach = reach + _const([pad_f * 2 - cx, pad_f * 2 - cy] * 2, x)
-        reach = reach.max(_const([0, 0] * 2, x)).min(_const([width - 1, height - 1] * 2, x))
-        mx0, my0, mx1, my1 = (int(v) for v in reach.ceil().to(torch.int32).tolist())
+        reach = reach + _const([pad_f * 2 - cx, pad_f * 2 - cy] * 2, g_inv)
+        reach = reach.max(_const([0, 0] * 2, g_inv)).min(_const([width - 1, height - 1] * 2, g_inv))
+        return reach.ceil().to(torch.int32)
+
+    def _warp_composed(self, x: torch.Tensor, g_inv: torch.Tensor, margins) -> torch.Tensor:
+        """The geometric stage as the reference spells it (ada_augment.py:286-301): reflect pad, x2 up, affine_grid + grid_sample, x2 down.
+        `margins`: four Python ints."""
+        n, k, height, width = x.shape
+        dev = x.device
+        pad_f = self.Hz_geom.shape[0] // 4
+        mx0, my0, mx1, my1 = margins
+        # (constant matrices in g_inv's dtype: float32 in the pipeline, float64 in the oracle tests)
+        shift = lambda tx, ty: torch.tensor([[1, 0, tx], [0, 1, ty], [0, 0, 1]], dtype=g_inv.dtype, device=dev)
+        zoom = lambda sx, sy: torch.tensor([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], dtype=g_inv.dtype, device=dev)
         x = F.pad(x, [mx0, mx1, my0, my1], mode='reflect')
-        g_inv = shift2((mx0 - mx1) / 2, (my0 - my1) / 2, device=dev) @ g_inv
+        g_inv = shift((mx0 - mx1) / 2, (my0 - my1) / 2) @ g_inv
 
         # x2 oversampling keeps the bilinear resampler away from the signal band
         x = upfirdn2d.upsample2d(x=x, f=self.Hz_geom, up=2)
-        g_inv = zoom2(2, 2, device=dev) @ g_inv @ zoom2(0.5, 0.5, device=dev)
-        g_inv = shift2(-0.5, -0.5, device=dev) @ g_inv @ shift2(0.5, 0.5, device=dev)
+        g_inv = zoom(2, 2) @ g_inv @ zoom(0.5, 0.5)
+        g_inv = shift(-0.5, -0.5) @ g_inv @ shift(0.5, 0.5)
 
         out_shape = [n, k, (height + pad_f * 2) * 2, (width + pad_f * 2) * 2]
-        g_inv = zoom2(2 / x.shape[3], 2 / x.shape[2], device=dev) @ g_inv @ zoom2(out_shape[3] / 2, out_shape[2] / 2, device=dev)
-        grid = F.affine_grid(theta=g_inv[:, :2, :], size=out_shape, align_corners=False)
+        g_inv = zoom(2 / x.shape[3], 2 / x.shape[2]) @ g_inv @ zoom(out_shape[3] / 2, out_shape[2] / 2)
+        grid = F.affine_grid(theta=g_inv[:, :2, :].to(x.dtype), size=out_shape, align_corners=False)
         x = grid_sample_gradfix.grid_sample(x, grid)
         return upfirdn2d.downsample2d(x=x, f=self.Hz_geom, down=2, padding=-pad_f * 2, flip_filter=True)
+
+    def _warp(self, x: torch.Tensor, g_inv: torch.Tensor) -> torch.Tensor:
+        """x [N, K, H, W] resampled through the inverse map g_inv [N, 3, 3] (pixel units, centred). float32 GPU tensors take the ONE
+        fused launch (torch_utils.ops.ada_ops.ada_warp: no padded / over-sampled intermediates in memory and no host read of the
+        margins); everything else the composition above."""
+        margins = self._warp_margins(g_inv, x.shape[3], x.shape[2])
+        if ada_ops.warp_supported(x, self.Hz_geom):
+            return ada_ops.ada_warp(x, g_inv, margins, self.Hz_geom, lambda xx, mm: self._warp_composed(xx, g_inv, mm))
+        return self._warp_composed(x, g_inv, [int(v) for v in margins.tolist()])
 
     # -- stage 2: colour ----------------------------------------------------------------------------
 
@@ -283,7 +302,11 @@ class AugmentPipe(torch.nn.Module):
             videos = self._warp(videos.reshape(n, channels * frames, height, width), g_inv)
 
         c_mat = self._colour_matrix(n, channels, dev, q)
-        if c_mat is not None:
+        # GPU float32 RGB clips: colour matrix, noise and cutout are applied together at the end by ONE pass over the pixels
+        # (ada_ops.ada_colour); the random numbers are still drawn here, in the reference's order. With the band filter on, the colour
+        # matrix has to be applied before it (the filter sits between the two in the reference).
+        fused = ada_ops.colour_supported(videos.reshape(n, channels, frames, height, width))
+        if c_mat is not None and not (fused and self.imgfilter == 0):
             flat = videos.reshape(n, channels, frames * height * width)
             if channels == 3:
                 flat = c_mat[:, :3, :3] @ flat + c_mat[:, :3, 3:]
@@ -293,6 +316,7 @@ class AugmentPipe(torch.nn.Module):
             else:
                 raise ValueError('Image must be RGB (3 channels) or L (1 channel)')
             videos = flat
+            c_mat = None
 
         if self.imgfilter > 0:
             taps = self._band_gains(n, dev, q) @ self.Hz_fbank                                  # [N, taps]
@@ -309,13 +333,17 @@ class AugmentPipe(torch.nn.Module):
 
         videos = videos.reshape(n, channels * frames, height, width)
 
+        sigma = noise = None
         if self.noise > 0:
             sigma = torch.randn([n, 1, 1, 1], device=dev).abs() * self.noise_std
             sigma = self._gate(self.noise, [n, 1, 1, 1], sigma, 0)
             if q is not None:
                 sigma = torch.full_like(sigma, float(torch.erfinv(q) * self.noise_std))
-            videos = videos + torch.randn([n, channels * frames, height, width], device=dev) * sigma
+            noise = torch.randn([n, channels * frames, height, width], device=dev)
+            if not fused:
+                videos = videos + noise * sigma
 
+        size = centre = None
         if self.cutout > 0:
             size = torch.full([n, 2, 1, 1, 1], self.cutout_size, device=dev)
             size = self._gate(self.cutout, [n, 1, 1, 1, 1], size, 0)
@@ -323,10 +351,17 @@ class AugmentPipe(torch.nn.Module):
             if q is not None:
                 size = torch.full_like(size, self.cutout_size)
                 centre = torch.full_like(centre, float(q))
-            xs = (torch.arange(width, device=dev).reshape(1, 1, 1, -1) + 0.5) / width
-            ys = (torch.arange(height, device=dev).reshape(1, 1, -1, 1) + 0.5) / height
-            keep = torch.logical_or((xs - centre[:, 0]).abs() >= size[:, 0] / 2, (ys - centre[:, 1]).abs() >= size[:, 1] / 2)
-            videos = videos * keep.to(torch.float32)
+            if not fused:
+                xs = (torch.arange(width, device=dev).reshape(1, 1, 1, -1) + 0.5) / width
+                ys = (torch.arange(height, device=dev).reshape(1, 1, -1, 1) + 0.5) / height
+                keep = torch.logical_or((xs - centre[:, 0]).abs() >= size[:, 0] / 2, (ys - centre[:, 1]).abs() >= size[:, 1] / 2)
+                videos = videos * keep.to(torch.float32)
+
+        if fused and (c_mat is not None or noise is not None or size is not None):
+            cut = None if size is None else torch.cat((centre.reshape(n, 2), size.reshape(n, 2)), dim=1)
+            videos = ada_ops.ada_colour(videos.reshape(n, channels, frames, height, width), c_mat,
+                                        None if noise is None else noise.reshape(n, channels, frames, height, width),
+                                        None if sigma is None else sigma.reshape(n), cut)
 
         return videos.reshape(n, channels, frames, height, width)
 
@@ -339,7 +374,7 @@ class AugmentPipe(torch.nn.Module):
         """Random per-sample FIR along time: a box of random length plus zero-mean noise taps (so the
         filter sums to one); a sample takes the filtered clip where p < u, u uniform (as the reference)."""
         assert video.dim() == 5 and 2 <= min_ksize <= max_ksize
-        if self.p.item() <= 0:
+        if not video.is_cuda and self.p.item() <= 0:                 # (GPU clips: no host read of p -- the mask below covers p <= 0)
             return video
         n, dev = video.size(0), video.device
         ksize = torch.randint(2, max_ksize + 1, (n, 1, 1, 1, 1), device=dev)
@@ -350,5 +385,5 @@ class AugmentPipe(torch.nn.Module):
         taps = (1 / ksize) * inside + taps - taps.mean(dim=2, keepdim=True)
         padded = F.pad(video, (0, 0, 0, 0, max_ksize // 2, (max_ksize - 1) // 2), mode='reflect')
         filtered = F.conv3d(padded.transpose(0, 1), taps, groups=n).transpose(0, 1)
-        use = self.p < torch.rand(n, 1, 1, 1, 1, device=dev)
+        use = (self.p < torch.rand(n, 1, 1, 1, 1, device=dev)) & (self.p > 0)
         return torch.where(use, filtered, video)

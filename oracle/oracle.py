@@ -342,3 +342,32 @@ def video_from_uint8(frames, flip=None):
                                     out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), c, t, h, w)
     assert rc == 0
     return out
+
+
+def ada_warp(x, g_inv, f, margins):
+    """ADA geometric stage (orc_ada_warp; reference ada_augment.py:271-304): x [N, K, H, W], g_inv [N, 3, 3] (pixel units, centred),
+    f [taps] the normalised 1-D low-pass, margins (mx0, my0, mx1, my1) the reflect padding of :283 -> [N, K, H, W]."""
+    x, g_inv, f = _f64(x), _f64(g_inv), _f64(f)
+    n, k, h, w = x.shape
+    y = np.empty_like(x)
+    rc = lib().orc_ada_warp(_dp(x), _dp(g_inv), _dp(f), ctypes.c_int(f.shape[0]), _dp(y), ctypes.c_int(n), ctypes.c_int(k), ctypes.c_int(h),
+                            ctypes.c_int(w), *[ctypes.c_int(int(m)) for m in margins])
+    assert rc == 0, rc
+    return y
+
+
+def ada_colour(x, cmat=None, noise=None, sigma=None, cut=None):
+    """ADA colour matrix / additive noise / cutout in one pass (orc_ada_colour; reference ada_augment.py:376-381, :407-427):
+    x [N, C, T, H, W]; cmat [N, 4, 4]; noise like x with sigma [N]; cut [N, 4] = (cx, cy, sx, sy) -> like x."""
+    x = _f64(x)
+    n, c, t, h, w = x.shape
+    y = np.empty_like(x)
+    cm = None if cmat is None else _f64(cmat)
+    nz = None if noise is None else _f64(noise)
+    sg = None if sigma is None else _f64(sigma)
+    ct = None if cut is None else _f64(cut)
+    null = ctypes.POINTER(ctypes.c_double)()
+    rc = lib().orc_ada_colour(_dp(x), null if cm is None else _dp(cm), null if nz is None else _dp(nz), null if sg is None else _dp(sg),
+                              null if ct is None else _dp(ct), _dp(y), ctypes.c_int(n), ctypes.c_int(c), ctypes.c_int(t), ctypes.c_int(h), ctypes.c_int(w))
+    assert rc == 0, rc
+    return y
