@@ -3,7 +3,8 @@
 `ada_warp`   -- the geometric stage (:271-304) in ONE launch: reflect padding, x2 up-sampling with the 12-tap low-pass, the bilinear
                 resampling through the inverse affine map and the x2 down-sampling, with the padding margins read from a device tensor
                 (the reference reads them back to the host, :286). The backward pass (the generator trains THROUGH the augmentation of
-                its fakes) re-runs the reference's composition of differentiable ops on the saved input.
+                its fakes) re-runs the reference's composition of differentiable ops on the saved input; the margins it needs as Python ints
+                were copied to pinned host memory behind the forward launch.
 `ada_colour` -- colour matrix, additive noise and cutout (:376-381, :407-427) in one pass over the pixels, forward and backward.
 
 CPU tensors and anything the kernels do not take use the compositions in lvg/ada_augment.py (the definition tested against)."""
@@ -33,6 +34,14 @@ class _AdaWarp(torch.autograd.Function):
         _hip.check(rc, 'ada_warp')
         ctx.save_for_backward(x, m)
         ctx.composed = composed
+        # the backward pass needs the margins as Python ints (F.pad): start their copy to pinned host memory now, behind the kernel;
+        # by the time a backward pass runs it has long landed, so reading it there waits for nothing
+        ctx.margins_host = ctx.margins_ready = None
+        if ctx.needs_input_grad[0] and not torch.cuda.is_current_stream_capturing():
+            ctx.margins_host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            ctx.margins_host.copy_(m, non_blocking=True)
+            ctx.margins_ready = torch.cuda.Event()
+            ctx.margins_ready.record()
         return y
 
     @staticmethod
@@ -40,7 +49,11 @@ class _AdaWarp(torch.autograd.Function):
         x, m = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None
-        margins = [int(v) for v in m.tolist()]                     # (the only host read of the stage: backward passes only)
+        if ctx.margins_host is not None:
+            ctx.margins_ready.synchronize()                        # (recorded in the forward pass: complete long before this point)
+            margins = [int(v) for v in ctx.margins_host.tolist()]
+        else:
+            margins = [int(v) for v in m.tolist()]
         again = torch.is_grad_enabled()                            # backward of a backward (R1): d x must stay a function of d y
         with torch.enable_grad():
             xx = x.detach().requires_grad_(True)
