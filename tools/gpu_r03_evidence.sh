@@ -33,7 +33,7 @@ LVG_SRES_STEP_GRAPH=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv
 python tools/pmc_traffic.py $(find gpurun_out/traffic/lres_f -name "*counter_collection.csv") $(find gpurun_out/traffic/lres_w -name "*counter_collection.csv") gpurun_out/r03_traffic_lres.json | grep -v detail -A0 | grep '": [0-9]' | head -12
 python tools/pmc_traffic.py $(find gpurun_out/traffic/sres_f -name "*counter_collection.csv") $(find gpurun_out/traffic/sres_w -name "*counter_collection.csv") gpurun_out/r03_traffic_sres.json | grep '": [0-9]' | head -12
 rm -rf gpurun_out/traffic
-python -c "import json; a=json.load(open('gpurun_out/r03_traffic_lres.json')); a.update(json.load(open('gpurun_out/r03_traffic_sres.json'))); json.dump(a, open('gpurun_out/r03_traffic_merged.json','w'), indent=1)"
+python -c "import json; a=json.load(open('gpurun_out/r03_traffic_sres.json')); a.update(json.load(open('gpurun_out/r03_traffic_lres.json'))); json.dump(a, open('gpurun_out/r03_traffic_merged.json','w'), indent=1)"
 # filtered_lrelu: per-layer timings and PMC of the shipped kernel
 timeout 120 tools/bin/flrelu_check time > gpurun_out/r03_flrelu_check_time.log 2>&1; tail -14 gpurun_out/r03_flrelu_check_time.log | cut -c1-150
 bash tools/gpu_pmc_flrelu.sh L8 1 1 2 r03_flrelu_pmc_L8_write > /dev/null 2>&1; cp gpurun_out/r03_flrelu_pmc_L8_write/summary.csv gpurun_out/r03_filtered_lrelu_mfma_pmc.csv; rm -rf gpurun_out/r03_flrelu_pmc_L8_write
