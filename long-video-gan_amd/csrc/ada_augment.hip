@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void ada_warp_kernel(WarpArgs p)
     const int tile = blockIdx.x, tyi = tile / p.tilesX, txi = tile - tyi * p.tilesX;
     const int oy0 = tyi * kTile, ox0 = txi * kTile;
     const int sample = blockIdx.z;
-    const int mx0 = p.margins[0], my0 = p.margins[1], mx1 = p.margins[2], my1 = p.margins[3];
+    // (clamped like the rule that produces them, :281-282: a reflection reaches at most w - 1 / h - 1 pixels)
+    const int mx0 = min(max(p.margins[0], 0), p.w - 1), my0 = min(max(p.margins[1], 0), p.h - 1);
+    const int mx1 = min(max(p.margins[2], 0), p.w - 1), my1 = min(max(p.margins[3], 0), p.h - 1);
     const int hp = p.h + my0 + my1, wp = p.w + mx0 + mx1, hu = 2 * hp, wu = 2 * wp;
     const int hm = (p.h + 6) * 2, wm = (p.w + 6) * 2;
     if (tid < kTaps) f[tid] = p.taps[tid];

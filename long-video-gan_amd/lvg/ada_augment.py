@@ -192,6 +192,7 @@ class AugmentPipe(torch.nn.Module):
         reach = torch.cat([-reach, reach]).max(dim=1).values                              # [x0, y0, x1, y1]
         pad_f = self.Hz_geom.shape[0] // 4
         reach = reach + _const([pad_f * 2 - cx, pad_f * 2 - cy] * 2, g_inv)
+        reach = torch.nan_to_num(reach, nan=0.0)                 # (a non-finite map must not turn into an out-of-range margin on the device)
         reach = reach.max(_const([0, 0] * 2, g_inv)).min(_const([width - 1, height - 1] * 2, g_inv))
         return reach.ceil().to(torch.int32)
 
