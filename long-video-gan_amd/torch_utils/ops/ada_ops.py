@@ -2,9 +2,9 @@
 
 `ada_warp`   -- the geometric stage (:271-304) in ONE launch: reflect padding, x2 up-sampling with the 12-tap low-pass, the bilinear
                 resampling through the inverse affine map and the x2 down-sampling, with the padding margins read from a device tensor
-                (the reference reads them back to the host, :286). The backward pass (the generator trains THROUGH the augmentation of
-                its fakes) re-runs the reference's composition of differentiable ops on the saved input; the margins it needs as Python ints
-                were copied to pinned host memory behind the forward launch.
+                (the reference reads them back to the host, :286). The stage is linear in the clip; its backward (the generator trains
+                THROUGH the augmentation of its fakes) is the adjoint kernel lvg_ada_warp_adjoint, and the two are each other's
+                backward to any order.
 `ada_colour` -- colour matrix, additive noise and cutout (:376-381, :407-427) in one pass over the pixels, forward and backward.
 
 CPU tensors and anything the kernels do not take use the compositions in lvg/ada_augment.py (the definition tested against)."""
@@ -20,52 +20,39 @@ def warp_supported(x, taps):
             and x.shape[2] >= 2 and x.shape[3] >= 2 and x.numel() < 2 ** 31 and _init())
 
 
-class _AdaWarp(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, g_inv, margins, taps, composed):
-        x = x.contiguous()
-        g = g_inv.detach().float().contiguous()
-        m = margins.to(torch.int32).contiguous()
-        n, k, h, w = x.shape
-        y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            rc = _hip.lib().lvg_ada_warp(x.data_ptr(), g.data_ptr(), m.data_ptr(), taps.float().contiguous().data_ptr(), y.data_ptr(),
-                                         n, k, h, w, _hip.stream(x.device))
-        _hip.check(rc, 'ada_warp')
-        ctx.save_for_backward(x, m)
-        ctx.composed = composed
-        # the backward pass needs the margins as Python ints (F.pad): start their copy to pinned host memory now, behind the kernel;
-        # by the time a backward pass runs it has long landed, so reading it there waits for nothing
-        ctx.margins_host = ctx.margins_ready = None
-        if ctx.needs_input_grad[0] and not torch.cuda.is_current_stream_capturing():
-            ctx.margins_host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-            ctx.margins_host.copy_(m, non_blocking=True)
-            ctx.margins_ready = torch.cuda.Event()
-            ctx.margins_ready.record()
-        return y
+def _warp_launch(x, g, m, taps, transposed):
+    x = x.contiguous()
+    n, k, h, w = x.shape
+    y = torch.empty_like(x)
+    fn = _hip.lib().lvg_ada_warp_adjoint if transposed else _hip.lib().lvg_ada_warp
+    with torch.cuda.device(x.device):
+        rc = fn(x.data_ptr(), g.data_ptr(), m.data_ptr(), taps.data_ptr(), y.data_ptr(), n, k, h, w, _hip.stream(x.device))
+    _hip.check(rc, 'ada_warp_adjoint' if transposed else 'ada_warp')
+    return y
+
+
+class _AdaWarpLinear(torch.autograd.Function):
+    """The stage is linear in the clip: y = A x (lvg_ada_warp) and d x = A^T d y (lvg_ada_warp_adjoint) are each the backward of the
+    other, to any order (R1 differentiates the discriminator's input gradient a second time, through the augmentation of the reals)."""
 
     @staticmethod
-    def backward(ctx, dy):
-        x, m = ctx.saved_tensors
+    def forward(ctx, x, g, m, taps, transposed):
+        ctx.save_for_backward(g, m, taps)
+        ctx.transposed = transposed
+        return _warp_launch(x, g, m, taps, transposed)
+
+    @staticmethod
+    def backward(ctx, gy):
+        g, m, taps = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None
-        if ctx.margins_host is not None:
-            ctx.margins_ready.synchronize()                        # (recorded in the forward pass: complete long before this point)
-            margins = [int(v) for v in ctx.margins_host.tolist()]
-        else:
-            margins = [int(v) for v in m.tolist()]
-        again = torch.is_grad_enabled()                            # backward of a backward (R1): d x must stay a function of d y
-        with torch.enable_grad():
-            xx = x.detach().requires_grad_(True)
-            yy = ctx.composed(xx, margins)
-            dx, = torch.autograd.grad(yy, xx, dy, create_graph=again)
-        return dx, None, None, None, None
+        return _AdaWarpLinear.apply(gy, g, m, taps, not ctx.transposed), None, None, None, None
 
 
-def ada_warp(x, g_inv, margins, taps, composed):
+def ada_warp(x, g_inv, margins, taps):
     """x [N, K, H, W] float32 on the GPU; g_inv [N, 3, 3] (pixel units, centred); margins int32 [4] = (mx0, my0, mx1, my1) on the device;
-    taps [12] the normalised low-pass; `composed(x, margins as ints)`: the differentiable composition (used by the backward pass)."""
-    return _AdaWarp.apply(x, g_inv, margins, taps, composed)
+    taps [12] the normalised low-pass. No host read, forward or backward."""
+    return _AdaWarpLinear.apply(x, g_inv.detach().float().contiguous(), margins.to(torch.int32).contiguous(), taps.detach().float().contiguous(), False)
 
 
 def colour_supported(x):

@@ -163,13 +163,44 @@ def test_hip_warp_matches_oracle_gpu(case, oracle):
     g_inv = (_random_maps(n, w, h, seed) @ aa.zoom2(extra_zoom, extra_zoom)).cuda()
     margins = pipe._warp_margins(g_inv, w, h)
     assert ada_ops.warp_supported(x, pipe.Hz_geom)
-    got = ada_ops.ada_warp(x, g_inv, margins, pipe.Hz_geom, None).cpu().numpy()
+    got = ada_ops.ada_warp(x, g_inv, margins, pipe.Hz_geom).cpu().numpy()
     want = oracle.ada_warp(x.cpu().numpy(), g_inv.cpu().double().numpy(), pipe.Hz_geom.cpu().double().numpy(), [int(v) for v in margins.tolist()])
     assert np.isfinite(got).all()
     np.testing.assert_allclose(got, want, rtol=0, atol=3e-5 * max(1.0, np.abs(want).max()))
     # ... and the whole stage as the pipeline calls it (fused) against its composition of library ops (float32 both)
     comp = pipe._warp_composed(x, g_inv, [int(v) for v in margins.tolist()]).cpu().numpy()
     np.testing.assert_allclose(pipe._warp(x, g_inv).cpu().numpy(), comp, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [((2, 3, 14, 22), 1, 1.0), ((1, 4, 20, 12), 3, 1.0), ((2, 5, 72, 128), 4, 1.0), ((1, 2, 40, 56), 5, 6.0)],
+                         ids=['small', 'tall', 'sres_quarter', 'zoomed_out'])
+def test_hip_warp_backward_is_the_adjoint_gpu(case):
+    """lvg_ada_warp_adjoint: <A x, r> = <x, A^T r> against the forward kernel, the input gradient against autograd of the reference's
+    composition (pad / upfirdn2d / grid_sample: their own backward passes), and the backward of the backward (R1) against the forward map."""
+    from torch_utils.ops import ada_ops
+    from lvg import ada_augment as aa
+    (n, k, h, w), seed, extra_zoom = case
+    pipe = AugmentPipe(**TRAIN_SRES_KW).cuda()
+    torch.manual_seed(seed)
+    x = torch.randn(n, k, h, w, device='cuda', requires_grad=True)
+    r = torch.randn(n, k, h, w, device='cuda', requires_grad=True)
+    g_inv = (_random_maps(n, w, h, seed) @ aa.zoom2(extra_zoom, extra_zoom)).cuda()
+    margins = pipe._warp_margins(g_inv, w, h)
+    y = ada_ops.ada_warp(x, g_inv, margins, pipe.Hz_geom)
+    (gx,) = torch.autograd.grad(y, x, r, create_graph=True)
+    lhs, rhs = float((y.double() * r.double()).sum()), float((x.double() * gx.double()).sum())
+    scale = float((y.double() * r.double()).abs().sum())
+    assert abs(lhs - rhs) <= 2e-5 * scale, (lhs, rhs, scale)
+    xc = x.detach().clone().requires_grad_(True)
+    yc = pipe._warp_composed(xc, g_inv, [int(v) for v in margins.tolist()])
+    (gc,) = torch.autograd.grad(yc, xc, r.detach())
+    torch.testing.assert_close(gx.detach(), gc, rtol=0, atol=1e-4 * max(1.0, float(gc.abs().max())))
+    # second order: d/d r <gx, s> = A s
+    s_ = torch.randn_like(gx)
+    (gr,) = torch.autograd.grad(gx, r, s_)
+    want = ada_ops.ada_warp(s_, g_inv, margins, pipe.Hz_geom)
+    torch.testing.assert_close(gr, want, rtol=0, atol=1e-5 * max(1.0, float(want.abs().max())))
 
 
 @pytest.mark.gpu
