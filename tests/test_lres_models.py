@@ -85,8 +85,9 @@ def _run(device, rtol_grad):
     differ by 9e-2 in that layer's gradients and 9e-3 in the gradient of the network input (measured between the library route and the
     split-operand route on the hand-written kernels, profiles/r03_f32_kink_flips.log; the library's own timed algorithm search flips it from
     run to run). So: the gates are checked as they stand; a GPU run that misses them passes only if (a) the library route of the same
-    device meets them and (b) every pre-activation whose sign differs between the two routes lies within 1e-6 of zero and at least one
-    does -- i.e. the deviation is the kink, not the arithmetic."""
+    device meets them and (b) every pre-activation whose sign differs between the two routes lies within 1e-5 of zero (relative to the
+    layer's maximum: the pre-activations of the two routes agree to 4e-6 .. 7e-6, their float32 noise over 13 824-term sums) and at least one
+    does -- i.e. the deviation is the kink, not the arithmetic. Measured: 7 differing signs, the farthest 4.7e-7 from zero."""
     g = load_golden('lres_models')
     g64 = load_golden('lres_models_f64')
     records = [] if device != 'cpu' else None
@@ -130,7 +131,7 @@ def _run(device, rtol_grad):
             flipped += [float(v) for v in (zl[differs].abs() / zl.abs().max())]
     record_measured(f'lres_T16_f32_kink_flips_{device}', flips=len(flipped), largest_relative_distance_from_zero=max(flipped, default=0.0),
                     split_route_vs_f64=max(vs64.values()), library_route_vs_f64=max(lib64.values()))
-    assert flipped and max(flipped) < 1e-6, ('deviation not explained by leaky-ReLU kinks', flipped[:8], vs32, vs64)
+    assert flipped and max(flipped) < 1e-5, ('deviation not explained by leaky-ReLU kinks', flipped[:8], vs32, vs64)
     assert max(vs32.values()) < 3e-2, (vs32, vs64)          # a flipped element of the 104 k-element block moves the deep gradients by ~1e-2; not more
 
 
