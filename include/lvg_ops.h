@@ -376,8 +376,11 @@ int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dty
  *     bit 1: without the offset column C[:3, 3] (the linear part alone: the backward of the backward).
  */
 int lvg_ada_warp(const float* x, const float* g_inv, const int* margins, const float* taps, float* y, int n, int k, int h, int w, void* stream);
-/* d x = A^T d y for the linear map y = A x of lvg_ada_warp (same arguments; dx is cleared by the call; float atomics: tiles overlap in the source) */
-int lvg_ada_warp_adjoint(const float* dy, const float* g_inv, const int* margins, const float* taps, float* dx, int n, int k, int h, int w, void* stream);
+/* d x = A^T d y for the linear map y = A x of lvg_ada_warp, by gathers only (no atomics, fixed summation order): the transposed
+ * down-sampler through lvg_upfirdn2d into `workspace` (n * k * (h + 6) * 2 * (w + 6) * 2 floats), then one kernel for the transposed
+ * bilinear sampling (through the inverse map), the transposed up-sampler and the reflection folding. */
+int lvg_ada_warp_adjoint(const float* dy, const float* g_inv, const int* margins, const float* taps, float* workspace, float* dx,
+                         int n, int k, int h, int w, void* stream);
 int lvg_ada_colour(const float* x, const float* cmat, const float* noise, const float* sigma, const float* cut, float* y,
                    int n, int t, int h, int w, int transpose, void* stream);
 

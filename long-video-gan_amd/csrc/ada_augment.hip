@@ -200,32 +200,34 @@ __global__ __launch_bounds__(256) void ada_warp_kernel(WarpArgs p)
     }
 }
 
-// The adjoint of ada_warp_kernel (the stage is linear in the clip): d x = P^T U^T B^T D^T d y. Same decomposition -- a workgroup takes
-// the 16 x 16 tile of d y that the forward workgroup produced -- run backwards: the tile's share of the gradient of the 42 x 42
-// intermediate points (transposed down-sampler, column pass then row pass through LDS), each point's four bilinear weights spread over
-// the 7 x 7 source window its corners draw on (transposed poly-phase up-sampler) into an LDS accumulator shaped like the forward's
-// source patch, and the patch added to d x through the reflection map. Tiles overlap in the source (and reflected pixels fold onto
-// their originals), so the last step uses float atomics: like grid_sample's own backward, the summation order is not fixed -- and
-// device-scope atomics are what its time is (21 ms against 2.5 ms for the forward kernel on 16 x 24 planes of 144 x 256; a gather
-// form through the inverse map would need the transposed down-sampler's output in memory: not built).
+// The adjoint of ada_warp_kernel (the stage is linear in the clip): d x = P^T U^T B^T D^T d y, as GATHERS only -- no atomics, a fixed
+// summation order. D^T (transposed down-sampler) is an ordinary x2 up-sampling of d y and is done by lvg_upfirdn2d into a workspace M~
+// of the intermediate grid's size; this kernel does the rest for one 16 x 16 tile of d x and the planes of a sample:
+//   B^T: the gradient of an up-sampled pixel (v, u) collects, from every point (a, b) of the intermediate grid whose bilinear footprint
+//        covers it, M~[a][b] * (1 - |px - u|)(1 - |py - v|). The points are found through the INVERSE of the affine map: they lie in
+//        the parallelogram J^-1 ([-1, 1]^2) around J^-1 (u, v), whose bounding box is enumerated (10 - 45 candidates for the zooms ADA draws);
+//   U^T: the transposed poly-phase up-sampler is a 12-tap x2 decimation of that gradient: row pass / column pass through LDS;
+//   P^T: a source pixel receives its own padded position and up to two mirror images per axis (reflect padding): the tile loops over the
+//        <= 9 reflection branches that exist for it and sums.
+// (A first version scattered through LDS and device-scope float atomics: 21 ms against 2.5 ms for the forward kernel on 16 x 24 planes of
+// 144 x 256, twice the time of the composition's backward; profiles/r03_ada_bench.log.)
+constexpr int kStage = 96;                 // edge of the LDS window of M~ (larger footprints read it from memory)
+
 __global__ __launch_bounds__(256) void ada_warp_adjoint_kernel(WarpArgs p)
 {
-    __shared__ float patch[kPatch * kPatch + 8];
-    __shared__ float mid[kMid * kMidPitch];
-    __shared__ float rowp[kMid * (kTile + 1)];
-    __shared__ float dyt[kTile * (kTile + 1)];
+    __shared__ float mst[kStage * kStage];
+    __shared__ float ut[kMid * kMidPitch];
+    __shared__ float rp[kMid * (kTile + 1)];
     __shared__ float f[kTaps];
-    __shared__ int box[4];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, tyi = tile / p.tilesX, txi = tile - tyi * p.tilesX;
-    const int oy0 = tyi * kTile, ox0 = txi * kTile;
+    const int y0 = tyi * kTile, x0 = txi * kTile;
     const int sample = blockIdx.z;
     const int mx0 = min(max(p.margins[0], 0), p.w - 1), my0 = min(max(p.margins[1], 0), p.h - 1);
     const int mx1 = min(max(p.margins[2], 0), p.w - 1), my1 = min(max(p.margins[3], 0), p.h - 1);
     const int hp = p.h + my0 + my1, wp = p.w + mx0 + mx1, hu = 2 * hp, wu = 2 * wp;
     const int hm = (p.h + 6) * 2, wm = (p.w + 6) * 2;
     if (tid < kTaps) f[tid] = p.taps[tid];
-    if (tid < 4) box[tid] = tid < 2 ? 0x7fffffff : -0x7fffffff;
     double G[9];
     #pragma unroll
     for (int i = 0; i < 9; i++) G[i] = (double)p.g[sample * 9 + i];
@@ -239,136 +241,115 @@ __global__ __launch_bounds__(256) void ada_warp_adjoint_kernel(WarpArgs p)
         const double Sa[9] = {2.0 / wu, 0, 0, 0, 2.0 / hu, 0, 0, 0, 1}, Sb[9] = {wm / 2.0, 0, 0, 0, hm / 2.0, 0, 0, 0, 1};
         mul3(Sa, G, G); mul3(G, Sb, G);
     }
+    // the forward map of a grid point (row a, column b) as px = cxb b + cxa a + cx0, py = cyb b + cya a + cy0, and its inverse
+    const double cxb = G[0] * (2.0 / wm) * wu / 2.0, cxa = G[1] * (2.0 / hm) * wu / 2.0;
+    const double cx0 = ((G[0] * (1.0 / wm - 1.0) + G[1] * (1.0 / hm - 1.0) + G[2] + 1.0) * wu - 1.0) / 2.0;
+    const double cyb = G[3] * (2.0 / wm) * hu / 2.0, cya = G[4] * (2.0 / hm) * hu / 2.0;
+    const double cy0 = ((G[3] * (1.0 / wm - 1.0) + G[4] * (1.0 / hm - 1.0) + G[5] + 1.0) * hu - 1.0) / 2.0;
+    const double det = cxb * cya - cxa * cyb;
+    // (a singular or non-finite map samples nothing the forward pass could have used consistently: its gradient is left zero)
+    const bool usable = isfinite(det) && fabs(det) > 1e-12 && isfinite(cx0) && isfinite(cy0);
+    const double i00 = cya / det, i01 = -cxa / det, i10 = -cyb / det, i11 = cxb / det;      // (b, a) = J^-1 (px - cx0, py - cy0)
+    const double hb = fabs(i00) + fabs(i01) + 1e-6, ha = fabs(i10) + fabs(i11) + 1e-6;
+    const int ty = tid / kTile, tx = tid % kTile;
+    const int y = y0 + ty, x = x0 + tx;
+    const int yEnd = min(y0 + kTile, p.h) - 1, xEnd = min(x0 + kTile, p.w) - 1;
     __syncthreads();
-    auto point = [&](int idx, int& x0, int& y0, float& tx, float& ty) -> bool
-    {
-        const int a = 2 * oy0 + 1 + idx / kMid, b = 2 * ox0 + 1 + idx % kMid;
-        const double xn = (2.0 * b + 1.0) / wm - 1.0, yn = (2.0 * a + 1.0) / hm - 1.0;
-        const double gx = G[0] * xn + G[1] * yn + G[2], gy = G[3] * xn + G[4] * yn + G[5];
-        const double px = ((gx + 1.0) * wu - 1.0) / 2.0, py = ((gy + 1.0) * hu - 1.0) / 2.0;
-        const double fx = floor(px), fy = floor(py);
-        if (!(fx >= -2.0 && fx <= (double)wu && fy >= -2.0 && fy <= (double)hu)) return false;
-        x0 = (int)fx; y0 = (int)fy; tx = (float)(px - fx); ty = (float)(py - fy);
-        return true;
-    };
-    #pragma unroll 1
-    for (int idx = tid; idx < kMid * kMid; idx += 256)
-    {
-        int x0, y0; float tx, ty;
-        if (point(idx, x0, y0, tx, ty))
-        {
-            const int ux0 = max(x0, 0), ux1 = min(x0 + 1, wu - 1), uy0 = max(y0, 0), uy1 = min(y0 + 1, hu - 1);
-            if (ux0 <= ux1 && uy0 <= uy1)
-            {
-                atomicMin(&box[0], ux0); atomicMin(&box[1], uy0); atomicMax(&box[2], ux1); atomicMax(&box[3], uy1);
-            }
-        }
-    }
-    __syncthreads();
-    const bool any = box[0] <= box[2];
-    const int pi0 = (box[0] - 6 + 1) >> 1, pj0 = (box[1] - 6 + 1) >> 1;
-    const int pw = any ? ((box[2] - 6 + 1) >> 1) + 6 - pi0 : 0, ph = any ? ((box[3] - 6 + 1) >> 1) + 6 - pj0 : 0;
-    const bool staged = pw <= kPatch && ph <= kPatch;
     const int k0 = blockIdx.y * p.planesPerGroup, k1 = min(p.k, k0 + p.planesPerGroup);
     for (int pl = k0; pl < k1; pl++)
     {
-        const float* dy = p.x + ((int64_t)sample * p.k + pl) * p.h * p.w;       // (x = the incoming gradient, y = d x, zero-filled by the launcher)
-        float* dx = p.y + ((int64_t)sample * p.k + pl) * p.h * p.w;
-        auto spread = [&](int j, int i, float v)                               // transposed reflect padding: the padded pixel (j, i) is a source pixel
-        {
-            if (v == 0.f || i < 0 || i >= wp || j < 0 || j >= hp) return;
-            unsafeAtomicAdd(dx + (int64_t)reflect(j - my0, p.h) * p.w + reflect(i - mx0, p.w), v);
-        };
-        if (staged)
-            for (int e = tid; e < pw * ph; e += 256) patch[(e / pw) * kPatch + e % pw] = 0.f;
-        for (int e = tid; e < kTile * kTile; e += 256)
-        {
-            const int oy = e / kTile, ox = e % kTile;
-            dyt[oy * (kTile + 1) + ox] = (oy0 + oy < p.h && ox0 + ox < p.w) ? dy[(int64_t)(oy0 + oy) * p.w + ox0 + ox] : 0.f;
-        }
-        __syncthreads();
-        // transposed down-sampler: rowp[r][ox] = sum_{oy: r = 2 oy + ky} d y[oy][ox] f[ky];  mid[r][c] = sum_{ox: c = 2 ox + kx} rowp[r][ox] f[kx]
-        for (int e = tid; e < kMid * kTile; e += 256)
-        {
-            const int r = e / kTile, ox = e - r * kTile;
-            float acc = 0.f;
-            #pragma unroll
-            for (int q = 0; q < 6; q++)
-            {
-                const int oy = (r >> 1) - q, ky = r - 2 * oy;
-                if (oy >= 0 && oy < kTile && ky < kTaps) acc = fmaf(dyt[oy * (kTile + 1) + ox], f[ky], acc);
-            }
-            rowp[r * (kTile + 1) + ox] = acc;
-        }
-        __syncthreads();
-        for (int e = tid; e < kMid * kMid; e += 256)
-        {
-            const int r = e / kMid, c = e - r * kMid;
-            float acc = 0.f;
-            #pragma unroll
-            for (int q = 0; q < 6; q++)
-            {
-                const int ox = (c >> 1) - q, kx = c - 2 * ox;
-                if (ox >= 0 && ox < kTile && kx < kTaps) acc = fmaf(rowp[r * (kTile + 1) + ox], f[kx], acc);
-            }
-            mid[r * kMidPitch + c] = acc;
-        }
-        __syncthreads();
-        // transposed bilinear sampling + transposed up-sampler, point by point
+        const float* M = p.x + ((int64_t)sample * p.k + pl) * hm * wm;
+        float acc = 0.f;
         #pragma unroll 1
-        for (int idx = tid; idx < kMid * kMid; idx += 256)
+        for (int br = 0; br < (usable ? 9 : 0); br++)
         {
-            const float gm = mid[(idx / kMid) * kMidPitch + idx % kMid];
-            int x0, y0; float tx, ty;
-            if (gm == 0.f || !point(idx, x0, y0, tx, ty)) continue;
-            const int ia = (x0 - 6 + 1) >> 1, ib = (x0 + 1 - 6 + 1) >> 1;
-            const int ja = (y0 - 6 + 1) >> 1, jb = (y0 + 1 - 6 + 1) >> 1;
-            const bool okL = x0 >= 0 && x0 < wu, okR = x0 + 1 >= 0 && x0 + 1 < wu;
-            const bool okT = y0 >= 0 && y0 < hu, okB = y0 + 1 >= 0 && y0 + 1 < hu;
-            const float g4 = 4.f * gm;
-            const float wTL = (okT && okL) ? g4 * (1.f - tx) * (1.f - ty) : 0.f, wTR = (okT && okR) ? g4 * tx * (1.f - ty) : 0.f;
-            const float wBL = (okB && okL) ? g4 * (1.f - tx) * ty : 0.f,         wBR = (okB && okR) ? g4 * tx * ty : 0.f;
-            float hT[7], hB[7];
+            const int by = br / 3, bx = br - 3 * by;
+            // rows / columns of the tile that have an image in this reflection branch, and the padded positions they come from
+            int yl, yh, xl, xh;
+            if (by == 0)      { yl = y0; yh = yEnd; }
+            else if (by == 1) { yl = max(y0, 1); yh = min(yEnd, my0); }
+            else              { yl = max(y0, p.h - 1 - my1); yh = min(yEnd, p.h - 2); }
+            if (bx == 0)      { xl = x0; xh = xEnd; }
+            else if (bx == 1) { xl = max(x0, 1); xh = min(xEnd, mx0); }
+            else              { xl = max(x0, p.w - 1 - mx1); xh = min(xEnd, p.w - 2); }
+            if (yl > yh || xl > xh) continue;                                   // (uniform over the workgroup)
+            auto prow = [&](int yy) { return by == 0 ? my0 + yy : (by == 1 ? my0 - yy : my0 + 2 * (p.h - 1) - yy); };
+            auto pcol = [&](int xx) { return bx == 0 ? mx0 + xx : (bx == 1 ? mx0 - xx : mx0 + 2 * (p.w - 1) - xx); };
+            const int jmin = min(prow(yl), prow(yh)), jmax = max(prow(yl), prow(yh));
+            const int imin = min(pcol(xl), pcol(xh)), imax = max(pcol(xl), pcol(xh));
+            const int v0 = 2 * jmin - 5, nv = 2 * (jmax - jmin) + 12, u0 = 2 * imin - 5, nu = 2 * (imax - imin) + 12;
+            // window of M~ that the up-sampled region's candidates can fall in
+            double bl = 1e300, bh = -1e300, al = 1e300, ah = -1e300;
             #pragma unroll
-            for (int ii = 0; ii < 7; ii++)
+            for (int c = 0; c < 4; c++)
             {
-                const int i = ia + ii;
-                const float cl = (ii < 6) ? f[5 + x0 - 2 * i] : 0.f;
-                const int tr = 5 + x0 + 1 - 2 * i;
-                const float cr = (i >= ib && i < ib + 6) ? f[min(max(tr, 0), kTaps - 1)] : 0.f;
-                hT[ii] = wTL * cl + wTR * cr;
-                hB[ii] = wBL * cl + wBR * cr;
+                const double du = (double)((c & 1) ? u0 + nu - 1 : u0) - cx0, dv = (double)((c & 2) ? v0 + nv - 1 : v0) - cy0;
+                const double bs = i00 * du + i01 * dv, as = i10 * du + i11 * dv;
+                bl = fmin(bl, bs); bh = fmax(bh, bs); al = fmin(al, as); ah = fmax(ah, as);
             }
-            #pragma unroll
-            for (int jj = 0; jj < 7; jj++)
-            {
-                const int j = ja + jj;
-                const float rT = (jj < 6) ? f[5 + y0 - 2 * j] : 0.f;
-                const int tb = 5 + y0 + 1 - 2 * j;
-                const float rB = (j >= jb && j < jb + 6) ? f[min(max(tb, 0), kTaps - 1)] : 0.f;
-                if (rT == 0.f && rB == 0.f) continue;
-                #pragma unroll
-                for (int ii = 0; ii < 7; ii++)
+            const double bLo = fmax(ceil(bl - hb), 0.0), bHi = fmin(floor(bh + hb), (double)(wm - 1));
+            const double aLo = fmax(ceil(al - ha), 0.0), aHi = fmin(floor(ah + ha), (double)(hm - 1));
+            if (!(bLo <= bHi && aLo <= aHi)) continue;                          // nothing of the intermediate grid maps here
+            const int b_lo = (int)bLo, b_hi = (int)bHi, a_lo = (int)aLo, a_hi = (int)aHi;
+            const int sw = b_hi - b_lo + 1, sh = a_hi - a_lo + 1;
+            const bool staged = sw <= kStage && sh <= kStage;
+            __syncthreads();                                                    // (previous branch / plane done with the LDS tiles)
+            if (staged)
+                for (int e = tid; e < sw * sh; e += 256)
                 {
-                    const float v = rT * hT[ii] + rB * hB[ii];
-                    if (v == 0.f) continue;
-                    if (staged)
-                    {
-                        const int pj = j - pj0, pi = ia + ii - pi0;
-                        if (pj >= 0 && pj < ph && pi >= 0 && pi < pw) unsafeAtomicAdd(&patch[pj * kPatch + pi], v);
-                    }
-                    else spread(j, ia + ii, v);
+                    const int r = e / sw, c = e - r * sw;
+                    mst[r * kStage + c] = M[(int64_t)(a_lo + r) * wm + b_lo + c];
                 }
+            __syncthreads();
+            // B^T: gradient of the up-sampled pixels of the region
+            #pragma unroll 1
+            for (int e = tid; e < nv * nu; e += 256)
+            {
+                const int r = e / nu, c = e - r * nu;
+                const int v = v0 + r, u = u0 + c;
+                float g = 0.f;
+                if (v >= 0 && v < hu && u >= 0 && u < wu)
+                {
+                    const double du = (double)u - cx0, dv = (double)v - cy0;
+                    const double bs = i00 * du + i01 * dv, as = i10 * du + i11 * dv;
+                    const int b0 = (int)fmax(ceil(bs - hb), (double)b_lo), b1 = (int)fmin(floor(bs + hb), (double)b_hi);
+                    const int a0 = (int)fmax(ceil(as - ha), (double)a_lo), a1 = (int)fmin(floor(as + ha), (double)a_hi);
+                    for (int a = a0; a <= a1; a++)
+                    {
+                        const double pxr = cxa * a + cx0 - (double)u, pyr = cya * a + cy0 - (double)v;
+                        for (int b = b0; b <= b1; b++)
+                        {
+                            const float wx = 1.f - fabsf((float)(cxb * b + pxr)), wy = 1.f - fabsf((float)(cyb * b + pyr));
+                            if (wx > 0.f && wy > 0.f)
+                                g = fmaf(staged ? mst[(a - a_lo) * kStage + (b - b_lo)] : M[(int64_t)a * wm + b], wx * wy, g);
+                        }
+                    }
+                }
+                ut[r * kMidPitch + c] = g;
+            }
+            __syncthreads();
+            // U^T, row pass: rp[r][ii] = sum_t ut[r][2 ii + t] f[t]   (padded column imin + ii draws on up-sampled columns 2 i - 5 + t, tap t)
+            const int ni = imax - imin + 1;
+            for (int e = tid; e < nv * ni; e += 256)
+            {
+                const int r = e / ni, ii = e - r * ni;
+                float s = 0.f;
+                #pragma unroll
+                for (int t = 0; t < kTaps; t++) s = fmaf(ut[r * kMidPitch + 2 * ii + t], f[t], s);
+                rp[r * (kTile + 1) + ii] = s;
+            }
+            __syncthreads();
+            // column pass at this thread's own pixel, if it has an image in the branch
+            if (y >= yl && y <= yh && x >= xl && x <= xh)
+            {
+                const int jj = prow(y) - jmin, ii = pcol(x) - imin;
+                float s = 0.f;
+                #pragma unroll
+                for (int t = 0; t < kTaps; t++) s = fmaf(rp[(2 * jj + t) * (kTile + 1) + ii], f[t], s);
+                acc = fmaf(4.f, s, acc);
             }
         }
-        __syncthreads();
-        if (staged)
-            for (int e = tid; e < pw * ph; e += 256)
-            {
-                const int j = e / pw, i = e - j * pw;
-                spread(pj0 + j, pi0 + i, patch[j * kPatch + i]);
-            }
-        __syncthreads();
+        if (y < p.h && x < p.w) p.y[(((int64_t)sample * p.k + pl) * p.h + y) * p.w + x] = acc;
     }
 }
 
@@ -449,13 +430,18 @@ extern "C" int lvg_ada_warp(const float* x, const float* g_inv, const int* margi
     return lvg_check_launch("ada_warp");
 }
 
-extern "C" int lvg_ada_warp_adjoint(const float* dy, const float* g_inv, const int* margins, const float* taps, float* dx,
+extern "C" int lvg_ada_warp_adjoint(const float* dy, const float* g_inv, const int* margins, const float* taps, float* workspace, float* dx,
                                     int n, int k, int h, int w, void* stream)
 {
-    LVG_REQUIRE(dy && g_inv && margins && taps && dx, "ada_warp_adjoint: null pointer");
-    LVG_REQUIRE(n >= 1 && n <= 65535 && k >= 1 && h >= 2 && w >= 2 && (int64_t)n * k * h * w < 0x7fffffffLL, "ada_warp_adjoint: bad sizes");
+    LVG_REQUIRE(dy && g_inv && margins && taps && workspace && dx, "ada_warp_adjoint: null pointer");
+    LVG_REQUIRE(n >= 1 && n <= 65535 && k >= 1 && h >= 2 && w >= 2 && (int64_t)n * k * (h + 6) * (w + 6) * 4 < 0x7fffffffLL, "ada_warp_adjoint: bad sizes");
+    // D^T: the transposed x2 down-sampler (flipped filter, one sample cropped on each side) = x2 up-sampling of d y with padding 12 / 11
+    const int hm = (h + 6) * 2, wm = (w + 6) * 2;
+    const int64_t xs[4] = {n, k, h, w}, xst[4] = {(int64_t)k * h * w, (int64_t)h * w, w, 1};
+    const int64_t ys[4] = {n, k, hm, wm}, yst[4] = {(int64_t)k * hm * wm, (int64_t)hm * wm, wm, 1};
+    if (int rc = lvg_upfirdn2d(dy, workspace, nullptr, taps, taps, xs, xst, ys, yst, kTaps, kTaps, 0, 0, 2, 2, 1, 1, 12, 12, 0, 1.0f, LVG_F32, stream)) return rc;
     WarpArgs a = {};
-    a.x = dy; a.g = g_inv; a.margins = margins; a.taps = taps; a.y = dx; a.n = n; a.k = k; a.h = h; a.w = w;
+    a.x = workspace; a.g = g_inv; a.margins = margins; a.taps = taps; a.y = dx; a.n = n; a.k = k; a.h = h; a.w = w;
     a.tilesX = (w + kTile - 1) / kTile;
     const int tiles = a.tilesX * ((h + kTile - 1) / kTile);
     int groups = 1;
@@ -463,12 +449,6 @@ extern "C" int lvg_ada_warp_adjoint(const float* dy, const float* g_inv, const i
     a.planesPerGroup = (k + groups - 1) / groups;
     groups = (k + a.planesPerGroup - 1) / a.planesPerGroup;
     LVG_REQUIRE(groups <= 65535, "ada_warp_adjoint: too many plane groups");
-    if (hipMemsetAsync(dx, 0, (size_t)n * k * h * w * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    {
-        (void)hipGetLastError();
-        lvg_set_error("ada_warp_adjoint: cannot clear the output");
-        return LVG_ERR_LAUNCH;
-    }
     hipLaunchKernelGGL(ada_warp_adjoint_kernel, dim3((unsigned)tiles, (unsigned)groups, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
     return lvg_check_launch("ada_warp_adjoint");
 }

@@ -28,7 +28,7 @@ from torch_utils.ops import ada_ops, conv2d_gradfix, grid_sample_gradfix, upfird
 SYM6 = (0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
         0.787641141030194, 0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578,
         0.0017677118642428036, -0.007800708325034148)
-WARP_GRAD = os.environ.get('LVG_ADA_WARP_GRAD', 'composed')       # 'adjoint': lvg_ada_warp_adjoint as the backward of the fused geometric stage
+WARP_GRAD = os.environ.get('LVG_ADA_WARP_GRAD', 'adjoint')        # 'composed': clips that carry a gradient take the reference's composition of ops
 
 SYM2 = (-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025)
 
@@ -224,11 +224,11 @@ class AugmentPipe(torch.nn.Module):
         return upfirdn2d.downsample2d(x=x, f=self.Hz_geom, down=2, padding=-pad_f * 2, flip_filter=True)
 
     def _warp(self, x: torch.Tensor, g_inv: torch.Tensor) -> torch.Tensor:
-        """x [N, K, H, W] resampled through the inverse map g_inv [N, 3, 3] (pixel units, centred). float32 GPU clips that need no
-        gradient (the discriminator update augments reals and detached fakes) take the ONE fused launch (ada_ops.ada_warp: no padded /
-        over-sampled intermediates in memory, no host read of the margins). Clips that carry a gradient (generator update, R1) take the
-        composition by default: its backward measured 11 ms against 21 ms for the adjoint kernel, whose scatter ends in device-scope float
-        atomics (profiles/r03_ada_bench.log); LVG_ADA_WARP_GRAD=adjoint selects the fused pair there too (no host read at all)."""
+        """x [N, K, H, W] resampled through the inverse map g_inv [N, 3, 3] (pixel units, centred). float32 GPU clips take the ONE fused
+        launch (ada_ops.ada_warp: no padded / over-sampled intermediates in memory, no host read of the margins); under a gradient its
+        backward is the gather-form adjoint (lvg_ada_warp_adjoint: 3 ms against 11 ms for the backward of the composition on 16 x 24
+        planes of 144 x 256, profiles/r03_ada_bench.log), to any order. LVG_ADA_WARP_GRAD=composed restores the composition for clips
+        that carry a gradient. Everything else (CPU, other dtypes) takes the composition above."""
         margins = self._warp_margins(g_inv, x.shape[3], x.shape[2])
         needs_grad = torch.is_grad_enabled() and x.requires_grad
         if ada_ops.warp_supported(x, self.Hz_geom) and (not needs_grad or WARP_GRAD == 'adjoint'):

@@ -57,7 +57,7 @@ _SIGNATURES = {
     'lvg_conv2d_frames_wgrad_splits': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames_wgrad': [_vp] * 3 + [_i64] + [_i32] * 8 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_ada_warp': [_vp] * 5 + [_i32] * 4 + [_vp],
-    'lvg_ada_warp_adjoint': [_vp] * 5 + [_i32] * 4 + [_vp],
+    'lvg_ada_warp_adjoint': [_vp] * 6 + [_i32] * 4 + [_vp],
     'lvg_ada_colour': [_vp] * 6 + [_i32] * 5 + [_vp],
     'lvg_plane_sum': [_vp, _vp, _i64, _i64, _i32, _vp],
     'lvg_weight_prep2d': [_vp] * 5 + [_i32] * 5 + [_f32, _i32, _vp],

@@ -24,9 +24,13 @@ def _warp_launch(x, g, m, taps, transposed):
     x = x.contiguous()
     n, k, h, w = x.shape
     y = torch.empty_like(x)
-    fn = _hip.lib().lvg_ada_warp_adjoint if transposed else _hip.lib().lvg_ada_warp
     with torch.cuda.device(x.device):
-        rc = fn(x.data_ptr(), g.data_ptr(), m.data_ptr(), taps.data_ptr(), y.data_ptr(), n, k, h, w, _hip.stream(x.device))
+        if transposed:
+            work = torch.empty([n, k, (h + 6) * 2, (w + 6) * 2], dtype=torch.float32, device=x.device)     # gradient of the intermediate grid
+            rc = _hip.lib().lvg_ada_warp_adjoint(x.data_ptr(), g.data_ptr(), m.data_ptr(), taps.data_ptr(), work.data_ptr(), y.data_ptr(),
+                                                 n, k, h, w, _hip.stream(x.device))
+        else:
+            rc = _hip.lib().lvg_ada_warp(x.data_ptr(), g.data_ptr(), m.data_ptr(), taps.data_ptr(), y.data_ptr(), n, k, h, w, _hip.stream(x.device))
     _hip.check(rc, 'ada_warp_adjoint' if transposed else 'ada_warp')
     return y
 

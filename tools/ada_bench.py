@@ -1,7 +1,7 @@
 """ADA augmentation pipeline on the GPU at the shape of the sres discriminator input (16 clips x 8 frames 144x256): the fused geometric
 stage / colour pass (csrc/ada_augment.hip) against the composition of library ops (pad, upfirdn2d up, grid_sample, upfirdn2d down with the
-margins read back to the host; bmm + elementwise). 'fused' = the shipped default (fused launches where no gradient is needed, the
-composition under a gradient), 'adjoint' = LVG_ADA_WARP_GRAD=adjoint. MEASUREMENT TOOL (GPU).  python tools/ada_bench.py"""
+margins read back to the host; bmm + elementwise). 'fused' = the shipped default (fused forward, gather-form adjoint backward), 'hybrid' =
+LVG_ADA_WARP_GRAD=composed (fused launch only where no gradient is needed). MEASUREMENT TOOL (GPU).  python tools/ada_bench.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'long-video-gan_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -27,8 +27,8 @@ pipe = AugmentPipe(**{**TRAIN_SRES_KW, 'noise': 1, 'cutout': 1}).cuda()
 pipe.p.fill_(1.0)
 sup_w, sup_c = ada_ops.warp_supported, ada_ops.colour_supported
 from lvg import ada_augment as aa
-for name, fused in (('fused', True), ('composed', False), ('adjoint', True), ('fused', True)):
-    aa.WARP_GRAD = 'adjoint' if name == 'adjoint' else 'composed'
+for name, fused in (('fused', True), ('composed', False), ('hybrid', True), ('fused', True)):
+    aa.WARP_GRAD = 'composed' if name == 'hybrid' else 'adjoint'
     ada_ops.warp_supported = sup_w if fused else (lambda *a: False)
     ada_ops.colour_supported = sup_c if fused else (lambda *a: False)
     with torch.no_grad():
