@@ -53,9 +53,13 @@ def save_checkpoint(path, trainer, step: int) -> None:
 
 
 def save_G_ema(path, trainer, init_kwargs: Optional[dict] = None) -> None:
-    """The inference artefact: generator EMA weights + the constructor arguments to rebuild the network."""
+    """The inference artefact: generator EMA weights + the constructor arguments to rebuild the network (`init_kwargs`, default: the
+    arguments the trainer built its generator with, `trainer.G_init_kwargs`)."""
     net = trainer.G_ema if getattr(trainer, 'G_ema', None) is not None else trainer.G
-    torch.save(dict(format='lvg-G-1', init_kwargs=dict(init_kwargs or {}), state=_module_state(net)), path)
+    if init_kwargs is None:
+        init_kwargs = getattr(trainer, 'G_init_kwargs', None)
+        assert init_kwargs is not None, 'save_G_ema: pass the generator constructor arguments (the trainer does not record them)'
+    torch.save(dict(format='lvg-G-1', init_kwargs=dict(init_kwargs), state=_module_state(net)), path)
 
 
 def load_trainer_state(trainer, state: dict) -> int:

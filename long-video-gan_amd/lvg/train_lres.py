@@ -31,7 +31,8 @@ class LowResTrainer:
         self.G_magnitude_ema_beta, self.G_ema_beta, self.G_ema_warmup_steps = G_magnitude_ema_beta, G_ema_beta, G_ema_warmup_steps
         self.G_grad_accum, self.D_grad_accum, self.r1_gamma = G_grad_accum, D_grad_accum, r1_gamma
         self.G_random_temp_translate, self.temp_scale_augment, self.diffaug_policy = G_random_temp_translate, temp_scale_augment, diffaug_policy
-        self.G = VideoGenerator(out_height=height, out_width=width, **(G_kwargs or {})).to(self.device).requires_grad_(False).train()
+        self.G_init_kwargs = dict(out_height=height, out_width=width, **(G_kwargs or {}))       # what save_G_ema records for load_G
+        self.G = VideoGenerator(**self.G_init_kwargs).to(self.device).requires_grad_(False).train()
         self.D = VideoDiscriminator(seq_length=seq_length, max_edge=max(height, width), **(D_kwargs or {})).to(self.device).requires_grad_(False).train()
         for net in (self.G, self.D):
             ddp.broadcast_module(net, src=0)

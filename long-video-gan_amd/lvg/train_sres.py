@@ -45,7 +45,8 @@ class SuperResTrainer:
         self.augment_p_max, self.augment_p_update_rate, self.augment_real_sign_target = augment_p_max, augment_p_update_rate, augment_real_sign_target
 
         sizes = dict(hr_height=hr_height, hr_width=hr_width, lr_height=lr_height, lr_width=lr_width)
-        self.G = sres.VideoGenerator(temporal_context=temporal_context, compute_dtype=compute_dtype, **sizes, **(G_kwargs or {}))
+        self.G_init_kwargs = dict(temporal_context=temporal_context, compute_dtype=compute_dtype, **sizes, **(G_kwargs or {}))      # for save_G_ema / load_G
+        self.G = sres.VideoGenerator(**self.G_init_kwargs)
         self.D = sres.VideoDiscriminator(channels=channels, seq_length=seq_length, compute_dtype=compute_dtype, **sizes, **(D_kwargs or {}))
         for net in (self.G, self.D):
             net.to(self.device).requires_grad_(False).train()
