@@ -37,14 +37,29 @@ def _const(value, like: torch.Tensor) -> torch.Tensor:
     return torch.as_tensor(value, dtype=torch.float32, device=like.device)
 
 
+_MAT_BASE = {}          # (constant pattern, device) -> the matrix with zeros where per-sample tensors go
+
+
 def _mat(rows: Sequence[Sequence], device=None) -> torch.Tensor:
-    """Matrix from a nested list whose entries are python numbers or [N] tensors -> [N, r, c] (or [r, c])."""
+    """Matrix from a nested list whose entries are python numbers or [N] tensors -> [N, r, c] (or [r, c]).
+    With per-sample entries: ONE copy of a cached constant pattern, then one strided assignment per tensor entry (it used to be a
+    `full_like` per constant entry plus a stack: ~2 x the launches, and the pipeline is a chain of a hundred such tiny launches)."""
     tensors = [e for row in rows for e in row if isinstance(e, torch.Tensor)]
     if not tensors:
         return torch.tensor(np.asarray(rows, dtype=np.float32), device=device)
     ref = tensors[0]
-    flat = [e if isinstance(e, torch.Tensor) else torch.full_like(ref, float(e)) for row in rows for e in row]
-    return torch.stack(flat, dim=-1).reshape(*ref.shape, len(rows), len(rows[0]))
+    r, c = len(rows), len(rows[0])
+    const = tuple(0.0 if isinstance(e, torch.Tensor) else float(e) for row in rows for e in row)
+    key = (const, r, c, ref.device, ref.dtype)
+    base = _MAT_BASE.get(key)
+    if base is None:
+        base = _MAT_BASE[key] = torch.tensor(const, dtype=ref.dtype, device=ref.device).reshape(r, c)
+    out = base.expand(*ref.shape, r, c).clone()
+    for i, row in enumerate(rows):
+        for j, e in enumerate(row):
+            if isinstance(e, torch.Tensor):
+                out[..., i, j] = e
+    return out
 
 
 def shift2(tx, ty, **kw):
