@@ -637,7 +637,7 @@ static std::atomic<int> g_flrelu_impl{0};
 
 extern "C" int lvg_filtered_lrelu_set_impl(int impl)
 {
-    if (impl < 0 || impl > 2) return LVG_ERR_INVALID;
+    if (impl < 0 || impl > 3) return LVG_ERR_INVALID;     // 0 default, 1 fp32-VALU kernel, 2 round-2 MFMA kernel, 3 wave-per-tile MFMA kernel
     return g_flrelu_impl.exchange(impl);
 }
 
@@ -694,16 +694,27 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     p.sOfsX = sofs_x; p.sOfsY = sofs_y;
     p.gain = gain; p.slope = slope; p.clamp = clamp; p.flip = flip ? 1 : 0;
     p.tilesX = p.tilesY = 0;
+    {
+        // extent of the x tensor around its first element (the wave kernel's 16-byte loads may touch up to 14 bytes outside
+        // a plane, never outside the tensor)
+        const int64_t es = dtype == LVG_F32 ? 4 : (dtype == LVG_F64 ? 8 : 2);
+        int64_t lo = 0, hi = 0;
+        for (int i = 0; i < 4; i++) { const int64_t e = (xshape[i] - 1) * xstride[i]; if (e < 0) lo -= e; else hi += e; }
+        p.xLoB = lo * es; p.xHiB = (hi + 1) * es;
+    }
 
     hipStream_t st = (hipStream_t)stream;
     // 16-bit I/O: the MFMA kernel (filtered_lrelu_mfma.hip). LVG_FLRELU_MFMA=0 keeps the fp32-VALU kernel
     // for every dtype (A/B measurements, bisecting); float32 I/O always uses it (exact f32 intermediates).
     static const bool env_mfma = []() { const char* e = getenv("LVG_FLRELU_MFMA"); return !(e && e[0] == '0'); }();
+    // LVG_FLRELU_WAVE=0 selects the round-2 kernel (four waves per tile) instead of the wave-per-tile kernel (A/B measurements).
+    static const bool env_wave = []() { const char* e = getenv("LVG_FLRELU_WAVE"); return !(e && e[0] == '0'); }();
     const int impl = g_flrelu_impl.load(std::memory_order_relaxed);
-    const bool use_mfma = impl == 0 ? env_mfma : impl == 2;
+    const bool use_mfma = impl == 0 ? env_mfma : impl >= 2;
+    const bool use_wave = impl == 0 ? env_wave : impl == 3;
     if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
     {
-        const int rc = lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);
+        const int rc = use_wave ? lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st) : lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);
         if (rc != LVG_ERR_UNSUPPORTED) return rc;      // (planes of 2 GiB and more: the VALU kernel below)
     }
     switch (dtype)

@@ -22,9 +22,12 @@ struct FlreluArgs
     float        gain, slope, clamp;
     int          flip;
     int          tilesX, tilesY;
+    int64_t      xLoB, xHiB;     // bytes of the x tensor below / above p.x: every address in [x - xLoB, x + xHiB) belongs to it
 };
 
 enum { LVG_FLRELU_CFG_NONE = 0, LVG_FLRELU_CFG_POINTWISE, LVG_FLRELU_CFG_U2D2, LVG_FLRELU_CFG_U4D2, LVG_FLRELU_CFG_U2D4 };
 
 // filtered_lrelu_mfma.hip. dtype is LVG_F16 or LVG_BF16; cfg one of U2D2 / U4D2 / U2D4.
 int lvg_flrelu_mfma_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
+// filtered_lrelu_wave.hip (round 4: one wave per tile, no workgroup barrier). Same arguments.
+int lvg_flrelu_wave_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);

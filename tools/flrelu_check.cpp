@@ -24,7 +24,7 @@ typedef int (*orc_fn)(const double*, const double*, const double*, const double*
                       int, int, int, int, int, int, int, int, int, int, int, int, int, int, double, double, double, int, int, int, int);
 
 static flrelu_fn g_flrelu; static setimpl_fn g_setimpl; static err_fn g_err; static orc_fn g_orc;
-typedef int (*timing_fn)(uint32_t*, int); static timing_fn g_timing;
+typedef int (*timing_fn)(uint32_t*, int); static timing_fn g_timing, g_wtiming;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -95,6 +95,9 @@ static double max_err(const std::vector<uint16_t>& got, const std::vector<double
     return m;
 }
 
+static const char* impl_name(int impl) { return impl == 3 ? "WAVE" : impl == 2 ? "MFMA" : "VALU"; }
+static int g_impl_mask = 0xe;     // bit i: run impl i (FLRELU_IMPLS=3,2,1)
+
 static int run_check(const Case& cs, int dtype)
 {
     const float gain = sqrtf(2.0f), slope = 0.2f, clamp = 2.5f;
@@ -130,8 +133,9 @@ static int run_check(const Case& cs, int dtype)
     HIPCHK(hipMemset(dzb.p, 0, c * 2));
     const double tol = dtype == 1 ? 5e-3 : 3e-2;
     int fails = 0;
-    for (int impl = 2; impl >= 1; impl--)
+    for (int impl = 3; impl >= 1; impl--)
     {
+        if (!((g_impl_mask >> impl) & 1)) continue;
         HIPCHK(hipMemset(dy.p, 0xff, ny * 2)); HIPCHK(hipMemset(ds.p, 0xee, ns)); HIPCHK(hipMemset(ddx.p, 0xff, nx * 2));
         if (call(impl, dtype, dx.p, dy.p, db.p, (uint8_t*)ds.p, (float*)dfu.p, (float*)dfd.p, n, c, xh, xw, yh, yw, nu, nd, up, down, cs.px0, cs.py0,
                  swb, sh, 0, 0, sw_active, gain, slope, clamp, 0, 1)) return 1;
@@ -177,7 +181,7 @@ static int run_check(const Case& cs, int dtype)
         for (size_t i = 0; i < ny; i++) if (gy[i] != gy2[i]) nomask_diff++;
         const bool ok = wrel <= tol && bwrel <= tol && (double)diff / total <= 3e-4 && padbad == 0 && nomask_diff == 0;
         printf("%-14s %s impl=%s  y[%d,%d,%d,%d] fwd max %.2e mean %.2e rel %.2e | mask diff %.1e pad %zu | bwd max %.2e mean %.2e rel %.2e | nomask diff %zu  %s\n",
-               cs.name, dtype == 1 ? "f16 " : "bf16", impl == 2 ? "MFMA" : "VALU", n, c, yh, yw, me, mean, wrel, (double)diff / total, padbad, bme, bmean, bwrel, nomask_diff, ok ? "OK" : "FAIL");
+               cs.name, dtype == 1 ? "f16 " : "bf16", impl_name(impl), n, c, yh, yw, me, mean, wrel, (double)diff / total, padbad, bme, bmean, bwrel, nomask_diff, ok ? "OK" : "FAIL");
         if (!ok) fails++;
     }
     return fails;
@@ -210,9 +214,10 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
     HIPCHK(hipMemset(dzb.p, 0, c * 2));
     const int pp0 = (nu - 1) + (nd - 1) - cs.px0, pq0 = (nu - 1) + (nd - 1) - cs.py0;
     const double gg = (double)gain * up * up / (down * down);
-    for (int impl = 2; impl >= 1; impl--)
+    for (int impl = 3; impl >= 1; impl--)
     {
         if (g_only_impl && impl != g_only_impl) continue;
+        if (!g_only_impl && !((g_impl_mask >> impl) & 1)) continue;
         auto once = [&]() {
             if (mode == 2)
                 return call(impl, dtype, ddy.p, ddx.p, dzb.p, (uint8_t*)ds.p, (float*)dfd.p, (float*)dfu.p, n, c, yh, yw, xh, xw, nd, nu, down, up, pp0, pq0,
@@ -238,8 +243,27 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
         }
         const double bytes = (double)(nx + ny) * 2 + (mode ? (double)ns : 0.0);
         printf("%-10s %s %-5s impl=%s  %8.1f us  %7.1f GB/s  (%.3f of 8 TB/s; algorithmic bytes %.1f MB)\n", cs.name, dtype == 1 ? "f16 " : "bf16",
-               mode == 1 ? "fwd+s" : mode == 0 ? "fwd" : "bwd", impl == 2 ? "MFMA" : "VALU", best * 1e3, bytes / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 8e12, bytes / 1e6);
+               mode == 1 ? "fwd+s" : mode == 0 ? "fwd" : "bwd", impl_name(impl), best * 1e3, bytes / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 8e12, bytes / 1e6);
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (g_wtiming && impl == 3)     // -DLVG_TIMING build of the wave kernel
+        {
+            std::vector<uint32_t> t(4096 * 16);
+            if (g_wtiming(t.data(), 4096 * 16) == 0)
+            {
+                static const char* names[10] = {"loop", "loads", "mask-in", "stageA", "xwrite", "stageBC", "wwrite", "mask-out", "stageD", "ystore"};
+                double sum[12] = {0}; double tiles = 0; int waves = 0;
+                for (int wv = 0; wv < 4096; wv++)
+                {
+                    if (!t[wv * 16 + 12]) continue;
+                    waves++; tiles += t[wv * 16 + 12];
+                    for (int r = 0; r < 10; r++) sum[r] += t[wv * 16 + r];
+                }
+                double tot = 0; for (int r = 0; r < 10; r++) tot += sum[r];
+                printf("  wave timing: %d waves, %.1f tiles each; cycles per tile per wave:", waves, tiles / waves);
+                for (int r = 0; r < 10; r++) printf(" %s %.0f", names[r], sum[r] / tiles);
+                printf(" | total %.0f\n", tot / tiles);
+            }
+        }
         if (g_timing && impl == 2)      // -DLVG_TIMING build of the library: cycles per region, mean over waves, per tile
         {
             std::vector<uint32_t> t(4096 * 16);
@@ -275,6 +299,8 @@ int main(int argc, char** argv)
     g_err = (err_fn)dlsym(lib, "lvg_last_error"); g_orc = (orc_fn)dlsym(orc, "orc_filtered_lrelu");
     if (!g_flrelu || !g_setimpl || !g_err || !g_orc) { printf("missing symbol\n"); return 2; }
     g_timing = (timing_fn)dlsym(lib, "lvg_flrelu_timing_read");
+    g_wtiming = (timing_fn)dlsym(lib, "lvg_flrelu_wave_timing_read");
+    if (const char* im = getenv("FLRELU_IMPLS")) { g_impl_mask = 0; for (const char* c = im; *c; c++) if (*c >= '1' && *c <= '3') g_impl_mask |= 1 << (*c - '0'); }
     int fails = 0;
     if (what == "check" || what == "all")
     {
@@ -286,6 +312,12 @@ int main(int argc, char** argv)
             {"L5_u4d2", 2, 3, 40, 54, 4, 2, 24, 12, -6, -9, -6, -9},
             {"L10_u4d2", 1, 3, 94, 150, 4, 2, 24, 12, -6, -9, -6, -9},
             {"tap4_u2d2", 2, 3, 30, 41, 2, 2, 4, 4, 3, 2, 3, 2},
+            {"L3_u4d2", 2, 5, 31, 38, 4, 2, 24, 12, -6, -9, -6, -9},
+            {"L6_u2d2", 3, 2, 58, 86, 2, 2, 12, 12, 9, 8, 9, 8},
+            {"odd_u2d2", 2, 2, 33, 47, 2, 2, 12, 12, 8, 9, 8, 9},
+            {"odd_u4d2", 1, 3, 21, 27, 4, 2, 24, 12, -5, -10, -5, -10},
+            {"wide_u2d2", 1, 2, 20, 300, 2, 2, 12, 12, 9, 8, 9, 8},
+            {"tall_u2d2", 1, 2, 300, 20, 2, 2, 12, 12, 9, 8, 9, 8},
         };
         for (const Case& cs : cases)
             for (int dtype = 1; dtype <= 2; dtype++) fails += run_check(cs, dtype);
