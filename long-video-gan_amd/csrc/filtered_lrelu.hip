@@ -714,7 +714,8 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     const bool use_wave = impl == 0 ? env_wave : impl == 3;
     if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
     {
-        const int rc = use_wave ? lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st) : lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);
+        int rc = use_wave ? lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st) : LVG_ERR_UNSUPPORTED;
+        if (rc == LVG_ERR_UNSUPPORTED) rc = lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);      // (slope > 1: the round-2 kernel)
         if (rc != LVG_ERR_UNSUPPORTED) return rc;      // (planes of 2 GiB and more: the VALU kernel below)
     }
     switch (dtype)

@@ -219,12 +219,26 @@ template <> __device__ __forceinline__ half2v pair_plus_bias<bf16_t>(uint32_t ra
     return r;
 }
 
-// Two f32 -> one dword of T (element 0 in the low half).
-template <class T> __device__ __forceinline__ uint32_t pack_pair(float a, float b)
+// Two f32 -> one dword of T (element 0 in the low half): one v_cvt_pk_* (written as a vector conversion; two scalar conversions
+// were paired across the wrong elements and glued back with four more instructions).
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf162v __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ uint32_t pack_pair(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack_pair<f16_t>(float a, float b)
 {
-    const T ta = from_acc<T>(a), tb = from_acc<T>(b);
-    return (uint32_t)ta.bits | ((uint32_t)tb.bits << 16);
+    const float2v f = {a, b};
+    const half2v h = __builtin_convertvector(f, half2v);
+    uint32_t u; __builtin_memcpy(&u, &h, 4); return u;
 }
+template <> __device__ __forceinline__ uint32_t pack_pair<bf16_t>(float a, float b)
+{
+    const float2v f = {a, b};
+    const bf162v h = __builtin_convertvector(f, bf162v);
+    uint32_t u; __builtin_memcpy(&u, &h, 4); return u;
+}
+
+// idx / D for the small indices of the vector maps (exact for idx < 65536 / D ... checked for the ranges used: tools note in DESIGN)
+template <int D> __device__ __forceinline__ int div_small(int idx) { return (int)(((uint32_t)idx * (uint32_t)((65536 + D - 1) / D)) >> 16); }
 
 struct ActConst
 {
@@ -408,7 +422,6 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
         K.selOdd = 0x01010101u * (uint32_t)(2 + g);
         K.sh01[0] = 0; K.sh01[1] = 2; K.sh23[0] = 4; K.sh23[1] = 6;
     }
-    const bool slopeMax = p.slope <= 1.0f;                                  // lrelu(x) = max(x, slope * x) (slope >= 0 is asserted by the caller)
     // No pre-activation of a tile can exceed  scale * l1(up taps per phase)^2 * max |x + bias|  in magnitude (and leaky
     // ReLU with slope <= 1 only shrinks it), so tiles whose input maximum stays below clamp / that factor (5 % margin
     // for the f16 roundings) skip the clamp and the "clamped" flag arithmetic: xLimitBits = that threshold as f16 bits
@@ -435,14 +448,16 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
     //      plane (rows above / below the image, and the wrap of negative ones) return zeros without faulting, whatever
     //      they fetch is replaced when the tile is written to LDS. ---------------------------------------------------
     const uint32_t pitchB = (uint32_t)((int)p.xs[2]) * 2u, colB = (uint32_t)((int)p.xs[3]) * 2u;
-    int ldRow[G::NLOAD], ldCol[G::NLOAD];                                   // this lane's vector of pass i: row, first column (-1: none)
+    // this lane's vector of pass i: (row, first column) = (idx / LPR, 8 (idx % LPR)), idx = lane + 64 i; recomputed where needed (a
+    // few integer operations) instead of held in registers; only the byte offset from the tile's first pixel is kept.
+    auto ld_row = [&](int i) __attribute__((always_inline)) { return div_small<G::LPR>(lane + 64 * i); };
+    auto ld_col = [&](int i, int row) __attribute__((always_inline)) { return (lane + 64 * i < G::NVEC) ? 8 * (lane + 64 * i - row * G::LPR) : -1; };
+    uint32_t ldOff[G::NLOAD];
     #pragma unroll
     for (int i = 0; i < G::NLOAD; i++)
     {
-        const int idx = lane + 64 * i;
-        ldRow[i] = idx / G::LPR;
-        ldCol[i] = 8 * (idx - ldRow[i] * G::LPR);
-        if (idx >= G::NVEC) { ldRow[i] = 0; ldCol[i] = -1; }
+        const int r = ld_row(i), c = ld_col(i, r);
+        ldOff[i] = (c >= 0) ? (uint32_t)r * pitchB + (uint32_t)c * colB : 0u;
     }
     v4u raw[G::NLOAD];                                                      // prefetched vectors of the NEXT tile (storage bits)
     float biasN = 0.0f;
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xpl - lo), 0, (int)planeSpanB + lo + hi, 0x00020000);
             #pragma unroll
             for (int i = 0; i < G::NLOAD; i++)
-                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + (uint32_t)lo + (uint32_t)ldRow[i] * pitchB + (uint32_t)max(ldCol[i], 0) * 2u), 0, 0);
+                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + (uint32_t)lo + ldOff[i]), 0, 0);
             if (lo < 16 || hi < 16)
             {
                 // first / last plane of the tensor: a vector that straddles the tensor's edge came back as zeros; fetch its pixels one by one
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
                 #pragma unroll
                 for (int i = 0; i < G::NLOAD; i++)
                 {
-                    const int o = (int)(base + (uint32_t)ldRow[i] * pitchB + (uint32_t)max(ldCol[i], 0) * 2u);
+                    const int o = (int)(base + ldOff[i]);
                     if ((o < 0 && o + 16 > 0) || (o < (int)planeSpanB && o + 16 > (int)planeSpanB))
                     {
                         #pragma unroll
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
             #pragma unroll
             for (int i = 0; i < G::NLOAD; i++)
             {
-                const uint32_t o = base + (uint32_t)ldRow[i] * pitchB + (uint32_t)max(ldCol[i], 0) * colB;
+                const uint32_t o = base + ldOff[i];
                 #pragma unroll
                 for (int d = 0; d < 4; d++)
                 {
@@ -524,17 +539,18 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
         #pragma unroll
         for (int i = 0; i < G::NLOAD; i++)
         {
-            const bool active = ldCol[i] >= 0;
+            const int lrow = ld_row(i), lcol = ld_col(i, lrow);
+            const bool active = lcol >= 0;
             // bit e of `valid`: pixel e of this lane's vector is a pixel of the image (integer arithmetic only: the compare / lane-mask
             // form of these tests cost more scalar and vector instructions than the rest of the loader)
             uint32_t valid = 0xffu;
             if (!interior)
             {
-                const int lo = min(max(xLo - ldCol[i], 0), 8), hi = min(max(xHi - ldCol[i], 0), 8);
+                const int lo = min(max(xLo - lcol, 0), 8), hi = min(max(xHi - lcol, 0), 8);
                 valid = (0xffu >> (8 - hi)) & (0xffu << lo);
-                valid = ((uint32_t)(ldRow[i] - yLo) < (uint32_t)(yHi - yLo)) ? valid : 0u;
+                valid = ((uint32_t)(lrow - yLo) < (uint32_t)(yHi - yLo)) ? valid : 0u;
             }
-            else if (G::LPR * 8 > G::IN_NX) valid = 0xffu >> max(ldCol[i] + 8 - G::IN_NX, 0);   // (the columns of a row's last vector beyond the tile)
+            else if (G::LPR * 8 > G::IN_NX) valid = 0xffu >> max(lcol + 8 - G::IN_NX, 0);   // (the columns of a row's last vector beyond the tile)
             v4u hvv;
             #pragma unroll
             for (int d = 0; d < 4; d++)
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
                     __builtin_memcpy(&mx2, &cm, 4);
                 }
             }
-            if (active) *reinterpret_cast<v4u*>(XL + ldRow[i] * G::SX + ldCol[i]) = hvv;
+            if (active) *reinterpret_cast<v4u*>(XL + lrow * G::SX + lcol) = hvv;
         }
         uint32_t m = 0;
         if (MODE != LVG_SIGNS_READ)
@@ -622,14 +638,14 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
     // ---- output: stage D leaves output row n in lane n; the tile goes through LDS once (the W region is free by then) and
     //      leaves as 16-byte vectors, vector lane + 64 i in pass i. -----------------------------------------------------
     const uint32_t yPitchB = (uint32_t)((int)p.ys[2]) * 2u, yColB = (uint32_t)((int)p.ys[3]) * 2u;
-    int stRow[G::NSTORE], stCol[G::NSTORE];
+    auto st_row = [&](int i) __attribute__((always_inline)) { return div_small<G::NVY>(lane + 64 * i); };
+    auto st_col = [&](int i, int row) __attribute__((always_inline)) { return (row < TH) ? 8 * (lane + 64 * i - row * G::NVY) : -1; };
+    uint32_t stOff[G::NSTORE];
     #pragma unroll
     for (int i = 0; i < G::NSTORE; i++)
     {
-        const int idx = lane + 64 * i;
-        stRow[i] = idx / G::NVY;
-        stCol[i] = 8 * (idx - stRow[i] * G::NVY);
-        if (stRow[i] >= TH) { stRow[i] = 0; stCol[i] = -1; }
+        const int r = st_row(i), c = st_col(i, r);
+        stOff[i] = (c >= 0) ? (uint32_t)r * yPitchB + (uint32_t)c * yColB : 0u;
     }
     const bool fastStore = p.ys[3] == 1;                                    // (16-byte stores need no alignment beyond the element's)
 
@@ -665,62 +681,62 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
 
         const bool hasNext = tile + kWaves < tileEnd, hasNext2 = tile + 2 * kWaves < tileEnd;
         TileCoord nxt2 = nxt;
-        if (hasNext2) advance(nxt2);
         uint32_t tmaxNext = 0;
         LVG_TICK(1);
 
-        // The tile body is instantiated per activation variant and selected ONCE per tile: inside it the four column blocks of a
-        // row block are one straight-line stretch the compiler can software-pipeline (a per-block branch on the variant cut it
-        // into pieces).
-        auto tile_body = [&](auto slopeMaxC, auto clampC) __attribute__((always_inline))
+        #pragma unroll
+        for (int vb = 0; vb < VB; vb++)
         {
-            constexpr bool SLOPEMAX = decltype(slopeMaxC)::value, CLAMP = decltype(clampC)::value;
-            #pragma unroll
-            for (int vb = 0; vb < VB; vb++)
+            // ---- READ: this row block's mask bytes; the next block's (or the next tile's first) loads go out ----------
+            uint32_t M8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (MODE == LVG_SIGNS_READ)
             {
-                // ---- READ: this row block's mask bytes; the next block's (or the next tile's first) loads go out ----------
-                uint32_t M8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (MODE == LVG_SIGNS_READ)
-                {
-                    stage_mask(M8);
-                    if (vb + 1 < VB) issue_mask_loads(cur, vb + 1);
-                    else if (hasNext) issue_mask_loads(nxt, 0);
-                }
-                LVG_TICK(2);
+                stage_mask(M8);
+                if (vb + 1 < VB) issue_mask_loads(cur, vb + 1);
+                else if (hasNext) issue_mask_loads(nxt, 0);
+            }
+            LVG_TICK(2);
 
-                // ---- stage A: T'[ic][v] for the 32 rows v of this block --------------------------------------------
-                half8 tpk[G::IN_BLK][2];
+            // ---- stage A: T'[ic][v] for the 32 rows v of this block --------------------------------------------
+            half8 tpk[G::IN_BLK][2];
+            {
+                f32x16 accA[G::IN_BLK];
+                #pragma unroll
+                for (int m = 0; m < G::IN_BLK; m++) accA[m] = zero16();
+                const int c0 = UpChunks<UP>::first(vb), cnt = UpChunks<UP>::count(vb), cls0 = UpChunks<UP>::cls0(vb);
+                #pragma unroll
+                for (int t = 0; t < 2; t++)
                 {
-                    f32x16 accA[G::IN_BLK];
-                    #pragma unroll
-                    for (int m = 0; m < G::IN_BLK; m++) accA[m] = zero16();
-                    const int c0 = UpChunks<UP>::first(vb), cnt = UpChunks<UP>::count(vb), cls0 = UpChunks<UP>::cls0(vb);
-                    #pragma unroll
-                    for (int t = 0; t < 2; t++)
+                    if (t < cnt)
                     {
-                        if (t < cnt)
+                        #pragma unroll
+                        for (int m = 0; m < G::IN_BLK; m++)
                         {
-                            #pragma unroll
-                            for (int m = 0; m < G::IN_BLK; m++)
-                            {
-                                const half8 xt = lds_tr_operand(XL, G::SX, 16 * (c0 + t), 32 * m, lane);
-                                accA[m] = mfma(xt, fAy[cls0 + t * UpChunks<UP>::step()], accA[m]);
-                            }
+                            const half8 xt = lds_tr_operand(XL, G::SX, 16 * (c0 + t), 32 * m, lane);
+                            accA[m] = mfma(xt, fAy[cls0 + t * UpChunks<UP>::step()], accA[m]);
                         }
                     }
-                    #pragma unroll
-                    for (int m = 0; m < G::IN_BLK; m++) { tpk[m][0] = pack_chunk(accA[m], 0); tpk[m][1] = pack_chunk(accA[m], 1); }
                 }
-                LVG_TICK(3);
-                // the last row block has read the input tile: the prefetched next tile can replace it (LDS operations of a wave
-                // execute in order)
-                if (vb == VB - 1 && !(LVG_WABL & 1))
-                {
-                    if (hasNext) tmaxNext = write_tile();
-                    if (hasNext2) issue_loads(nxt2);
-                }
-                LVG_TICK(4);
+                #pragma unroll
+                for (int m = 0; m < G::IN_BLK; m++) { tpk[m][0] = pack_chunk(accA[m], 0); tpk[m][1] = pack_chunk(accA[m], 1); }
+            }
+            LVG_TICK(3);
+            // the last row block has read the input tile: the prefetched next tile can replace it (LDS operations of a wave
+            // execute in order)
+            if (vb == VB - 1 && !(LVG_WABL & 1))
+            {
+                if (hasNext) tmaxNext = write_tile();
+                if (hasNext2) { advance(nxt2); issue_loads(nxt2); }
+            }
+            LVG_TICK(4);
 
+            // Stages B, activation, C, the W rows and the mask of this row block: instantiated per activation variant and selected once
+            // per row block, so that the four column blocks are one straight-line stretch the compiler can software-pipeline (a
+            // per-block branch on the variant cut it into pieces). Loader and stage A above are shared by the variants.
+            uint32_t mdw[4] = {0, 0, 0, 0};
+            auto row_block = [&](auto slopeMaxC, auto clampC) __attribute__((always_inline))
+            {
+                constexpr bool SLOPEMAX = decltype(slopeMaxC)::value, CLAMP = decltype(clampC)::value;
                 // One 32 x 32 block of U^T = A_x * T' (stage B) for column block b of the up-sampled tile.
                 auto stage_b = [&](int b) __attribute__((always_inline)) -> f32x16
                 {
@@ -742,7 +758,6 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
                 f32x16 accW[G::OBX];
                 #pragma unroll
                 for (int bo = 0; bo < G::OBX; bo++) accW[bo] = zero16();
-                uint32_t mdw[4] = {0, 0, 0, 0};
                 f32x16 accU = stage_b(0);
                 #pragma unroll
                 for (int b = 0; b < 4; b++)
@@ -782,71 +797,72 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
                     }
                 LVG_TICK(6);
 
-                // ---- WRITE mode: this row block's mask -> global, only the part this tile owns ----------------------------
-                if (MODE == LVG_SIGNS_WRITE)
+            };
+            if (MODE == LVG_SIGNS_READ) row_block(BoolC<true>(), BoolC<false>());
+            else if (noClamp)           row_block(BoolC<true>(), BoolC<false>());
+            else                        row_block(BoolC<true>(), BoolC<true>());   // (slope > 1: the launcher hands the call to the round-2 kernel)
+            // ---- WRITE mode: this row block's mask -> global, only the part this tile owns ----------------------------
+            if (MODE == LVG_SIGNS_WRITE)
+            {
+                // lanes (n, g = 0) / (n, g = 1) hold the even / odd bytes of the 8 mask bytes of a block: exchange, interleave,
+                // and every lane owns 4 consecutive bytes (8 b + 4 g ..) of row n
+                const uint32_t selIl = g ? 0x07030602u : 0x05010400u;
+                #pragma unroll
+                for (int b = 0; b < 4; b++)
                 {
-                    // lanes (n, g = 0) / (n, g = 1) hold the even / odd bytes of the 8 mask bytes of a block: exchange, interleave,
-                    // and every lane owns 4 consecutive bytes (8 b + 4 g ..) of row n
-                    const uint32_t selIl = g ? 0x07030602u : 0x05010400u;
+                    const uint2v sw = __builtin_amdgcn_permlane32_swap(mdw[b], mdw[b], false, false);    // [0] = even bytes, [1] = odd bytes of the row
+                    *reinterpret_cast<uint32_t*>(ML + n * G::SM + 8 * b + 4 * g) = __builtin_amdgcn_perm(sw[1], sw[0], selIl);
+                }
+                const int row = lane >> 1, half = lane & 1;
+                const uint32_t* m = reinterpret_cast<const uint32_t*>(ML + row * G::SM + 16 * half);
+                uint32_t wds[4] = {m[0], m[1], m[2], m[3]};
+                const int uStart = outX0 * DOWN, upY0 = outY0 * DOWN + 32 * vb;   // (sign offsets are 0 when writing)
+                const int signByte0 = uStart >> 2;
+                const int ownRows = ((tileY == p.tilesY - 1) ? G::V : TH * DOWN) - 32 * vb;
+                const int sy = upY0 + row;
+                const bool lastX = tileX == p.tilesX - 1;
+                // bytes of this lane's 16 the tile owns and the plane has; bytes at and beyond swLimit carry no pixels: 0
+                const int b0 = signByte0 + 16 * half;
+                const int nOwn = min(16, (lastX ? p.sWBytes : signByte0 + (TW * DOWN) / 4) - b0);
+                const int nPix = p.swLimit - b0;
+                if (lastX)
+                {
                     #pragma unroll
-                    for (int b = 0; b < 4; b++)
+                    for (int d = 0; d < 4; d++)
                     {
-                        const uint2v sw = __builtin_amdgcn_permlane32_swap(mdw[b], mdw[b], false, false);    // [0] = even bytes, [1] = odd bytes of the row
-                        *reinterpret_cast<uint32_t*>(ML + n * G::SM + 8 * b + 4 * g) = __builtin_amdgcn_perm(sw[1], sw[0], selIl);
+                        const int nv = nPix - 4 * d;
+                        if (nv < 4) wds[d] = nv <= 0 ? 0u : (wds[d] & ((1u << (8 * nv)) - 1u));
                     }
-                    const int row = lane >> 1, half = lane & 1;
-                    const uint32_t* m = reinterpret_cast<const uint32_t*>(ML + row * G::SM + 16 * half);
-                    uint32_t wds[4] = {m[0], m[1], m[2], m[3]};
-                    const int uStart = outX0 * DOWN, upY0 = outY0 * DOWN + 32 * vb;   // (sign offsets are 0 when writing)
-                    const int signByte0 = uStart >> 2;
-                    const int ownRows = ((tileY == p.tilesY - 1) ? G::V : TH * DOWN) - 32 * vb;
-                    const int sy = upY0 + row;
-                    const bool lastX = tileX == p.tilesX - 1;
-                    // bytes of this lane's 16 the tile owns and the plane has; bytes at and beyond swLimit carry no pixels: 0
-                    const int b0 = signByte0 + 16 * half;
-                    const int nOwn = min(16, (lastX ? p.sWBytes : signByte0 + (TW * DOWN) / 4) - b0);
-                    const int nPix = p.swLimit - b0;
-                    if (lastX)
+                }
+                const bool dwAligned = (signByte0 & 3) == 0;                 // (rows of the mask plane are dword aligned)
+                if (row < ownRows && sy < p.sH && !(LVG_WABL & 16))
+                {
+                    uint8_t* srow = p.s + (int64_t)cur.plane * ((int64_t)p.sH * p.sWBytes) + (uint32_t)(sy * p.sWBytes) + b0;
+                    if (nOwn == 16 && dwAligned) *reinterpret_cast<uint4*>(srow) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+                    else
                     {
                         #pragma unroll
                         for (int d = 0; d < 4; d++)
                         {
-                            const int nv = nPix - 4 * d;
-                            if (nv < 4) wds[d] = nv <= 0 ? 0u : (wds[d] & ((1u << (8 * nv)) - 1u));
-                        }
-                    }
-                    const bool dwAligned = (signByte0 & 3) == 0;                 // (rows of the mask plane are dword aligned)
-                    if (row < ownRows && sy < p.sH && !(LVG_WABL & 16))
-                    {
-                        uint8_t* srow = p.s + (int64_t)cur.plane * ((int64_t)p.sH * p.sWBytes) + (uint32_t)(sy * p.sWBytes) + b0;
-                        // the row padding can reach beyond the 32 bytes of the tile: define it as 0 too
-                        if (lastX && half == 1)
-                            for (int kb = 16; kb < 24 && b0 + kb < p.sWBytes; kb++) srow[kb] = 0;
-                        if (nOwn <= 0) {}
-                        else if (nOwn == 16 && dwAligned) *reinterpret_cast<uint4*>(srow) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-                        else
-                        {
-                            #pragma unroll
-                            for (int d = 0; d < 4; d++)
+                            if (4 * d + 4 <= nOwn && dwAligned) *reinterpret_cast<uint32_t*>(srow + 4 * d) = wds[d];
+                            else
                             {
-                                if (4 * d + 4 <= nOwn && dwAligned) *reinterpret_cast<uint32_t*>(srow + 4 * d) = wds[d];
-                                else
-                                {
-                                    #pragma unroll
-                                    for (int kb = 0; kb < 4; kb++)
-                                        if (4 * d + kb < nOwn) srow[4 * d + kb] = (uint8_t)(wds[d] >> (8 * kb));
-                                }
+                                #pragma unroll
+                                for (int kb = 0; kb < 4; kb++)
+                                    if (4 * d + kb < nOwn) srow[4 * d + kb] = (uint8_t)(wds[d] >> (8 * kb));
                             }
                         }
                     }
+                    // the row padding can reach beyond the 32 bytes of the tile: define it as 0 too
+                    if (lastX && half == 1)
+                    {
+                        #pragma unroll 1
+                        for (int kb = 16; kb < 24 && b0 + kb < p.sWBytes; kb++) srow[kb] = 0;
+                    }
                 }
-                LVG_TICK(7);
             }
-        };
-        if (MODE == LVG_SIGNS_READ) tile_body(BoolC<true>(), BoolC<false>());
-        else if (!slopeMax)         tile_body(BoolC<false>(), BoolC<true>());
-        else if (noClamp)           tile_body(BoolC<true>(), BoolC<false>());
-        else                        tile_body(BoolC<true>(), BoolC<true>());
+            LVG_TICK(7);
+        }
 
         // ---- stage D: Y^T[ox][oy] = W^T * D_y^T: lanes = output rows, registers 4q .. 4q + 3 = four consecutive ox ------
         if (!(LVG_WABL & 8))
@@ -881,16 +897,17 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
             #pragma unroll
             for (int i = 0; i < G::NSTORE; i++)
             {
-                const v4u v = *reinterpret_cast<const v4u*>(YL + stRow[i] * G::YP + max(stCol[i], 0) * 2);
-                const uint32_t yoff = ybase + (uint32_t)stRow[i] * yPitchB + (uint32_t)max(stCol[i], 0) * yColB;
-                if (stCol[i] >= 0 && stRow[i] < rowsHere && !(LVG_WABL & 2))
+                const int srow = st_row(i), scol = st_col(i, srow);
+                const v4u v = *reinterpret_cast<const v4u*>(YL + (scol >= 0 ? srow * G::YP + scol * 2 : 0));
+                const uint32_t yoff = ybase + stOff[i];
+                if (scol >= 0 && srow < rowsHere && !(LVG_WABL & 2))
                 {
-                    if (fastStore && stCol[i] + 8 <= colsHere) *reinterpret_cast<v4u*>(ypl + yoff) = v;
+                    if (fastStore && scol + 8 <= colsHere) *reinterpret_cast<v4u*>(ypl + yoff) = v;
                     else
                     {
                         #pragma unroll
                         for (int e = 0; e < 8; e++)
-                            if (stCol[i] + e < colsHere) *reinterpret_cast<uint16_t*>(ypl + yoff + (uint32_t)e * yColB) = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+                            if (scol + e < colsHere) *reinterpret_cast<uint16_t*>(ypl + yoff + (uint32_t)e * yColB) = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
                     }
                 }
             }
@@ -918,6 +935,8 @@ int launch_wave(FlreluArgs& p, int mode, hipStream_t stream)
     p.tilesY = (p.yh + TH - 1) / TH;
     const int64_t tiles = (int64_t)p.tilesX * p.tilesY * p.n * p.c;
     LVG_REQUIRE(tiles <= 0x7fffffffLL, "filtered_lrelu: too many tiles for one launch");
+    // leaky ReLU as max(x, slope * x) needs slope <= 1 (forward modes; the READ mode multiplies by a looked-up factor)
+    if (mode != LVG_SIGNS_READ && !(p.slope <= 1.0f)) return LVG_ERR_UNSUPPORTED;
     // lane offsets inside a plane are 32-bit byte offsets
     if (((int64_t)p.xh * p.xs[2] + (int64_t)p.xw * p.xs[3]) * 2 >= 0x7fffffffLL || ((int64_t)p.yh * p.ys[2] + (int64_t)p.yw * p.ys[3]) * 2 >= 0x7fffffffLL ||
         (int64_t)p.sH * p.sWBytes >= 0x7fffffffLL || p.xs[2] < 0 || p.xs[3] < 0 || p.ys[2] < 0 || p.ys[3] < 0)

@@ -151,7 +151,8 @@ static int run_check(const Case& cs, int dtype)
             for (int v = 0; v < sh; v++)
             {
                 const uint8_t* a = &gs[(pl * sh + v) * swb]; const uint8_t* r = &sref[(pl * sh + v) * swb];
-                for (int u = 0; u < sw_active; u++) { total++; if (((a[u >> 2] >> ((u & 3) * 2)) & 3) != ((r[u >> 2] >> ((u & 3) * 2)) & 3)) diff++; }
+                for (int u = 0; u < sw_active; u++) { total++; if (((a[u >> 2] >> ((u & 3) * 2)) & 3) != ((r[u >> 2] >> ((u & 3) * 2)) & 3)) { diff++;
+                    if (getenv("FLRELU_DEBUG_MASK") && diff <= 12) printf("    mask mismatch plane %zu v %d u %d (byte %d): got %d want %d\n", pl, v, u, u >> 2, (a[u >> 2] >> ((u & 3) * 2)) & 3, (r[u >> 2] >> ((u & 3) * 2)) & 3); } }
                 for (int k = (sw_active + 3) >> 2; k < swb; k++) if (a[k]) padbad++;
             }
         // backward-shaped call reading the GPU's own mask; oracle in READ mode on the same mask
