@@ -590,7 +590,9 @@ int run_fused(FlreluArgs& p, int cfg, int mode, hipStream_t stream)
     switch (cfg)
     {
         case CFG_POINTWISE: return launch_pointwise<T>(p, mode, stream);
-        case CFG_U2D2:      return launch_fused<T, 2, 2, 12, 12, 64, 32>(p, mode, stream);
+        // (narrow planes -- the float32 layers of the super-resolution generator are 36 x 29 -- take a 40-column tile: one tile
+        // per plane either way, two thirds of the up-sampled columns)
+        case CFG_U2D2:      return p.yw <= 40 ? launch_fused<T, 2, 2, 12, 12, 40, 32>(p, mode, stream) : launch_fused<T, 2, 2, 12, 12, 64, 32>(p, mode, stream);
         case CFG_U4D2:      return launch_fused<T, 4, 2, 24, 12, 64, 32>(p, mode, stream);
         case CFG_U2D4:      return launch_fused<T, 2, 4, 12, 24, 32, 16>(p, mode, stream);
     }
