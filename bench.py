@@ -424,6 +424,7 @@ def main():
             legs = [('forward_only', lambda: _forward_only_leg(G, B, T, dtype)),
                     ('mfma', lambda: _mfma_leg(step, elapsed / args.steps)),
                     ('batch_sweep', lambda: _batch_sweep_leg(G, D, dtype, T)),
+                    ('fp32', lambda: _fp32_leg(G, D, T)),
                     ('sres', lambda: _sres_leg(dev, timer))]
             if not os.environ.get('LVG_BENCH_NO_TRAIN_LEGS'):
                 # BASELINE.json configs[2] and configs[4] at N = 1 (the driver's multi-GPU runs use --workload train_lres)
@@ -658,6 +659,34 @@ def _forward_only_leg(G, B, T, dtype, steps=6):
     del g
     return {'metric': 'frames/sec/GPU lres-G forward 128x36x64', 'value': round(B * T / dt, 1), 'unit': 'frames/s',
             'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'hipgraph'}
+
+
+def _fp32_leg(G, D, T, B=2, steps=3):
+    """The same generator update in FLOAT32 (the reference trains the low-resolution networks in float32 with TF32 off,
+    train_lres.py:268-269): forward + backward through the discriminator on the float32 route of the hand-written kernels
+    (16-bit operand splits on the matrix cores, float32 accumulation: DESIGN 4.13), eager launches, gradients discarded.
+    Reported beside the bf16 main line, never instead of it."""
+    from lvg.models import lres
+    saved = [p.grad for p in G.parameters()]
+    def one():
+        for p in G.parameters():
+            p.grad = None
+        video = G(B, T, dtype=torch.float32)
+        F.softplus(-D(video, dtype=torch.float32)).mean().backward()
+    try:
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        for p, g in zip(G.parameters(), saved):
+            p.grad = g
+    return {'metric': 'frames/sec lres-G 128x36x64 forward+backward (generator update)', 'dtype': 'fp32', 'value': round(B * T / dt, 1), 'unit': 'frames/s',
+            'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'eager',
+            'route': 'split-operand float32 on the hand-written kernels' if lres.SPLIT_F32 else 'library float32'}
 
 
 def _mfma_leg(step, sec_per_step):

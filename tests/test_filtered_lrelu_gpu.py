@@ -16,7 +16,9 @@ from torch_utils.ops import filtered_lrelu
 DEV = 'cuda'
 # float64: gain/slope/clamp cross the C ABI as float32 (as in the reference plugin), hence 1e-6.
 TOL = {torch.float32: dict(rtol=5e-5, atol=5e-6), torch.float64: dict(rtol=2e-6, atol=2e-7),
-       torch.float16: dict(rtol=5e-3, atol=5e-3), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+       # 16-bit gates at about twice the measured worst case of the MFMA kernels (tools/flrelu_check: float16 forward 9e-4, the
+       # up-2 / down-4 backward 1.6e-3 of |want| + 1; bfloat16 3.2e-3): VERDICT r03 weak 2
+       torch.float16: dict(rtol=2e-3, atol=2e-3), torch.bfloat16: dict(rtol=1e-2, atol=1e-2)}
 
 
 def dev(a, dtype, grad=False):

@@ -24,32 +24,51 @@ def _build(device):
     return G.to(device).requires_grad_(True), D.to(device).requires_grad_(True)
 
 
-def _pre_activation_spy(records):
+def _pre_activation_spy(records, pin_to=None, pinned=None):
     """Patch of lres._TapConvEpilogue._backward that also records z = ysum * pre + b (+ res) of every activated call (the argument of the
-    leaky ReLU whose derivative the backward pass takes): returns the original to restore."""
+    leaky ReLU whose derivative the backward pass takes): returns the original to restore.
+
+    `pin_to` (records of another run, same call order): where the sign of z differs from that run's, the saved sum handed to the backward
+    pass is moved so that z takes the OTHER run's sign (magnitude 1e-4 of the layer's maximum) -- the leaky-ReLU derivative of those
+    elements is then the one the other run used; nothing else changes. `pinned` collects |z_other| / max |z_other| of the moved elements."""
     from lvg.models import lres
     orig = lres._TapConvEpilogue._backward
+    other = {}
+    for key, z in (pin_to or []):
+        other.setdefault(key, []).append(z)
+    seen = {}
 
     def spy(ctx, x, weight, ysum, pre, b, res, post, dout, wt_packed, need):
         if ctx.cfg[2] != 'linear' and ysum is not None:
-            z = ysum.detach().double()
-            if pre is not None:
-                z = z * pre.detach().double().reshape(z.shape[0], -1, 1, 1)
+            scale = None if pre is None else pre.detach().double().reshape(ysum.shape[0], -1, 1, 1)
+            shift = torch.zeros((), dtype=torch.float64, device=ysum.device)
             if b is not None:
-                z = z + b.detach().double().reshape(1, -1, 1, 1)
+                shift = shift + b.detach().double().reshape(1, -1, 1, 1)
             if res is not None:
-                z = z + res.detach().double()
-            records.append(((tuple(x.shape), tuple(weight.shape)), z.cpu()))
+                shift = shift + res.detach().double()
+            z = ysum.detach().double() * (1.0 if scale is None else scale) + shift
+            key = (tuple(x.shape), tuple(weight.shape))
+            i = seen.get(key, 0)
+            seen[key] = i + 1
+            records.append((key, z.cpu()))
+            if pin_to is not None and key in other and i < len(other[key]):
+                zo = other[key][i].to(z.device)
+                differs = zo.sign() != z.sign()
+                if bool(differs.any()):
+                    pinned += [float(v) for v in (zo[differs].abs() / zo.abs().max())]
+                    target = zo.sign() * 1e-4 * zo.abs().max()
+                    want_sum = (target - shift) / (1.0 if scale is None else scale)
+                    ysum = torch.where(differs, want_sum.to(ysum.dtype), ysum)
         return orig(ctx, x, weight, ysum, pre, b, res, post, dout, wt_packed, need)
     lres._TapConvEpilogue._backward = staticmethod(spy)
     return orig
 
 
-def _forward_backward(device, g, records=None):
+def _forward_backward(device, g, records=None, pin_to=None, pinned=None):
     """One generator + discriminator pass on the golden inputs -> (features' rms, video, logits, loss, the seven parameter gradients)."""
     from lvg.models import lres
     G, D = _build(device)
-    orig = _pre_activation_spy(records) if records is not None else None
+    orig = _pre_activation_spy(records, pin_to, pinned) if records is not None else None
     try:
         noise = torch.tensor(g['noise'], device=device)
         emb = G.temporal_emb.blur(noise)
@@ -80,14 +99,16 @@ def _run(device, rtol_grad):
     5e-7 .. 1e-5. This repo's networks order the float32 arithmetic differently (modulation on the activations, demodulation on the output,
     fused epilogues) and sit at 1e-6 .. 5e-4 on the CPU.
 
-    Leaky-ReLU kinks: this golden has pre-activations within 4e-8 .. 5e-7 (relative to the layer's maximum) of zero, one of them in the
-    104 k-element first block of the generator. Two correct float32 evaluations that round such an element to different sides of zero
-    differ by 9e-2 in that layer's gradients and 9e-3 in the gradient of the network input (measured between the library route and the
-    split-operand route on the hand-written kernels, profiles/r03_f32_kink_flips.log; the library's own timed algorithm search flips it from
-    run to run). So: the gates are checked as they stand; a GPU run that misses them passes only if (a) the library route of the same
-    device meets them and (b) every pre-activation whose sign differs between the two routes lies within 1e-5 of zero (relative to the
-    layer's maximum: the pre-activations of the two routes agree to 4e-6 .. 7e-6, their float32 noise over 13 824-term sums) and at least one
-    does -- i.e. the deviation is the kink, not the arithmetic. Measured: 7 differing signs, the farthest 4.7e-7 from zero."""
+    Leaky-ReLU kinks. The 16-frame networks evaluate ~2e7 leaky-ReLU arguments; the nearest to zero lie 4e-8 .. 5e-7 of their layer's maximum
+    away from it, and two correct float32 evaluations agree in those arguments to 4e-6 .. 7e-6 only (13 824-term sums). An element that lands
+    on the other side of zero changes that layer's derivative from 1 to 0.2: 9e-2 in the layer's gradients, 9e-3 in the gradient of the
+    network input (profiles/r03_f32_kink_flips.log) -- a discontinuity of the function, not an error of either evaluation. No choice of seed
+    removes it (the expected number of arguments within 1e-5 of zero is several hundred for ANY input of this size), so the fixture is kept
+    and the EVALUATION is made independent of the kink instead: on the GPU the hand-written float32 route runs a second time
+    with the sign of every leaky-ReLU argument pinned to the sign the library route of the same device computed (`_pre_activation_spy`,
+    `pin_to`), and THAT run is held to the gates as they stand -- `rtol_grad` against the float32 golden, 1e-3 against the float64 one. The
+    pinned elements must lie within 1e-5 of zero (relative to the layer's maximum); the library route must meet the same gates unpinned. The
+    unpinned errors of the hand route are recorded for the record (profiles/r04_parity_measured.json)."""
     g = load_golden('lres_models')
     g64 = load_golden('lres_models_f64')
     records = [] if device != 'cpu' else None
@@ -104,12 +125,11 @@ def _run(device, rtol_grad):
     assert abs(loss - float(g['loss'])) < 1e-3
     vs32, vs64 = _gradient_errors(grads, g), _gradient_errors(grads, g64)
     record_measured(f'lres_T16_f32_grads_vs_reference_f64_{device}', **vs64)
-    ok = max(vs32.values()) <= rtol_grad and max(vs64.values()) < 1e-3
-    if ok or device == 'cpu':
-        assert ok, (vs32, vs64)
+    if device == 'cpu':
+        assert max(vs32.values()) <= rtol_grad and max(vs64.values()) < 1e-3, (vs32, vs64)
         return
     from lvg.models import lres
-    assert lres.SPLIT_F32, (vs32, vs64)                    # the library route has nothing to be compared with
+    assert lres.SPLIT_F32, 'the hand-written float32 route is the one under test'
     lres.SPLIT_F32 = False
     try:
         lib_records = []
@@ -118,21 +138,15 @@ def _run(device, rtol_grad):
         lres.SPLIT_F32 = True
     lib32, lib64 = _gradient_errors(lib_grads, g), _gradient_errors(lib_grads, g64)
     assert max(lib32.values()) <= rtol_grad and max(lib64.values()) < 1e-3, ('library route', lib32, lib64)
-    lib_z = {}
-    for key, z in lib_records:
-        lib_z.setdefault(key, []).append(z)
-    seen, flipped = {}, []
-    for key, z in records:
-        i = seen.get(key, 0)
-        seen[key] = i + 1
-        if key in lib_z and i < len(lib_z[key]):
-            zl = lib_z[key][i]
-            differs = zl.sign() != z.sign()
-            flipped += [float(v) for v in (zl[differs].abs() / zl.abs().max())]
-    record_measured(f'lres_T16_f32_kink_flips_{device}', flips=len(flipped), largest_relative_distance_from_zero=max(flipped, default=0.0),
-                    split_route_vs_f64=max(vs64.values()), library_route_vs_f64=max(lib64.values()))
-    assert flipped and max(flipped) < 1e-5, ('deviation not explained by leaky-ReLU kinks', flipped[:8], vs32, vs64)
-    assert max(vs32.values()) < 3e-2, (vs32, vs64)          # a flipped element of the 104 k-element block moves the deep gradients by ~1e-2; not more
+    pinned, pin_records = [], []
+    _, _, pin_video, pin_logits, _, pin_grads = _forward_backward(device, g, pin_records, pin_to=lib_records, pinned=pinned)
+    pin32, pin64 = _gradient_errors(pin_grads, g), _gradient_errors(pin_grads, g64)
+    record_measured(f'lres_T16_f32_kink_pinned_{device}', pinned_elements=len(pinned), largest_relative_distance_from_zero=max(pinned, default=0.0),
+                    hand_route_unpinned_vs_f64=max(vs64.values()), hand_route_pinned_vs_f64=max(pin64.values()), hand_route_pinned_vs_f32=max(pin32.values()),
+                    library_route_vs_f64=max(lib64.values()))
+    assert max(pinned, default=0.0) < 1e-5, ('a pinned leaky-ReLU argument is not at the kink', sorted(pinned)[-4:])
+    np.testing.assert_allclose(pin_video, g['video'], rtol=0, atol=1e-3)
+    assert max(pin32.values()) <= rtol_grad and max(pin64.values()) < 1e-3, ('hand-written float32 route, kinks pinned', pin32, pin64, len(pinned))
 
 
 def test_state_dict_keys_match_reference_layout():
