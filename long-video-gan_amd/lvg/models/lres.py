@@ -337,11 +337,95 @@ class _TemporalConvFrames(torch.autograd.Function):
         return gx, gw, None, None
 
 
+# The contraction as a node that can be differentiated any number of times ON THE HAND-WRITTEN KERNELS (round 4; R1 differentiates the
+# discriminator's input gradient again, reference model/video_gan_lres.py:180-197). A convolution is linear in each argument, so the
+# three passes are closed under differentiation: with  C(x, w) = conv,  D(g, w) = data gradient,  W(x, g) = weight gradient,
+#     C' : (dx, dw)  = (D(gy, w), W(x, gy))        D' : (dg, dw) = (C(ggx, w), W(ggx, g))        W' : (dx, dg) = (D(g, ggw), C(x, ggw))
+# and every right-hand side is again one launch of conv3d_igemm / conv3d_wgrad at the layer's own shapes. Round 3 sent the whole pass to
+# the library's kt-convolution form instead (`second_order()`), 2.0 s per R1 update in the driver line. LVG_HAND_SECOND_ORDER=0 restores that.
+HAND_SECOND_ORDER = os.environ.get('LVG_HAND_SECOND_ORDER', '1') == '1'
+
+
+def _flip_w(weight: torch.Tensor) -> torch.Tensor:
+    """The weight of the data gradient: taps mirrored, channel roles swapped."""
+    return weight.flip(2, 3, 4).transpose(0, 1)
+
+
+class _HandConv(torch.autograd.Function):
+    """C(x, w): conv3d ('same' in time and space) on time-major frames, channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, weight, n):
+        ctx.save_for_backward(x, weight)
+        ctx.n = n
+        return conv3d_frames.conv3d_frames_forward(_cl(x), weight, n, keep_sum=False)[0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = _HandDgrad.apply(gy, weight, ctx.n) if ctx.needs_input_grad[0] else None
+        gw = _HandWgrad.apply(x, gy, tuple(weight.shape[2:]), ctx.n) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class _HandDgrad(torch.autograd.Function):
+    """D(g, w): the data gradient of C = the convolution of g with the mirrored, transposed weight."""
+
+    @staticmethod
+    def forward(ctx, g, weight, n):
+        ctx.save_for_backward(g, weight)
+        ctx.n = n
+        return conv3d_frames.conv3d_frames_forward(_cl(g), _flip_w(weight), n, keep_sum=False)[0]
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, weight = ctx.saved_tensors
+        dg = _HandConv.apply(ggx, weight, ctx.n) if ctx.needs_input_grad[0] else None
+        dw = _HandWgrad.apply(ggx, g, tuple(weight.shape[2:]), ctx.n) if ctx.needs_input_grad[1] else None
+        return dg, dw, None
+
+
+class _HandWgrad(torch.autograd.Function):
+    """W(x, g): the weight gradient [Co, Ci, kt, kh, kw] of C, in x's dtype (float32 accumulation, one rounding)."""
+
+    @staticmethod
+    def forward(ctx, x, g, taps, n):
+        ctx.save_for_backward(x, g)
+        ctx.n = n
+        kt, kh, kw = taps
+        return conv3d_frames.conv3d_frames_wgrad(_cl(x), _cl(g), kt, kh, kw, n).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, g = ctx.saved_tensors
+        ggw = ggw.to(x.dtype)
+        dx = _HandDgrad.apply(g, ggw, ctx.n) if ctx.needs_input_grad[0] else None
+        dg = _HandConv.apply(x, ggw, ctx.n) if ctx.needs_input_grad[1] else None
+        return dx, dg, None, None
+
+
+def _hand_second_order_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) -> bool:
+    """All three passes of this layer on the hand-written kernels (the derivatives reuse exactly these shapes)? CPU tensors take the
+    plain definitions behind the same nodes (tests)."""
+    if not HAND_SECOND_ORDER or weight.dim() != 5 or tuple(padding_hw) != (weight.shape[3] // 2, weight.shape[4] // 2):
+        return False
+    if not x.is_cuda:
+        return True
+    co, ci = weight.shape[:2]
+    if x.dtype not in (torch.float16, torch.bfloat16) or ci % 64 or co % 64 or weight.dtype != x.dtype:
+        return False
+    xc = _cl(x)
+    return (_hand_conv_takes(xc, weight, padding_hw) and _hand_conv_shape_ok(xc, co, ci, weight, padding_hw)
+            and _hand_wgrad_shape_ok(xc, co, weight, padding_hw) and conv3d_frames.supported(xc, weight))
+
+
 def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw) -> torch.Tensor:
     """conv3d with 'same' zero padding in time, as kt 2-D convolutions. x [(T N), Ci, H, W] and
     weight [Co, Ci, kt, kh, kw] in the compute dtype."""
     if POINTWISE_GEMM and tuple(weight.shape[2:]) == (1, 1, 1):
         return pointwise_conv(x, weight[:, :, 0, 0, 0])
+    if SECOND_ORDER and _hand_second_order_takes(x, weight, padding_hw):
+        return _HandConv.apply(x, weight, n)
     return _TemporalConvFrames.apply(x, weight, n, tuple(padding_hw))
 
 

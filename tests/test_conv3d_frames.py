@@ -410,3 +410,64 @@ def test_split32_matches_oracle_at_float32_accuracy_gpu(oracle, case):
         errs['gw'] = float(np.abs(_np(gw) - gw_ref).max() / np.abs(gw_ref).max())
     record_measured(f'lres_split32_{kt}x{kh}x{kw}_{ci}to{co}', **errs)
     assert max(errs.values()) < 2e-5, errs
+
+
+def test_second_order_nodes_are_closed_under_differentiation_cpu():
+    """lres._HandConv / _HandDgrad / _HandWgrad (the twice-differentiable contraction of the R1 pass; on CPU tensors the same nodes run
+    the plain definitions): value, input gradient and the gradients of an R1-style penalty on that gradient against autograd of F.conv3d."""
+    import torch.nn.functional as F
+    from lvg.models import lres
+    torch.manual_seed(0)
+    T, N, ci, co, h, w = 6, 2, 4, 5, 5, 6
+    x = torch.randn(T * N, ci, h, w, requires_grad=True)
+    wt = (torch.randn(co, ci, 3, 3, 3) * 0.3).requires_grad_(True)
+
+    def ref(x, wt):
+        v = x.reshape(T, N, ci, h, w).permute(1, 2, 0, 3, 4)
+        return F.conv3d(v, wt, padding=1).permute(2, 0, 1, 3, 4).reshape(T * N, co, h, w)
+
+    def r1(fn):
+        y = fn(x, wt)
+        (g,) = torch.autograd.grad(y.tanh().sum(), [x], create_graph=True)
+        gw, gx = torch.autograd.grad(g.square().sum(), [wt, x])
+        return y.detach(), g.detach(), gw, gx
+
+    with lres.second_order():
+        got = r1(lambda x, wt: lres.temporal_conv_frames(x, wt, N, (1, 1)))
+    for a, b, name in zip(got, r1(ref), ['y', 'dx', 'd penalty / dw', 'd penalty / dx']):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_second_order_on_hand_kernels_matches_library_route_gpu(dtype, monkeypatch):
+    """The R1 pattern through one discriminator-sized layer (64 -> 128 channels, 5 x 3 x 3, 32 x 32 pixels): penalty on the input gradient,
+    differentiated with respect to weight and input, on the hand-written kernels vs the library's kt-convolution form (float32 as the
+    yardstick: both 16-bit routes must sit within 16-bit rounding of it). Every pass must have run on conv3d_igemm / conv3d_wgrad."""
+    from lvg.models import lres
+    from torch_utils.ops import conv3d_frames
+    torch.manual_seed(1)
+    T, N, ci, co, h, w = 8, 2, 64, 128, 32, 32
+    x32 = torch.randn(T * N, ci, h, w, device='cuda').contiguous(memory_format=torch.channels_last)
+    w32 = torch.randn(co, ci, 5, 3, 3, device='cuda') / (ci * 45) ** 0.5
+
+    def r1(dt, hand):
+        monkeypatch.setattr(lres, 'HAND_SECOND_ORDER', hand)
+        x = x32.to(dt).requires_grad_(True)
+        wt = w32.to(dt).requires_grad_(True)
+        with lres.second_order():
+            y = lres.temporal_conv_frames(x, wt, N, (1, 1))
+        (g,) = torch.autograd.grad(y.float().tanh().sum(), [x], create_graph=True)
+        gw, gx = torch.autograd.grad(g.float().square().sum(), [wt, x])
+        return [t.detach().float() for t in (y, g, gw, gx)]
+
+    ref = r1(torch.float32, False)
+    before = conv3d_frames.stats['launches']
+    hand = r1(dtype, True)
+    assert conv3d_frames.stats['launches'] - before >= 5            # C, D, then C / W (from D') and D / W (from C')
+    lib = r1(dtype, False)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    for a, b, c, name in zip(hand, lib, ref, ['y', 'dx', 'd penalty / dw', 'd penalty / dx']):
+        scale = float(c.abs().max())
+        assert float((a - c).abs().max()) <= tol * scale, (name, 'hand route', float((a - c).abs().max()) / scale)
+        assert float((b - c).abs().max()) <= tol * scale, (name, 'library route', float((b - c).abs().max()) / scale)
