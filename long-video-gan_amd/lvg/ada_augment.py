@@ -394,7 +394,9 @@ class AugmentPipe(torch.nn.Module):
 
     def random_temporal_filter(self, video: torch.Tensor, min_ksize: int = 2, max_ksize: int = 16, max_std: float = 1.0) -> torch.Tensor:
         """Random per-sample FIR along time: a box of random length plus zero-mean noise taps (so the
-        filter sums to one); a sample takes the filtered clip where p < u, u uniform (as the reference)."""
+        filter sums to one); a sample takes the filtered clip where p < u, u uniform (as the reference).
+        GPU clips always draw the random numbers and run the filter (no host read of p), so with p <= 0 the GPU path consumes random
+        numbers where the CPU / reference path returns early: same result, different position in the random stream afterwards."""
         assert video.dim() == 5 and 2 <= min_ksize <= max_ksize
         if not video.is_cuda and self.p.item() <= 0:                 # (GPU clips: no host read of p -- the mask below covers p <= 0)
             return video

@@ -17,19 +17,41 @@ def _module_state(module) -> Optional[dict]:
     return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
 
 
-def trainer_state(trainer, step: int) -> dict:
-    """Everything `load_trainer_state` needs to resume `trainer` (single rank; ranks hold identical copies): networks, generator
-    EMA, both optimizers, the random streams (CPU and the trainer's GPU) and -- for the super-resolution trainer -- the ADA state the
-    reference's `ckpt()` stores next to the networks (model/video_gan_sres.py: `augment`, `in_augment`, `real_sign_collector`):
-    the adapted probability `augment.p`, the conditioning-side pipe's buffers and the real-sign statistics accumulated since the
-    last probability update."""
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _own_rng(trainer) -> dict:
+    rng = dict(cpu=torch.get_rng_state())
+    dev = getattr(trainer, 'device', None)
+    if dev is not None and torch.device(dev).type == 'cuda' and torch.cuda.is_available():
+        rng['cuda'] = torch.cuda.get_rng_state(torch.device(dev))
+    return rng
+
+
+def trainer_state(trainer, step: int, all_ranks: bool = False) -> dict:
+    """Everything `load_trainer_state` needs to resume `trainer`: networks, generator EMA, both optimizers, the random streams (CPU and
+    the trainer's GPU) and -- for the super-resolution trainer -- the ADA state the reference's `ckpt()` stores next to the networks
+    (model/video_gan_sres.py: `augment`, `in_augment`, `real_sign_collector`): the adapted probability `augment.p`, the conditioning-side
+    pipe's buffers and the real-sign statistics accumulated since the last probability update.
+
+    Ranks hold identical copies of the networks and optimizers, but NOT of the random streams (every rank draws its own latents,
+    augmentations and noise: train_lres.py:69). `rng` is therefore the CALLING rank's stream, tagged with its rank and the world size, and
+    is only restored into that same rank of a run of the same size. `all_ranks=True` (a collective: every rank must call) additionally
+    gathers every rank's streams into `rng_ranks`, so that a multi-rank resume continues every stream bit for bit."""
+    rank, world = _rank_world()
     state = dict(format='lvg-train-1', step=int(step),
                  G=_module_state(trainer.G), D=_module_state(trainer.D), G_ema=_module_state(getattr(trainer, 'G_ema', None)),
                  G_opt=_cpu(trainer.G_opt.state_dict()), D_opt=_cpu(trainer.D_opt.state_dict()),
-                 rng=dict(cpu=torch.get_rng_state()))
-    dev = getattr(trainer, 'device', None)
-    if dev is not None and torch.device(dev).type == 'cuda' and torch.cuda.is_available():
-        state['rng']['cuda'] = torch.cuda.get_rng_state(torch.device(dev))
+                 rng=_own_rng(trainer), rng_rank=rank, rng_world=world)
+    if all_ranks and world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, _cpu(state['rng']))
+        state['rng_ranks'] = gathered
     for name in ('augment', 'in_augment'):
         if getattr(trainer, name, None) is not None:
             state[name] = _module_state(getattr(trainer, name))
@@ -78,10 +100,19 @@ def load_trainer_state(trainer, state: dict) -> int:
             trainer._real_sign_sum.copy_(state['real_sign_sum'])
     trainer.G_opt.load_state_dict(state['G_opt'])
     trainer.D_opt.load_state_dict(state['D_opt'])
-    if 'rng' in state and 'cpu' in state['rng']:
-        torch.set_rng_state(state['rng']['cpu'])
-    if 'rng' in state and 'cuda' in state['rng'] and torch.cuda.is_available() and torch.device(getattr(trainer, 'device', 'cpu')).type == 'cuda':
-        torch.cuda.set_rng_state(state['rng']['cuda'], torch.device(trainer.device))
+    # Random streams: a rank continues ITS OWN stream or keeps the one it has. Restoring the saving rank's stream into every rank would
+    # make all ranks draw identical latents / augmentations / noise from then on.
+    rank, world = _rank_world()
+    rng = None
+    if state.get('rng_ranks') is not None and len(state['rng_ranks']) == world:
+        rng = state['rng_ranks'][rank]
+    elif 'rng' in state and state.get('rng_world', 1) == world and state.get('rng_rank', 0) == rank:
+        rng = state['rng']
+    if rng is not None:
+        if 'cpu' in rng:
+            torch.set_rng_state(rng['cpu'])
+        if 'cuda' in rng and torch.cuda.is_available() and torch.device(getattr(trainer, 'device', 'cpu')).type == 'cuda':
+            torch.cuda.set_rng_state(rng['cuda'], torch.device(trainer.device))
     return int(state['step'])
 
 

@@ -493,6 +493,7 @@ def _pair_view(t: torch.Tensor) -> torch.Tensor:
 
 
 def _unpair_view(t: torch.Tensor) -> torch.Tensor:
+    t = _cl(t)                                  # (a dense channels-last buffer is what the strides below describe; a no-op for the kernels' own outputs)
     f, c2, h, w2 = t.shape
     return t.as_strided((f, c2 // 2, h, 2 * w2), (h * w2 * c2, 1, w2 * c2, c2 // 2))
 
@@ -579,6 +580,8 @@ def _hand_conv_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw, cl: bool
         return False
     if _pairable(x, weight):
         co, ci, kt, kh, kw = weight.shape
+        if weight.dtype != x.dtype or _cl(x).data_ptr() % 16:          # (what conv3d_frames.supported checks on the paired views)
+            return False
         return conv3d_frames.workgroups(x.shape[0], x.shape[2], x.shape[3] // 2, 2 * ci, 2 * co, kt, kh, kw) >= HAND_CONV_MIN_TILES
     if not conv3d_frames.supported(_cl(x) if cl else x, weight):
         return False

@@ -16,8 +16,11 @@ from .modconv_epilogue import _init
 
 
 def warp_supported(x, taps):
+    """(the size bound is the ADJOINT kernel's workspace, 4 (h + 6) (w + 6) floats per plane, indexed with 32 bits: a clip the forward
+    kernel would take but whose backward could not run goes to the composed path as a whole)"""
     return (x.device.type == 'cuda' and x.dtype == torch.float32 and x.dim() == 4 and taps.dim() == 1 and taps.shape[0] == 12
-            and x.shape[2] >= 2 and x.shape[3] >= 2 and x.numel() < 2 ** 31 and _init())
+            and x.shape[2] >= 2 and x.shape[3] >= 2 and x.numel() < 2 ** 31
+            and x.shape[0] * x.shape[1] * (x.shape[2] + 6) * (x.shape[3] + 6) * 4 < 2 ** 31 and _init())
 
 
 def _warp_launch(x, g, m, taps, transposed):

