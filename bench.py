@@ -386,7 +386,7 @@ def main():
         def line(name):
             """roofline object of one kernel family: HBM-bound streams in GB/s, the convolution in TFLOP/s."""
             d = fam[name]
-            common = dict(kernel=name, traffic=_pmc_traffic(name), launches=d['launches'], avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
+            common = dict(kernel=name, traffic=_pmc_traffic(name, 'lres'), traffic_source=_TRAFFIC_SOURCE.format(scope='lres'), launches=d['launches'], avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
                           measured_on='all launches of this kernel from one step, captured once each (step order) into a hipGraph replayed 3x between HIP events on the launch stream, right after the timed region')
             if name in flop_ops:
                 tf = d['bytes'] / (d['total_ms'] * 1e-3) / 1e12          # the work unit of these entries is FLOPs
@@ -792,7 +792,8 @@ def _sres_leg(dev, timer, segments=2, steps=6, warmup=2):
            'config': {'workload': f'generator_sres + discriminator_sres, {segments} segments x 8 frames 144x256 from 36x64 (+-4 context), Adam step', 'global_batch': segments},
            'roofline': {'bound': 'hbm', 'kernel': 'filtered_lrelu', 'achieved': round(gb, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gb / HBM_PEAK_GBPS, 4),
                         'launches': n, 'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2), 'algorithmic_bytes_per_launch': int(tot_b / max(n, 1)),
-                        'traffic': _pmc_traffic('filtered_lrelu_mfma'), 'traffic_scope': 'per launch of the MFMA kernel family only (16-bit layers)',
+                        'traffic': _pmc_traffic('filtered_lrelu_wave', 'sres'), 'traffic_source': _TRAFFIC_SOURCE.format(scope='sres'),
+                        'traffic_scope': 'per launch of the MFMA (wave-per-tile) kernel family only (16-bit layers)',
                         'algorithmic_bytes_per_launch_mfma_family': int(mf_bytes / max(mf_launches, 1)), 'launches_mfma_family': mf_launches,
                         'measured_on': 'all fused filtered_lrelu launches of one step (forward with mask write, backward with mask read), captured once each into a hipGraph per family, replayed 3x between HIP events',
                         'families': {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1)) for k, v in ops.items()},
@@ -804,9 +805,15 @@ def _sres_leg(dev, timer, segments=2, steps=6, warmup=2):
     return out
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/*traffic*.json), else None."""
-    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+_TRAFFIC_SOURCE = ('profiles/traffic_{scope}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload (tools/gpu_traffic.sh), '
+                   'committed with the round; NOT collected in this invocation')
+
+
+def _pmc_traffic(kernel, scope):
+    """HBM bytes per launch of `kernel` in the `scope` workload ('lres': the main line's step, 'sres': the super-resolution leg) from the
+    committed rocprofv3 --pmc run of that workload (profiles/traffic_<scope>.json), else None. Keyed by workload: the same kernel family
+    moves different tensors in the two steps."""
+    path = os.path.join(ROOT, 'profiles', f'traffic_{scope}.json')
     try:
         with open(path) as f:
             return json.load(f).get(kernel)

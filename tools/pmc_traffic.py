@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {'conv2d_wgrad': 'conv2d_wgrad', 'conv2d_igemm': ', 2, 2, true, ', 'conv3d_igemm': 'conv3d_igemm', 'conv3d_wgrad': 'conv3d_wgrad', 'bias_act': 'bias_act', 'upfirdn2d': 'upfirdn2d', 'filtered_lrelu_mfma': 'filtered_lrelu_mfma', 'filtered_lrelu': 'filtered_lrelu',
+FAMILIES = {'conv2d_wgrad': 'conv2d_wgrad', 'conv2d_igemm': ', 2, 2, true, ', 'conv3d_igemm': 'conv3d_igemm', 'conv3d_wgrad': 'conv3d_wgrad', 'bias_act': 'bias_act', 'upfirdn2d': 'upfirdn2d', 'filtered_lrelu_wave': 'filtered_lrelu_wave', 'filtered_lrelu_mfma': 'filtered_lrelu_mfma', 'filtered_lrelu': 'filtered_lrelu',
             'tapconv_epilogue': 'tapconv_', 'modconv_epilogue': 'epilogue_', 'modconv2d_layout': 'LayoutArgs'}     # first match wins
 
 
