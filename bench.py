@@ -514,7 +514,11 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
     assert total_batch % world == 0
     B = total_batch // world
     if accum is None:
-        accum = max(2, B // 8) if B % 2 == 0 else 1
+        # micro-batches of at most 8 clips (the size the main line measures); ONE micro-batch whenever the rank's share is 8 clips or
+        # fewer -- at 8 ranks that is 4 clips in one pass instead of the reference recipe's 2 x 2 (train_lres.py:65-69: its accumulation
+        # exists to fit 32 clips into 8 x 32 GB; 288 GB of HBM do not need it, the gradient mean is the same, and the per-launch fixed cost
+        # of the step is paid once instead of twice: VERDICT r03 item 4b)
+        accum = max(1, B // 8)
     torch.manual_seed(0)
     tr = LowResTrainer(seq_length=frames_per_clip, device=dev, compute_dtype=dtype, G_grad_accum=accum, D_grad_accum=accum,
                        overlap_grad_sync=True, with_ema=True)
