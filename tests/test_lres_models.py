@@ -55,7 +55,7 @@ def _pre_activation_spy(records, pin_to=None, pinned=None):
                 zo = other[key][i].to(z.device)
                 differs = zo.sign() != z.sign()
                 if bool(differs.any()):
-                    pinned += [float(v) for v in (zo[differs].abs() / zo.abs().max())]
+                    pinned.extend(float(v) for v in (zo[differs].abs() / zo.abs().max()))
                     target = zo.sign() * 1e-4 * zo.abs().max()
                     want_sum = (target - shift) / (1.0 if scale is None else scale)
                     ysum = torch.where(differs, want_sum.to(ysum.dtype), ysum)
