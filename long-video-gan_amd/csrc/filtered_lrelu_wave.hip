@@ -19,8 +19,8 @@
 //     neighbouring output pixels of a row, and a store instruction writes 128 contiguous bytes per row instead of
 //     32 scattered 8-byte pieces (the round-3 ablation put the scattered stores at a quarter of the time);
 //   * the mask leaves / enters the registers as whole dwords: bytes are assembled with v_perm / v_sad_u8 and one
-//     v_permlane32_swap per block instead of byte-wide LDS traffic; READ mode turns 2-bit codes into packed
-//     gradient factors with two v_perm look-ups instead of LDS look-ups.
+//     v_permlane32_swap per block instead of byte-wide LDS traffic; READ mode turns a mask byte into the four packed
+//     gradient factors of its pixels with ONE 8-byte LDS table read (the kernel is bound by the vector-instruction port).
 //
 // Arithmetic (unchanged): f16 operands (bfloat16 tensors are converted: their 8-bit mantissa is exact in f16), f32
 // accumulation; T', Z and W are rounded to f16 between stages; filter taps are rounded to f16.
@@ -99,7 +99,11 @@ struct WGeo
     static constexpr int TAPS   = (FU + FD + 3) / 4 * 4;
     // LDS map (bytes)
     static constexpr int OFF_TAPS  = 0;
-    static constexpr int OFF_TAB   = TAPS * 4;
+    static constexpr int OFF_LUT   = TAPS * 4;                              // READ mode: mask byte -> four packed gradient factors (8 bytes per entry)
+    static constexpr int WAVES_LDS = X_ROWS * SX * 2 + 64 + V * SW * 2 + 16 + (HAS_M ? 32 * SM : 0);
+    // 256 entries where the two workgroups of a CU leave room, else the 171 a writer can produce (codes 0..2 per pixel: <= 0xAA)
+    static constexpr int LUTN      = MODE != LVG_SIGNS_READ ? 0 : ((2 * (OFF_LUT + 2048 + NDY * 1024 + kWaves * WAVES_LDS) <= 160 * 1024) ? 256 : 171);
+    static constexpr int OFF_TAB   = OFF_LUT + (LUTN * 8 + 15) / 16 * 16;
     static constexpr int OFF_WAVE  = OFF_TAB + NDY * 1024;
     static constexpr int X_BYTES   = X_ROWS * SX * 2 + 64;                  // (+64: stage A's last transpose read runs past the last row; its result is never used)
     static constexpr int W_BYTES   = V * SW * 2 + 16;                       // (the output staging rows alias W: stage D has read W when it writes them)
@@ -244,9 +248,8 @@ struct ActConst
 {
     half2v slope2, clampP, clampN;
     uint32_t clampBits;
-    uint32_t lut0, lut1;          // READ: low / high bytes of the f16 factors of codes 0..3 (1, slope, 0, 0)
-    uint32_t selEven, selOdd;     // READ: v_perm selectors replicating this lane's mask byte of an even / odd q
-    ushort2v sh01, sh23;          // READ: per-half shifts (0, 2) and (4, 6)
+    uint32_t shEven, shOdd;       // READ: bit offset of this lane's mask byte inside its dword for an even / odd q
+    uint32_t lutBase;             // READ: LDS byte address of the factor table
 };
 
 // Activation of one 32 x 32 block of U^T held as an MFMA result (register r = pixel u = (r & 3) + 8 (r >> 2) + 4 g of this
@@ -260,7 +263,7 @@ struct ActConst
 //          pixel in bits 0-1, and (code | 4 * byte parity) selects the low / high byte of the f16 factor.
 // The file is compiled with -fno-honor-nans (no canonicalisation ops around min / max): a NaN pre-activation comes out as
 // -clamp instead of NaN.
-template <int MODE, bool SLOPEMAX, bool CLAMP>
+template <int MODE, bool SLOPEMAX, bool CLAMP, int LUTN>
 __device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8], uint32_t& mdw, uint32_t mlo, uint32_t mhi, const ActConst& k)
 {
     uint32_t bA = 0, bB = 0;
@@ -272,16 +275,14 @@ __device__ __forceinline__ void act_block(const f32x16& accU, uint32_t (&zp)[8],
         for (int h = 0; h < 2; h++) { P[h][0] = (_Float16)accU[4 * q + 2 * h]; P[h][1] = (_Float16)accU[4 * q + 2 * h + 1]; }
         if (MODE == LVG_SIGNS_READ)
         {
-            const uint32_t m4 = __builtin_amdgcn_perm(0u, q < 2 ? mlo : mhi, (q & 1) ? k.selOdd : k.selEven);
-            #pragma unroll
-            for (int h = 0; h < 2; h++)
-            {
-                ushort2v mv; __builtin_memcpy(&mv, &m4, 4);
-                mv = mv >> (h ? k.sh23 : k.sh01);
-                uint32_t sel; __builtin_memcpy(&sel, &mv, 4);
-                sel = (sel & 0x03030303u) | 0x04000400u;
-                zp[2 * q + h] = h2_bits(P[h] * bits_h2(__builtin_amdgcn_perm(k.lut1, k.lut0, sel)));
-            }
+            // the mask byte of these four pixels indexes a table of their four factors (1, slope, 0 by code): one LDS read replaces the
+            // bit arithmetic -- the kernel is bound by the vector-instruction port, the LDS pipe has room
+            uint32_t byte = __builtin_amdgcn_ubfe(q < 2 ? mlo : mhi, (q & 1) ? k.shOdd : k.shEven, 8u);
+            if (LUTN < 256) byte = min(byte, (uint32_t)(LUTN - 1));
+            typedef __attribute__((address_space(3))) const uint2v* lds_u2;
+            const uint2v f = *(lds_u2)(uintptr_t)(k.lutBase + byte * 8u);
+            zp[2 * q] = h2_bits(P[0] * bits_h2(f[0]));
+            zp[2 * q + 1] = h2_bits(P[1] * bits_h2(f[1]));
         }
         else
         {
@@ -363,6 +364,24 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
         taps[FU + t] = v;
     }
     for (int i = lane; i < G::X_BYTES / 4; i += 64) reinterpret_cast<uint32_t*>(XL)[i] = 0u;
+    if (MODE == LVG_SIGNS_READ)
+    {
+        // mask byte (codes of four pixels, 2 bits each: 0 pass, 1 negative, 2 / 3 clamped) -> (f0, f1), (f2, f3) packed f16
+        uint32_t* lut = reinterpret_cast<uint32_t*>(smem + G::OFF_LUT);
+        const _Float16 one = (_Float16)1.0f, sl = (_Float16)p.slope, zero = (_Float16)0.0f;
+        for (int e = tid; e < G::LUTN; e += kThreads)
+        {
+            half2v lo, hi;
+            #pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int c = (e >> (2 * j)) & 3;
+                const _Float16 f = c == 0 ? one : (c == 1 ? sl : zero);
+                if (j < 2) lo[j] = f; else hi[j - 2] = f;
+            }
+            lut[2 * e] = h2_bits(lo); lut[2 * e + 1] = h2_bits(hi);
+        }
+    }
     __syncthreads();
 
     // Launch-constant geometry: the column shift that aligns the tile with the mask bytes in READ mode and the
@@ -415,12 +434,10 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
         const _Float16 clamp_h = (_Float16)(p.clamp < 65504.0f ? p.clamp : 65504.0f);    // no clamp = the largest finite f16
         K.clampP[0] = clamp_h; K.clampP[1] = clamp_h; K.clampN[0] = -clamp_h; K.clampN[1] = -clamp_h;
         K.clampBits = h2_bits(K.clampP);
-        const uint32_t sb = h2_bits(K.slope2) & 0xffffu;
-        K.lut0 = (sb & 0xffu) << 8;                                          // low bytes of (1.0, slope, 0, 0)
-        K.lut1 = 0x3cu | ((sb >> 8) << 8);                                   // high bytes
-        K.selEven = 0x01010101u * (uint32_t)g;
-        K.selOdd = 0x01010101u * (uint32_t)(2 + g);
-        K.sh01[0] = 0; K.sh01[1] = 2; K.sh23[0] = 4; K.sh23[1] = 6;
+        K.shEven = 8u * (uint32_t)g;
+        K.shOdd = 16u + 8u * (uint32_t)g;
+        typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+        K.lutBase = (uint32_t)(uintptr_t)(lds_bytes)(smem + G::OFF_LUT);     // LDS byte address of the table
     }
     // No pre-activation of a tile can exceed  scale * l1(up taps per phase)^2 * max |x + bias|  in magnitude (and leaky
     // ReLU with slope <= 1 only shrinks it), so tiles whose input maximum stays below clamp / that factor (5 % margin
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(kThreads, 2) void filtered_lrelu_wave_kernel(Flrelu
                     if (b < 3) accUn = stage_b(b + 1);
                     uint32_t zp[8];
                     if (LVG_WABL & 4) { for (int i = 0; i < 8; i++) { half2v t; t[0] = (_Float16)accU[2 * i]; t[1] = (_Float16)accU[2 * i + 1]; zp[i] = h2_bits(t); } }
-                    else act_block<MODE, SLOPEMAX, CLAMP>(accU, zp, mdw[b], M8[2 * b], M8[2 * b + 1], K);
+                    else act_block<MODE, SLOPEMAX, CLAMP, G::LUTN>(accU, zp, mdw[b], M8[2 * b], M8[2 * b + 1], K);
                     #pragma unroll
                     for (int h = 0; h < 2; h++)
                     {
