@@ -61,7 +61,7 @@ int env_int(const char* name, int dflt)
 // Tile choice (measured on MI355X, tools/conv_bench.py, profiles/r02_conv_variants.log): 128 pixels x 128 channels on
 // 4 waves with two independent workgroups per CU is the fastest form on every 512- / 256-channel layer (two
 // workgroups de-synchronise their barriers; 256-pixel tiles on 8 waves ran 20 % slower there). Wide frames
-// (W >= 32: the halo is half a 128-pixel tile) with >= 128 output channels take 256-pixel tiles.
+// (W >= 32: the halo is half a 128-pixel tile) take 256-pixel tiles.
 // LVG_CONV_BM / _BN / _NB override (A/B measurements).
 int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl, bool outF32 = false)
 {
@@ -81,7 +81,9 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
     static const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);   // read once per process
     int bn = (Co % 128 == 0) ? 128 : 64;
     if (fbn == 64 || (fbn == 128 && Co % 128 == 0)) bn = fbn;
-    int bm = (2 * reach >= 64 && bn == 128 && lvg_ceil_div(M, 256) * (Co / bn) >= 512) ? 256 : 128;
+    // (round 4: 64-channel tiles of wide frames too -- the 64 -> 64 layers at 36 x 64 stream 0.9 GB per launch and re-read weights and
+    // halo per tile: 513 -> 460 us with 256-pixel tiles, tools/conv_bench.py)
+    int bm = (2 * reach >= 64 && lvg_ceil_div(M, 256) * (Co / bn) >= 512) ? 256 : 128;
     if (fbm == 128 || fbm == 256) bm = fbm;
     int nb = 2;
     if (fnb == 2 || fnb == 3) nb = fnb;
