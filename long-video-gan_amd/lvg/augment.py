@@ -2,6 +2,8 @@
 sample shared by all frames (reference model/diff_augment.py:20-102). Written against the same
 distributions; on-device, no host synchronisation."""
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -55,9 +57,54 @@ def diff_augment(x: torch.Tensor, policy: str = 'color,translation,cutout') -> t
     return x.contiguous()
 
 
+def temporal_scale_params(n: int, frames: int, seq_length: int, amount: float):
+    """The host-side random draws of `temporal_scale_augment` for `n` clips of `frames` frames, in the reference's order (per sample: the
+    stretch, the pad offset, the crop offset; video_gan_lres.py:242-263), turned into what the device needs: for every output frame the
+    source frame below it, the interpolation weight of the next one and whether it lies inside the stretched clip (else zero padding).
+    -> (i0 [n, seq_length] int64, frac [n, seq_length] float32, valid [n, seq_length] float32), CPU tensors."""
+    i0s, fracs, valids = [], [], []
+    steps = torch.arange(seq_length, dtype=torch.float64)
+    for _ in range(n):
+        scale = float(2 ** torch.empty(()).uniform_(-amount, amount))
+        length = int(math.floor(float(frames * scale)))                  # F.interpolate's output size for scale_factor = scale
+        room = max(0, seq_length - length)
+        p0 = int(torch.randint(room + 1, ()))
+        c0 = int(torch.randint(length + room - seq_length + 1, ()))
+        s = steps + (c0 - p0)                                            # index into the stretched clip
+        src = ((s + 0.5) / scale - 0.5).clamp(min=0.0)                   # bilinear, align_corners=False, the GIVEN scale (recompute_scale_factor=False)
+        if length == frames:                                             # upsample_bilinear2d copies when the size does not change, whatever the scale
+            src = s.clamp(min=0.0)
+        lo = src.floor().clamp(max=frames - 1)
+        i0s.append(lo.long())
+        fracs.append((src - lo).clamp(0.0, 1.0).float())
+        valids.append(((s >= 0) & (s < length)).float())
+    return torch.stack(i0s), torch.stack(fracs), torch.stack(valids)
+
+
+def temporal_scale_apply(video: torch.Tensor, i0: torch.Tensor, frac: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
+    """[N, C, T, H, W] -> [N, C, seq_length, H, W]: two gathers along time, one lerp, one mask -- for all samples at once (the reference
+    form interpolates, pads, crops and stacks sample by sample: 24 slow launches of a bilinear kernel on a strided view per 8 clips)."""
+    n, c, t, h, w = video.shape
+    seq = i0.shape[1]
+    i1 = (i0 + 1).clamp(max=t - 1)
+    view = lambda v: v[:, None, :, None, None]
+    g0 = video.gather(2, view(i0).expand(n, c, seq, h, w))
+    g1 = video.gather(2, view(i1).expand(n, c, seq, h, w))
+    return torch.lerp(g0, g1, view(frac).to(video.dtype)) * view(valid).to(video.dtype)
+
+
 def temporal_scale_augment(video: torch.Tensor, seq_length: int, amount: float) -> torch.Tensor:
     """Per-sample random time stretch by 2**U(-amount, amount) (bilinear along T), then random
     pad/crop back to seq_length (reference video_gan_lres.py:242-263)."""
+    if amount <= 0:
+        return video
+    i0, frac, valid = temporal_scale_params(video.size(0), video.size(2), seq_length, amount)
+    dev = video.device
+    return temporal_scale_apply(video, i0.to(dev, non_blocking=True), frac.to(dev, non_blocking=True), valid.to(dev, non_blocking=True))
+
+
+def temporal_scale_augment_reference_form(video: torch.Tensor, seq_length: int, amount: float) -> torch.Tensor:
+    """The sample-by-sample form of the reference (kept as the definition the vectorised form is tested against)."""
     if amount <= 0:
         return video
     out = []
@@ -70,3 +117,11 @@ def temporal_scale_augment(video: torch.Tensor, seq_length: int, amount: float) 
         i0 = int(torch.randint(v.size(-1) - seq_length + 1, ()))
         out.append(v[..., i0:i0 + seq_length])
     return torch.stack(out).permute(0, 1, 4, 2, 3)
+
+
+def crop_time(video: torch.Tensor, t0: torch.Tensor, seq_length: int) -> torch.Tensor:
+    """video[i, :, t0[i] : t0[i] + seq_length] for every sample i as ONE gather (t0 on the video's device): no host-side indices, so the
+    crop can live inside a captured graph."""
+    n, c, _, h, w = video.shape
+    idx = t0.reshape(n, 1) + torch.arange(seq_length, device=video.device).reshape(1, seq_length)
+    return video.gather(2, idx[:, None, :, None, None].expand(n, c, seq_length, h, w))

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import ddp
 from .optim import FlatAdam
-from .augment import diff_augment, temporal_scale_augment
+from .augment import crop_time, diff_augment, temporal_scale_apply, temporal_scale_augment, temporal_scale_params
 from .models import lres as lres_models
 from .models.lres import VideoDiscriminator, VideoGenerator
 
@@ -25,7 +25,7 @@ class LowResTrainer:
                  G_grad_accum: int = 1, D_lrate: float = 0.002, D_beta2: float = 0.99, D_grad_accum: int = 1,
                  r1_gamma: float = 10.0, G_random_temp_translate: bool = True, temp_scale_augment: float = 1.0,
                  diffaug_policy: str = 'color,translation,cutout', overlap_grad_sync: bool = True,
-                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True):
+                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True, use_graphs: bool = False):
         self.seq_length, self.height, self.width = seq_length, height, width
         self.device, self.dtype = torch.device(device), compute_dtype
         self.G_magnitude_ema_beta, self.G_ema_beta, self.G_ema_warmup_steps = G_magnitude_ema_beta, G_ema_beta, G_ema_warmup_steps
@@ -43,22 +43,78 @@ class LowResTrainer:
                               ema_params=self.G_ema.parameters() if self.G_ema is not None else None)
         self.D_opt = FlatAdam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
         self._step = 0
+        # use_graphs: the compute of update_G / update_D (generator pass, augmentation, discriminator pass, backward) is captured ONCE per
+        # micro-batch shape into hipGraphs and replayed; what stays eager is what cannot be captured on this stack or must see host values:
+        # the gradient exchange (an RCCL collective inside a captured graph aborts), the optimizer steps, R1. The host-side random draws of
+        # the reference (crop offsets, temporal stretch) are drawn in the same order as in eager mode and handed to the graphs through
+        # static device buffers. Bucket all-reduces from autograd hooks would be captured too, so the exchange runs after the replay.
+        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
+        self._graphs = {}
+        if self.use_graphs:
+            overlap_grad_sync = False
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
         self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
 
     # ------------------------------------------------------------------------------------------
-    def _gen(self, batch: int, beta: float = 1.0) -> torch.Tensor:
+    def _gen(self, batch: int, beta: float = 1.0, t0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`t0`: crop offsets on the device (graph mode); None: drawn here on the host like the reference (video_gan_lres.py:107-116)."""
         extra = self.G.total_temporal_scale if self.G_random_temp_translate else 0
         video = self.G(batch, self.seq_length + extra, magnitude_ema_beta=beta, dtype=self.dtype)
         if extra:
-            t0 = torch.randint(video.size(2) - self.seq_length, (batch,))
-            video = torch.stack([video[i, :, int(t0[i]):int(t0[i]) + self.seq_length] for i in range(batch)])
+            if t0 is None:
+                t0 = self._draw_crop(batch, video.size(2)).to(video.device, non_blocking=True)
+            video = crop_time(video, t0, self.seq_length)
         return video
 
-    def run_D(self, video: torch.Tensor) -> torch.Tensor:
+    def _draw_crop(self, batch: int, frames: int) -> torch.Tensor:
+        return torch.randint(frames - self.seq_length, (batch,))
+
+    def run_D(self, video: torch.Tensor, stretch=None) -> torch.Tensor:
+        """`stretch`: (i0, frac, valid) of `temporal_scale_params` on the device (graph mode); None: drawn here on the host."""
         video = diff_augment(video, self.diffaug_policy)
-        video = temporal_scale_augment(video, self.seq_length, self.temp_scale_augment)
+        if stretch is None:
+            video = temporal_scale_augment(video, self.seq_length, self.temp_scale_augment)
+        elif self.temp_scale_augment > 0:
+            video = temporal_scale_apply(video, *stretch)
         return self.D(video, dtype=self.dtype)
+
+    # ---- graph mode ---------------------------------------------------------------------------
+    def _static_draws(self, key, batch: int):
+        """Static device buffers for the host-side draws of one `_gen` + `run_D` (+ a second `run_D`) of `batch` clips."""
+        buf = self._graphs.get(('draws', key, batch))
+        if buf is None:
+            dev, T = self.device, self.seq_length
+            buf = dict(t0=torch.zeros(batch, dtype=torch.int64, device=dev),
+                       stretch=[(torch.zeros(batch, T, dtype=torch.int64, device=dev), torch.zeros(batch, T, device=dev), torch.ones(batch, T, device=dev))
+                                for _ in range(2)])
+            self._graphs[('draws', key, batch)] = buf
+        return buf
+
+    def _fill_stretch(self, dst, batch: int) -> None:
+        if self.temp_scale_augment > 0:
+            for d, s in zip(dst, temporal_scale_params(batch, self.seq_length, self.seq_length, self.temp_scale_augment)):
+                d.copy_(s, non_blocking=True)
+
+    def _replay(self, key, fn):
+        """Run `fn` from its graph. First time `key` is seen: one eager run on a side stream (lazy initialisation, library plans) whose
+        side effects on the gradient buffers and the generator's running statistics are rolled back, then the capture. `fn` must read its
+        inputs from static tensors and leave its outputs in static tensors."""
+        g = self._graphs.get(key)
+        if g is None:
+            keep = [t for t in (self.G_sync.flat, self.D_sync.flat, *self.G.buffers())]
+            saved = [t.clone() for t in keep]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            for t, v in zip(keep, saved):
+                t.copy_(v)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+        g.replay()
 
     # ------------------------------------------------------------------------------------------
     def _ema_beta(self, step: int) -> float:
@@ -74,6 +130,14 @@ class LowResTrainer:
         for k in range(self.G_grad_accum):
             if k == self.G_grad_accum - 1 and self.G_sync.overlap:
                 self.G_sync.arm()
+            if self.use_graphs:
+                b = batch // self.G_grad_accum
+                draws = self._static_draws('G', b)
+                if self.G_random_temp_translate:                           # host draws in eager order: crop, then the stretch
+                    draws['t0'].copy_(self._draw_crop(b, self.seq_length + self.G.total_temporal_scale), non_blocking=True)
+                self._fill_stretch(draws['stretch'][0], b)
+                self._replay(('G', b), lambda: F.softplus(-self.run_D(self._gen(b, t0=draws['t0']), stretch=draws['stretch'][0])).mean().backward())
+                continue
             logits = self.run_D(self._gen(batch // self.G_grad_accum))
             F.softplus(-logits).mean().backward()
         self.G.requires_grad_(False)
@@ -84,6 +148,8 @@ class LowResTrainer:
 
     def update_D(self, real_video: torch.Tensor) -> None:
         assert real_video.size(0) % self.D_grad_accum == 0
+        if self.use_graphs:
+            return self._update_D_graphs(real_video)
         with torch.no_grad():
             fake_video = self._gen(real_video.size(0), beta=self.G_magnitude_ema_beta)
         self.D.requires_grad_(True)
@@ -94,6 +160,37 @@ class LowResTrainer:
             if k == len(chunks) - 1 and self.D_sync.overlap:
                 self.D_sync.arm()
             F.softplus(-self.run_D(real)).mean().backward()
+        self.D.requires_grad_(False)
+        self.D_sync.finish(gain=1 / self.D_grad_accum)
+        self.D_opt.step()
+
+    def _update_D_graphs(self, real_video: torch.Tensor) -> None:
+        """update_D with the generator pass and every (fake, real) micro-batch replayed from graphs; same order of host draws as eager."""
+        n = real_video.size(0)
+        b = n // self.D_grad_accum
+        gen = self._static_draws('Dgen', n)
+        st = self._graphs.setdefault(('Dio', n, b), dict(fake=None, fake_in=torch.empty(b, *real_video.shape[1:], dtype=self.dtype, device=self.device),
+                                                         real_in=torch.empty(b, *real_video.shape[1:], dtype=real_video.dtype, device=self.device)))
+        if self.G_random_temp_translate:
+            gen['t0'].copy_(self._draw_crop(n, self.seq_length + self.G.total_temporal_scale), non_blocking=True)
+
+        def generate():
+            with torch.no_grad():
+                st['fake'] = self._gen(n, beta=self.G_magnitude_ema_beta, t0=gen['t0'])
+        self._replay(('Dgen', n), generate)
+        self.D.requires_grad_(True)
+        self.D_sync.zero()
+        draws = self._static_draws('D', b)
+
+        def passes():
+            F.softplus(self.run_D(st['fake_in'], stretch=draws['stretch'][0])).mean().backward()
+            F.softplus(-self.run_D(st['real_in'], stretch=draws['stretch'][1])).mean().backward()
+        for fake, real in zip(st['fake'].chunk(self.D_grad_accum), real_video.chunk(self.D_grad_accum)):
+            st['fake_in'].copy_(fake)
+            st['real_in'].copy_(real)
+            self._fill_stretch(draws['stretch'][0], b)
+            self._fill_stretch(draws['stretch'][1], b)
+            self._replay(('D', b), passes)
         self.D.requires_grad_(False)
         self.D_sync.finish(gain=1 / self.D_grad_accum)
         self.D_opt.step()

@@ -225,3 +225,36 @@ def test_checkpoint_random_streams_are_per_rank_cpu():
     a = torch.rand(4)
     checkpoint.load_trainer_state(tr, gathered)
     assert torch.equal(torch.rand(4), a)
+
+
+@pytest.mark.parametrize('amount,frames', [(1.0, 16), (0.5, 16), (2.0, 24)])
+def test_vectorised_temporal_stretch_matches_the_sample_by_sample_form_cpu(amount, frames):
+    """lvg.augment.temporal_scale_augment (host draws -> indices, ONE pair of gathers on the device) against the per-sample
+    interpolate / pad / crop / stack form of the reference (video_gan_lres.py:242-263): same values (the interpolation weights are
+    computed in float64 here, float32 inside F.interpolate: 1e-4 on unit-variance clips) and the same consumption of the CPU generator."""
+    from lvg import augment
+    video = torch.randn(5, 3, frames, 6, 7, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(11)
+    want = augment.temporal_scale_augment_reference_form(video, 16, amount)
+    after_want = torch.rand(3)
+    torch.manual_seed(11)
+    got = augment.temporal_scale_augment(video, 16, amount)
+    after_got = torch.rand(3)
+    assert got.shape == want.shape == (5, 3, 16, 6, 7)
+    assert (got - want).abs().max() <= 1e-4
+    assert torch.equal(after_got, after_want)
+    assert augment.temporal_scale_augment(video, 16, 0.0) is video
+
+
+def test_crop_time_is_per_sample_slicing_cpu():
+    from lvg import augment
+    video = torch.randn(4, 3, 20, 5, 6)
+    t0 = torch.tensor([0, 7, 12, 3])
+    want = torch.stack([video[i, :, int(t):int(t) + 8] for i, t in enumerate(t0)])
+    assert torch.equal(augment.crop_time(video, t0, 8), want)
+
+
+def test_graph_mode_is_ignored_without_a_gpu_cpu():
+    from lvg.train_lres import LowResTrainer
+    tr = LowResTrainer(seq_length=8, height=36, width=64, device='cpu', compute_dtype=torch.float32, use_graphs=True, with_ema=False)
+    assert tr.use_graphs is False
