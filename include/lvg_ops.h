@@ -254,8 +254,15 @@ int lvg_conv3d_frames_wgrad(const void* x, const void* dy, float* part, const vo
                             int64_t x_pixel_stride, int64_t dy_pixel_stride, int splits, int dtype, void* stream);
 int lvg_conv3d_frames_wgrad_splits(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw);
 
-/* Workgroups lvg_conv3d_frames launches for this shape (= length of msq_partial); 0 = unsupported shape. */
+/* Tiles lvg_conv3d_frames cuts this shape into (= length of msq_partial; one workgroup per tile, or a persistent grid walking them);
+ * 0 = unsupported shape. */
 int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw);
+
+/* Measurement / test control (no counterpart in the reference): force the tile of lvg_conv3d_frames -- bm pixels (128 | 256) x bn output
+ * channels (64 | 128), weight ring depth nb (2 | 3); 0 = the kernel's own choice -- and switch the persistent-workgroup form of the
+ * 64-channel tiles on / off. Every form computes the same bits (tests/test_conv3d_frames.py). Initial values: LVG_CONV_BM / _BN / _NB /
+ * _PERSIST from the environment. */
+int lvg_conv3d_frames_set_plan(int bm, int bn, int nb, int persist);
 
 /*
  * Backward of lvg_tapconv_epilogue from dout and the saved ysum; the gradient is written already scattered

@@ -50,7 +50,20 @@ struct Plan
 {
     int bm, bn, pb, bandRows, nABuf, nBBuf, ldsBytes;
     int64_t mTiles;
+    int persistGrid;            // > 0: the persistent kernel with this many workgroups (igemm_kernel.h, PERSIST)
 };
+
+int device_cus()
+{
+    static int cus = 0;
+    if (cus == 0)
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        cus = n;
+    }
+    return cus;
+}
 
 int env_int(const char* name, int dflt)
 {
@@ -62,7 +75,14 @@ int env_int(const char* name, int dflt)
 // 4 waves with two independent workgroups per CU is the fastest form on every 512- / 256-channel layer (two
 // workgroups de-synchronise their barriers; 256-pixel tiles on 8 waves ran 20 % slower there). Wide frames
 // (W >= 32: the halo is half a 128-pixel tile) take 256-pixel tiles.
-// LVG_CONV_BM / _BN / _NB override (A/B measurements).
+// LVG_CONV_BM / _BN / _NB / _PERSIST (environment, read once) or lvg_conv3d_frames_set_plan (at run time) override -- A/B measurements and
+// the test that all forms compute the same bits.
+struct Overrides { int bm, bn, nb, persist; };
+Overrides& overrides()
+{
+    static Overrides o = {env_int("LVG_CONV_BM", 0), env_int("LVG_CONV_BN", 0), env_int("LVG_CONV_NB", 0), env_int("LVG_CONV_PERSIST", 0)};
+    return o;
+}
 int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl, bool outF32 = false)
 {
     const int reach = (kh / 2) * W + kw / 2;
@@ -78,7 +98,7 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
         const int epilogue = (bm / 64 * 2) * 64 * (bn + 16);             // the epilogue stages every wave's 64-pixel x bn/2-channel tile, pitch bn + 16 bytes
         if (pl.ldsBytes < epilogue) pl.ldsBytes = epilogue;
     };
-    static const int fbm = env_int("LVG_CONV_BM", 0), fbn = env_int("LVG_CONV_BN", 0), fnb = env_int("LVG_CONV_NB", 0);   // read once per process
+    const int fbm = overrides().bm, fbn = overrides().bn, fnb = overrides().nb;
     int bn = (Co % 128 == 0) ? 128 : 64;
     if (fbn == 64 || (fbn == 128 && Co % 128 == 0)) bn = fbn;
     // (round 4: 64-channel tiles of wide frames too -- the 64 -> 64 layers at 36 x 64 stream 0.9 GB per launch and re-read weights and
@@ -92,6 +112,26 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
     if (pl.ldsBytes > 160 * 1024 && nb == 3) fill(bm, bn, 2);
     if (pl.ldsBytes > 160 * 1024 && bm == 256) fill(128, bn, 2);
     if (pl.ldsBytes > 160 * 1024) return -1;
+    // Persistent workgroups for the 64-channel tiles (round 4): a tile of these layers has 9 .. 45 K-steps, and one workgroup per tile ran
+    // prologue (band from HBM) -> K loop -> stores one after the other (memory operations alone 254 us, arithmetic alone ~160 us, together
+    // 410 us on 64 -> 64 @ 36 x 64: profiles/r04_conv_abl64.log). LVG_CONV_PERSIST=0 switches it off (A/B).
+    pl.persistGrid = 0;
+    const int persistOn = overrides().persist;
+    if (persistOn && !outF32 && ntap > 1 && pl.bn == 64 && nb == 2)
+    {
+        const int aBytes = pl.bandRows * kRowBytes;
+        const int lds = kZeroBytes + 2 * aBytes + pl.nBBuf * pl.bn * kRowBytes;
+        const int staging = (pl.bm / 64 * 2) * 64 * (pl.bn + 16);     // every wave's 64 pixels x 32 channels, pitch 64 + 16 bytes: must fit the finished band
+        const int64_t tiles = pl.mTiles * (Co / pl.bn);
+        int perCu = (160 * 1024) / lds;
+        if (perCu > 2) perCu = 2;
+        if (staging <= aBytes && perCu >= 1)
+        {
+            int grid = device_cus() * perCu;
+            if (grid > 8) grid -= grid % 8;
+            if (tiles >= 3 * (int64_t)grid && tiles < ((int64_t)1 << 30)) { pl.persistGrid = grid; pl.nABuf = 2; pl.ldsBytes = lds; }
+        }
+    }
     const int nw = pl.bm / (32 * pl.pb) * 2;
     const int aw = ntap > 1 ? nw / 4 : nw;                             // band-staging waves (see `split` in the kernel)
     if (lvg_ceil_div(pl.bandRows / 8, aw * ntap) > 6) return -1;       // MAXAI band pieces per wave and K-step
@@ -106,10 +146,10 @@ bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int 
     return xstride >= ci && xstride % 8 == 0 && (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * xstride * 2 < ((int64_t)1 << 32);
 }
 
-template <class T, int BM, int BN, int PB, int NB, bool OUTF = false>
+template <class T, int BM, int BN, int PB, int NB, bool OUTF = false, bool PERSIST = false>
 int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB, false, OUTF>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB, false, OUTF, PERSIST>;
     if (pl.ldsBytes > 64 * 1024)
     {
         // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
@@ -120,7 +160,7 @@ int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
             return LVG_ERR_LAUNCH;
         }
     }
-    const int64_t blocks = pl.mTiles * a.nTiles;
+    const int64_t blocks = PERSIST ? (int64_t)pl.persistGrid : pl.mTiles * a.nTiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM / (32 * PB) * 128), pl.ldsBytes, stream, a);
     return lvg_check_launch("conv3d_frames");
 }
@@ -128,6 +168,10 @@ int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 template <class T, int NB>
 int launch_ring(const ConvArgs& a, const Plan& pl, hipStream_t s)
 {
+    if constexpr (NB == 2)
+    {
+        if (pl.persistGrid > 0) return pl.bm == 256 ? launch<T, 256, 64, 2, 2, false, true>(a, pl, s) : launch<T, 128, 64, 2, 2, false, true>(a, pl, s);
+    }
     if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, 2, NB>(a, pl, s) : launch<T, 256, 64, 2, NB>(a, pl, s);
     return pl.bn == 128 ? launch<T, 128, 128, 2, NB>(a, pl, s) : launch<T, 128, 64, 2, NB>(a, pl, s);
 }
@@ -147,6 +191,14 @@ int launch_tile(const ConvArgs& a, const Plan& pl, hipStream_t s)
 }
 
 } // namespace
+
+extern "C" int lvg_conv3d_frames_set_plan(int bm, int bn, int nb, int persist)
+{
+    LVG_REQUIRE((bm == 0 || bm == 128 || bm == 256) && (bn == 0 || bn == 64 || bn == 128) && (nb == 0 || nb == 2 || nb == 3) && (persist == 0 || persist == 1),
+                "conv3d_frames_set_plan: bm in {0, 128, 256}, bn in {0, 64, 128}, nb in {0, 2, 3} (0 = the kernel's own choice), persist in {0, 1}");
+    overrides().bm = bm; overrides().bn = bn; overrides().nb = nb; overrides().persist = persist;
+    return LVG_OK;
+}
 
 extern "C" int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int kw)
 {
@@ -218,6 +270,7 @@ extern "C" int lvg_conv3d_frames_ex(const void* x, const void* w, const float* p
     a.nABuf = pl.nABuf;
     a.nBBuf = pl.nBBuf;
     a.nTiles = co / pl.bn;
+    a.totalTiles = (int)(pl.mTiles * (co / pl.bn));
     a.slopeNeg = act == LVG_ACT_LINEAR ? 1.f : (act == LVG_ACT_RELU ? 0.f : alpha);
     a.gain = gain;
     a.clamp = clamp;

@@ -30,6 +30,7 @@ struct ConvArgs
     int          nABuf;        // 2 when there is more than one band per tile
     int          nBBuf;        // weight-tile ring: 2 (prefetch one K-step ahead) or 3 (two)
     int          nTiles;       // Co / BN
+    int          totalTiles;   // pixel tiles x channel tiles (the persistent kernels walk them; the others have one workgroup per tile)
     float        slopeNeg;     // activation as max-free form: u > 0 ? u : u * slopeNeg (linear 1, relu 0, lrelu alpha)
     float        gain, clamp;
 };
@@ -151,9 +152,15 @@ constexpr int kPatchPitch = kTileW + 2;
 
 // OUTF: the result leaves as float32 straight from the accumulators (one 16-byte store per lane and register quad; `out` is a float
 // tensor, `ysum` unused) -- the output side of the float32-accurate contraction built from split 16-bit operands (conv2d_frames.py).
-template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false>
+// PERSIST (time-major kernel with spatial taps, generic K loop): a workgroup walks a strided sequence of tiles of its XCD's range. The band of
+// the NEXT tile is staged during the K-steps of this one (two band buffers always), the weight ring runs on into the next tile's first
+// tiles, and the epilogue stages the output rows in the band buffer the tile has just finished with -- so the HBM reads of tile i + 1, the
+// matrix work of tile i and the stores of tile i - 1 overlap inside ONE workgroup (the layers with few K-steps per tile -- 64 channels --
+// spent their time in the serial prologue -> K loop -> stores of each workgroup: profiles/r04_conv_abl64.log).
+template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false, bool PERSIST = false>
 __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(typename ConvArgsOf<T2D>::type p)
 {
+    static_assert(!PERSIST || (!T2D && !OUTF), "persistent form: time-major frames, 16-bit output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW  = BM / (32 * PB) * 2;      // waves: BM / (32 PB) along the pixels x 2 along the output channels
     constexpr int NCB = BN / 64;                 // 32-channel MFMA blocks per wave
@@ -171,13 +178,19 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
 
     // XCD-aware tile order: the dispatcher puts workgroup b on XCD b % 8; give every XCD a contiguous range of
     // tiles (channel tile fastest), so that the workgroups sharing an L2 share bands and walk the weights together.
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = PERSIST ? p.totalTiles : (int)gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
-    const int mt = tile / p.nTiles, nt = tile - mt * p.nTiles;
-    const int64_t m0 = (int64_t)mt * BM;
+    const int xcdFirst = xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
+    int tile = xcdFirst + (bid >> 3);
+    // PERSIST: this workgroup's tiles are tile, tile + tileStep, ... below tileEnd (the workgroups of an XCD walk its range side by side:
+    // neighbouring tiles -- shared halo rows, the same weights -- are in flight together)
+    const int tileEnd = xcdFirst + q + (xcd < rm ? 1 : 0), tileStep = (int)(gridDim.x >> 3);
+    if constexpr (PERSIST) { if (tile >= tileEnd) return; }
+    int mt = tile / p.nTiles, nt = tile - mt * p.nTiles;
+    int64_t m0 = (int64_t)mt * BM;
     int co0 = nt * BN;
     if constexpr (T2D) co0 += p.coBase;
+    int64_t aM0 = m0;                                                  // the tile whose band `issueA` stages (PERSIST: also the next tile's)
     // T2D: spatial tile -> (frame, tile row, tile column)
     int n2 = 0, y0 = 0, x0 = 0;
     if constexpr (T2D)
@@ -200,8 +213,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     const int nMacro = p.kt * nchunk;
     const int nSteps = nMacro * ntap;
     const int nAI = p.bandRows >> 3;                                   // band pieces in total
-    // weight-tile ring: NB slots with spatial taps (tiles staged NB - 1 K-steps ahead), 2 without (host sets nBBuf)
-    const int dist = p.nBBuf - 1;
+    // weight-tile ring: NB slots with spatial taps (tiles staged NB - 1 K-steps ahead), 2 without (host sets nBBuf): `dist` below
     // Without spatial taps (one K-step per band) everything is staged by all waves one K-step ahead (host: nBBuf = 2).
     const bool split = ntap > 1;
     const int bWaves = split ? NWB : NW, aWaves = split ? NWA : NW, aWave0 = split ? NWB : 0;
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     const uint32_t aChunkOff = (uint32_t)(lane & 7);
     auto issueA = [&](int dt, int kc, int tapSlot, int buf, int per, int nw, int w0)
     {
-        const int g0 = (int)(m0 - p.reach + (int64_t)(dt - pt) * p.tShift);     // |.| < 2^31 (host check)
+        const int g0 = (int)(aM0 - p.reach + (int64_t)(dt - pt) * p.tShift);    // |.| < 2^31 (host check)
         const int last = (int)p.M - 1;
         #pragma unroll
         for (int i = 0; i < MAXAI; i++)
@@ -296,6 +308,23 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
             }
         }
     };
+
+    // State that runs on from tile to tile in the persistent form: the weight ring position, the parity of the band buffers.
+    const int dist = p.nBBuf - 1;                                     // weight-tile ring: tiles are staged `dist` K-steps ahead
+    int bufNext = dist;                                               // ring slot the next staged weight tile goes to
+    uint32_t curB = 0;                                                // byte offset of the current weight tile in the ring
+    uint32_t stageOffB = (uint32_t)((NB - 1) * bBytes);               // (weight waves of the split loop) ring offset of the slot being staged
+    int gbase = 0;                                                    // bands completed in earlier tiles (PERSIST; 0 otherwise)
+    bool firstTile = true;
+    (void)firstTile; (void)stageOffB;
+
+next_tile:                                                            // PERSIST: the per-tile part starts over from here (a backwards goto: one body, no re-indentation)
+    const int tileNext = tile + tileStep;
+    const bool haveNext = PERSIST && tileNext < tileEnd;
+    const int mtNext = tileNext / p.nTiles;
+    const int64_t m0Next = (int64_t)mtNext * BM;
+    const int co0Next = (tileNext - mtNext * p.nTiles) * BN;
+    (void)haveNext; (void)m0Next; (void)co0Next;
 
     // ---- which temporal taps and which spatial taps read a real pixel, per lane and pixel block ------------------
     uint32_t vmask[PB];
@@ -357,18 +386,19 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     }
 
     // ---- prologue: first band (all waves), first `dist` weight tiles ------------------------------------------------
-    for (int t = 0; t < ntap; t++) issueA(0, 0, t, 0, aPerStep0, NW, 0);
-    for (int d = 0; d < dist; d++)
-        if (d < nSteps) issueB(d);
-    wait_vm_const<0>();
-    __syncthreads();
+    if (!PERSIST || firstTile)                                         // (later tiles of a persistent workgroup: staged during the previous tile)
+    {
+        for (int t = 0; t < ntap; t++) issueA(0, 0, t, 0, aPerStep0, NW, 0);
+        for (int d = 0; d < dist; d++)
+            if (d < nSteps) issueB(d);
+        wait_vm_const<0>();
+        __syncthreads();
+    }
 
     // ---- K loop: (dt, kc) = band, tap = spatial tap inside it --------------------------------------------------------
     int dt = 0, kc = 0, tap = 0, dh = 0, dw = 0, macro = 0;
     (void)dh;
-    int bufNext = dist;                                               // ring slot the next staged weight tile goes to
-    uint32_t curB = 0;                                                // byte offset of the current weight tile in the ring
-    uint32_t curA = (uint32_t)aOff;                                   // byte offset of the current band
+    uint32_t curA = (uint32_t)aOff + (uint32_t)((gbase & 1) * aBytes);   // byte offset of the current band
     const uint32_t ringBytes = (uint32_t)(p.nBBuf * bBytes);
 
     // One K-step of arithmetic: fragment addresses of this tap, then 4 x (fragment reads, MFMAs) with the reads of
@@ -465,7 +495,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
         {
             tap = 0; dh = 0; dw = 0; shift = 0; macro++;
             if (++kc == nchunk) { kc = 0; dt++; tbit++; }
-            curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);  // nABuf == 1 only when there is one band
+            curA = (uint32_t)aOff + (uint32_t)(((gbase + macro) & 1) * aBytes);  // nABuf == 1 only when there is one band
         }
     };
 
@@ -618,7 +648,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
             }
         }
     }
-    else if (!T2D && kStatic3D && (BN == 128 || kStatic3DBn64) && NB == 2 && split && p.kh == 3 && p.kw == 3 && nAI <= NWA * 9 * ((BN == 128 || BM == 256) ? 3 : 4))
+    else if (!PERSIST && !T2D && kStatic3D && (BN == 128 || kStatic3DBn64) && NB == 2 && split && p.kh == 3 && p.kw == 3 && nAI <= NWA * 9 * ((BN == 128 || BM == 256) ? 3 : 4))
     {
         // ---- time-major frames, 3 x 3 spatial taps (any number of temporal taps): the static-tap loop of the 2-D kernel with the 'same'
         // padding masks kept. Per (tap, pixel block) the band row and its swizzle phase are precomputed as ONE address word; a K-step
@@ -789,7 +819,7 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
         // next band -- so the per-step scalar work is the staging itself and a handful of counters.
         constexpr int D = NB - 1;
         const uint32_t ldsB0 = ldsBase + bOff;
-        uint32_t stageOff = (uint32_t)(D * bBytes);                    // ring offset of the slot being staged
+        uint32_t& stageOff = stageOffB;                                // ring offset of the slot being staged (starts at D * bBytes)
         auto kstep = [&]() __attribute__((always_inline))
         {
             if constexpr (!(kAbl & (1 | 128)))
@@ -817,10 +847,12 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
         for (macro = 0; macro < nMacro; macro++)
         {
             tap = 0; dh = 0; dw = 0; shift = 0;
-            curA = (uint32_t)aOff + (uint32_t)((macro & 1) * aBytes);
+            curA = (uint32_t)aOff + (uint32_t)(((gbase + macro) & 1) * aBytes);
             for (int t = 0; t < ntap - D; t++) kstep();
-            // the staged tile moves on to the next band (on the last band: back to this band's first tile, never read)
+            // the staged tile moves on to the next band (on the last band: back to this band's first tile, never read -- or, in the
+            // persistent form, on to the first tile of the workgroup's next tile)
             if (macro + 1 < nMacro) wMacro += (kc + 1 == nchunk) ? macroJump : (uint64_t)kRowBytes;
+            else if constexpr (PERSIST) { if (haveNext) wMacro = wb + (uint64_t)co0Next * rowStride; }
             wNext = wMacro;
             for (int t = 0; t < D; t++) kstep();
             if (++kc == nchunk) { kc = 0; dt++; tbit++; }
@@ -833,7 +865,12 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
         {
             const int mkc = (kc + 1 == nchunk) ? 0 : kc + 1;
             const int mdt = (kc + 1 == nchunk) ? dt + 1 : dt;
-            if (macro + 1 < nMacro && !(kAbl & (1 | 64))) issueA(mdt, mkc, tap, (macro + 1) & 1, aPerStep, aWaves, aWave0);
+            if (macro + 1 < nMacro && !(kAbl & (1 | 64))) issueA(mdt, mkc, tap, (gbase + macro + 1) & 1, aPerStep, aWaves, aWave0);
+            else if constexpr (PERSIST)
+            {
+                // last band of the tile: the first band of the next tile goes into the other buffer
+                if (haveNext && macro + 1 == nMacro && !(kAbl & (1 | 64))) { aM0 = m0Next; issueA(0, 0, tap, (gbase + macro + 1) & 1, aPerStep, aWaves, aWave0); aM0 = m0; }
+            }
             compute();
             if constexpr (!(kAbl & 16))
             {
@@ -863,7 +900,9 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
     constexpr int RPI = 64 / CPR;                 // rows per wave instruction on the way out
     constexpr int NI = ROWS / RPI;
     constexpr bool kLdsStore = !(kAbl & 512) && !OUTF;
-    unsigned char* const stage = smem + wave * (ROWS * PITCH);
+    // (persistent form: in the band buffer this tile has finished with -- the front of the LDS holds the zero page, the next tile's first
+    // weight tiles and possibly its band; the host only picks this form when NW x ROWS x PITCH fits a band)
+    unsigned char* const stage = smem + (PERSIST ? aOff + ((gbase + nMacro - 1) & 1) * aBytes : 0) + wave * (ROWS * PITCH);
     wait_vm_const<0>();                           // weight waves leave the K loop with re-staged tiles still in flight towards LDS: they must
                                                   // have landed before the staging below reuses that LDS -- and, on the float32-output path that
                                                   // stages nothing, before this wave can end (a workgroup that ends with LDS-DMA in flight lets the
@@ -899,103 +938,235 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
         __builtin_amdgcn_wave_barrier();
     };
     float sq = 0.f;
-    #pragma unroll
-    for (int pb = 0; pb < PB; pb++)
+    // The arithmetic of the epilogue, in three forms. FAST (16-bit output, bias present, `pre` and `post` both present -- the generator's
+    // modulated convolutions -- or both absent -- the discriminator's layers --, 0 < negative slope <= 1): no per-quad pointer tests (they cost ~165 register copies and ~150 selects per wave tile as
+    // merges of uniform branches), leaky ReLU as max(u, u * slope), two-element float vectors throughout (v_pk_fma / v_pk_mul), clamp and
+    // residual as compile-time variants. On the 64- and 128-channel layers a wave tile has 72 .. 288 MFMAs but 2 048 .. 4 096 outputs, and
+    // the epilogue was the larger part of the tile's issue cycles (849 vector instructions per 32 outputs of a lane before, r04).
+    // PLAIN (no operand but the accumulators, linear: the data gradients): a conversion. The generic form keeps every other combination
+    // and the float32-output kernels.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto fast_math = [&](auto clampTag, auto resTag, auto scaleTag) __attribute__((always_inline))
     {
-        int64_t mt_ = m0 + jrow[pb];
-        bool valid = mt_ < p.M;
-        if constexpr (T2D)
-        {
-            const int j = wr * (32 * PB) + pb * 32 + l31;
-            const int oy = y0 + j / kTileW, ox = x0 + txl;
-            valid = oy < p.H && ox < p.W;
-            mt_ = (int64_t)(n2 * p.H + oy) * p.W + ox;
-        }
-        if constexpr (!kLdsStore) { if (!valid) continue; }
-        const int64_t m = valid ? mt_ : (T2D ? (int64_t)n2 * p.H * p.W : p.M - 1);   // pixels past the end: computed on a valid pixel's terms, never stored
-        const int64_t f = T2D ? (int64_t)n2 : (int64_t)((uint32_t)m / hw);
+        constexpr bool CLAMP = decltype(clampTag)::value, RES = decltype(resTag)::value, SCALE = decltype(scaleTag)::value;
+        const float slope = p.slopeNeg, gainv = p.gain, cl = p.clamp;
         #pragma unroll
-        for (int cb = 0; cb < NCB; cb++)
-            #pragma unroll
-            for (int qd = 0; qd < 4; qd++)
+        for (int pb = 0; pb < PB; pb++)
+        {
+            int64_t mt_ = m0 + jrow[pb];
+            bool valid = mt_ < p.M;
+            if constexpr (T2D)
             {
-                const int co = co0 + wc * (BN / 2) + cb * 32 + 8 * qd + 4 * hi;
-                float pre4[4] = {1.f, 1.f, 1.f, 1.f}, post4[4] = {1.f, 1.f, 1.f, 1.f}, add4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.pre)  { const float4 v = *reinterpret_cast<const float4*>(p.pre + f * p.Co + co);  pre4[0] = v.x; pre4[1] = v.y; pre4[2] = v.z; pre4[3] = v.w; }
-                if (p.post) { const float4 v = *reinterpret_cast<const float4*>(p.post + f * p.Co + co); post4[0] = v.x; post4[1] = v.y; post4[2] = v.z; post4[3] = v.w; }
-                if constexpr (OUTF)
-                {
-                    // float32 output: bias and residual are float32 tensors too
-                    if (bias) { const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + co); add4[0] += v.x; add4[1] += v.y; add4[2] += v.z; add4[3] += v.w; }
-                    if (res)  { const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + m * p.Co + co); add4[0] += v.x; add4[1] += v.y; add4[2] += v.z; add4[3] += v.w; }
-                }
-                else
-                {
-                if (bias)
-                {
-                    uint2 raw = *reinterpret_cast<const uint2*>(bias + co);
-                    T t4[4];
-                    __builtin_memcpy(t4, &raw, 8);
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
-                }
-                if (res)
-                {
-                    uint2 raw = *reinterpret_cast<const uint2*>(res + m * p.Co + co);
-                    T t4[4];
-                    __builtin_memcpy(t4, &raw, 8);
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
-                }
-                }
-                T o4[4], y4[4];
-                float sqq = 0.f;
-                #pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    const float a = acc[cb][pb][qd * 4 + e];
-                    const float u = fmaf(a, pre4[e], add4[e]);
-                    float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
-                    if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
-                    if constexpr (kLdsStore) sqq = fmaf(g, g, sqq); else sq = fmaf(g, g, sq);
-                    o4[e] = from_acc<T>(g * post4[e]);
-                    y4[e] = from_acc<T>(a);
-                }
-                if (kLdsStore && valid) sq += sqq;
-                uint2 ov, yv;
-                __builtin_memcpy(&ov, o4, 8);
-                __builtin_memcpy(&yv, y4, 8);
-                if constexpr (OUTF)
-                {
-                    float4 fv;
-                    {
-                        float o[4];
-                        #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                        {
-                            const float a = acc[cb][pb][qd * 4 + e];
-                            const float u = fmaf(a, pre4[e], add4[e]);
-                            float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
-                            if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
-                            o[e] = g * post4[e];                 // (the magnitude statistic was accumulated by the common code above)
-                        }
-                        fv = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                    const int64_t ostr = T2D ? (int64_t)ConvArgs2DStride(p) : (int64_t)p.Co;
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * ostr + co) = fv;
-                    if (p.ysum)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ysum) + m * ostr + co) =
-                            make_float4(acc[cb][pb][qd * 4], acc[cb][pb][qd * 4 + 1], acc[cb][pb][qd * 4 + 2], acc[cb][pb][qd * 4 + 3]);
-                }
-                else if constexpr (kLdsStore)
-                    *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
-                else if (!(kAbl & 256) || sq == 12345.f)                 // (ablation 256: no output stores)
-                {
-                    *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
-                    if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
-                }
+                const int j = wr * (32 * PB) + pb * 32 + l31;
+                const int oy = y0 + j / kTileW, ox = x0 + txl;
+                valid = oy < p.H && ox < p.W;
+                mt_ = (int64_t)(n2 * p.H + oy) * p.W + ox;
             }
+            const int64_t m = valid ? mt_ : (T2D ? (int64_t)n2 * p.H * p.W : p.M - 1);   // pixels past the end: computed on a valid pixel's terms, never stored
+            const int64_t f = T2D ? (int64_t)n2 : (int64_t)((uint32_t)m / hw);
+            const float* const preRow = SCALE ? p.pre + f * p.Co + (co0 + wc * (BN / 2) + 4 * hi) : nullptr;
+            const float* const postRow = SCALE ? p.post + f * p.Co + (co0 + wc * (BN / 2) + 4 * hi) : nullptr;
+            const T* const biasRow = bias + (co0 + wc * (BN / 2) + 4 * hi);
+            const T* const resRow = RES ? res + m * p.Co + (co0 + wc * (BN / 2) + 4 * hi) : nullptr;
+            f32x2 sq2 = {0.f, 0.f};
+            #pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                #pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+                {
+                    const int cOff = cb * 32 + 8 * qd;
+                    float4 pv = make_float4(1.f, 1.f, 1.f, 1.f), qv = pv;
+                    if constexpr (SCALE)
+                    {
+                        pv = *reinterpret_cast<const float4*>(preRow + cOff);
+                        qv = *reinterpret_cast<const float4*>(postRow + cOff);
+                    }
+                    const uint2 braw = *reinterpret_cast<const uint2*>(biasRow + cOff);
+                    T b4[4];
+                    __builtin_memcpy(b4, &braw, 8);
+                    f32x2 add2[2] = {{to_acc(b4[0]), to_acc(b4[1])}, {to_acc(b4[2]), to_acc(b4[3])}};
+                    if constexpr (RES)
+                    {
+                        const uint2 rraw = *reinterpret_cast<const uint2*>(resRow + cOff);
+                        T r4[4];
+                        __builtin_memcpy(r4, &rraw, 8);
+                        add2[0] += f32x2{to_acc(r4[0]), to_acc(r4[1])};
+                        add2[1] += f32x2{to_acc(r4[2]), to_acc(r4[3])};
+                    }
+                    const f32x2 pre2[2] = {{pv.x, pv.y}, {pv.z, pv.w}}, post2[2] = {{qv.x, qv.y}, {qv.z, qv.w}};
+                    T o4[4];
+                    #pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++)
+                    {
+                        const f32x2 a = {acc[cb][pb][qd * 4 + 2 * h2], acc[cb][pb][qd * 4 + 2 * h2 + 1]};
+                        const f32x2 u = SCALE ? a * pre2[h2] + add2[h2] : a + add2[h2];
+                        const f32x2 nn = u * slope;
+                        f32x2 g = {fmaxf(u.x, nn.x), fmaxf(u.y, nn.y)};           // u > 0 ? u : u * slope for 0 < slope <= 1 (NaN stays NaN)
+                        g = g * gainv;
+                        if constexpr (CLAMP)
+                        {
+                            g.x = g.x > cl ? cl : (g.x < -cl ? -cl : g.x);
+                            g.y = g.y > cl ? cl : (g.y < -cl ? -cl : g.y);
+                        }
+                        sq2 = g * g + sq2;
+                        const f32x2 o = SCALE ? g * post2[h2] : g;
+                        o4[2 * h2] = from_acc<T>(o.x);
+                        o4[2 * h2 + 1] = from_acc<T>(o.y);
+                    }
+                    uint2 ov;
+                    __builtin_memcpy(&ov, o4, 8);
+                    if constexpr (kLdsStore)
+                        *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
+                    else if (valid && (!(kAbl & 256) || sq == 12345.f))
+                    {
+                        T y4[4];
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) y4[e] = from_acc<T>(acc[cb][pb][qd * 4 + e]);
+                        uint2 yv;
+                        __builtin_memcpy(&yv, y4, 8);
+                        const int co = co0 + wc * (BN / 2) + cb * 32 + 8 * qd + 4 * hi;
+                        *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
+                        if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
+                    }
+                }
+            if (valid) sq += sq2.x + sq2.y;
+        }
+    };
+    auto generic_math = [&]() __attribute__((always_inline))
+    {
+        #pragma unroll
+        for (int pb = 0; pb < PB; pb++)
+        {
+            int64_t mt_ = m0 + jrow[pb];
+            bool valid = mt_ < p.M;
+            if constexpr (T2D)
+            {
+                const int j = wr * (32 * PB) + pb * 32 + l31;
+                const int oy = y0 + j / kTileW, ox = x0 + txl;
+                valid = oy < p.H && ox < p.W;
+                mt_ = (int64_t)(n2 * p.H + oy) * p.W + ox;
+            }
+            if constexpr (!kLdsStore) { if (!valid) continue; }
+            const int64_t m = valid ? mt_ : (T2D ? (int64_t)n2 * p.H * p.W : p.M - 1);   // pixels past the end: computed on a valid pixel's terms, never stored
+            const int64_t f = T2D ? (int64_t)n2 : (int64_t)((uint32_t)m / hw);
+            #pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                #pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+                {
+                    const int co = co0 + wc * (BN / 2) + cb * 32 + 8 * qd + 4 * hi;
+                    float pre4[4] = {1.f, 1.f, 1.f, 1.f}, post4[4] = {1.f, 1.f, 1.f, 1.f}, add4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.pre)  { const float4 v = *reinterpret_cast<const float4*>(p.pre + f * p.Co + co);  pre4[0] = v.x; pre4[1] = v.y; pre4[2] = v.z; pre4[3] = v.w; }
+                    if (p.post) { const float4 v = *reinterpret_cast<const float4*>(p.post + f * p.Co + co); post4[0] = v.x; post4[1] = v.y; post4[2] = v.z; post4[3] = v.w; }
+                    if constexpr (OUTF)
+                    {
+                        // float32 output: bias and residual are float32 tensors too
+                        if (bias) { const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.b) + co); add4[0] += v.x; add4[1] += v.y; add4[2] += v.z; add4[3] += v.w; }
+                        if (res)  { const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + m * p.Co + co); add4[0] += v.x; add4[1] += v.y; add4[2] += v.z; add4[3] += v.w; }
+                    }
+                    else
+                    {
+                    if (bias)
+                    {
+                        uint2 raw = *reinterpret_cast<const uint2*>(bias + co);
+                        T t4[4];
+                        __builtin_memcpy(t4, &raw, 8);
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
+                    }
+                    if (res)
+                    {
+                        uint2 raw = *reinterpret_cast<const uint2*>(res + m * p.Co + co);
+                        T t4[4];
+                        __builtin_memcpy(t4, &raw, 8);
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) add4[e] += to_acc(t4[e]);
+                    }
+                    }
+                    T o4[4], y4[4];
+                    float sqq = 0.f;
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++)
+                    {
+                        const float a = acc[cb][pb][qd * 4 + e];
+                        const float u = fmaf(a, pre4[e], add4[e]);
+                        float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
+                        if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
+                        if constexpr (kLdsStore) sqq = fmaf(g, g, sqq); else sq = fmaf(g, g, sq);
+                        o4[e] = from_acc<T>(g * post4[e]);
+                        y4[e] = from_acc<T>(a);
+                    }
+                    if (kLdsStore && valid) sq += sqq;
+                    uint2 ov, yv;
+                    __builtin_memcpy(&ov, o4, 8);
+                    __builtin_memcpy(&yv, y4, 8);
+                    if constexpr (OUTF)
+                    {
+                        float4 fv;
+                        {
+                            float o[4];
+                            #pragma unroll
+                            for (int e = 0; e < 4; e++)
+                            {
+                                const float a = acc[cb][pb][qd * 4 + e];
+                                const float u = fmaf(a, pre4[e], add4[e]);
+                                float g = (u > 0.f ? u : u * p.slopeNeg) * p.gain;
+                                if (p.clamp >= 0.f) g = g > p.clamp ? p.clamp : (g < -p.clamp ? -p.clamp : g);
+                                o[e] = g * post4[e];                 // (the magnitude statistic was accumulated by the common code above)
+                            }
+                            fv = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                        const int64_t ostr = T2D ? (int64_t)ConvArgs2DStride(p) : (int64_t)p.Co;
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * ostr + co) = fv;
+                        if (p.ysum)
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ysum) + m * ostr + co) =
+                                make_float4(acc[cb][pb][qd * 4], acc[cb][pb][qd * 4 + 1], acc[cb][pb][qd * 4 + 2], acc[cb][pb][qd * 4 + 3]);
+                    }
+                    else if constexpr (kLdsStore)
+                        *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
+                    else if (!(kAbl & 256) || sq == 12345.f)                 // (ablation 256: no output stores)
+                    {
+                        *reinterpret_cast<uint2*>(out + m * p.Co + co) = ov;
+                        if (ysum) *reinterpret_cast<uint2*>(ysum + m * p.Co + co) = yv;
+                    }
+                }
+        }
+    };
+    auto plain_math = [&]() __attribute__((always_inline))
+    {
+        const float gainv = p.gain;
+        #pragma unroll
+        for (int pb = 0; pb < PB; pb++)
+            #pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                #pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+                {
+                    T o4[4];
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) o4[e] = from_acc<T>(acc[cb][pb][qd * 4 + e] * gainv);
+                    uint2 ov;
+                    __builtin_memcpy(&ov, o4, 8);
+                    *reinterpret_cast<uint2*>(stage + (pb * 32 + l31) * PITCH + cb * 64 + qd * 16 + ((hi ^ flipW) << 3)) = ov;
+                }
+    };
+    int form = 0;                                                     // 0 generic, 1 fast with scales, 2 fast without, 3 plain
+    if constexpr (!OUTF && !T2D && kLdsStore)
+    {
+        const bool lrelu = p.slopeNeg > 0.f && p.slopeNeg <= 1.f;
+        if (bias && lrelu && p.pre && p.post) form = 1;
+        else if (bias && lrelu && !p.pre && !p.post) form = 2;
+        else if (!bias && !res && !p.pre && !p.post && p.slopeNeg == 1.f && p.clamp < 0.f && !p.msqPartial) form = 3;
     }
+    auto pick = [&](auto scaleTag) __attribute__((always_inline))
+    {
+        if (p.clamp >= 0.f) { if (res) fast_math(std::true_type{}, std::true_type{}, scaleTag); else fast_math(std::true_type{}, std::false_type{}, scaleTag); }
+        else                { if (res) fast_math(std::false_type{}, std::true_type{}, scaleTag); else fast_math(std::false_type{}, std::false_type{}, scaleTag); }
+    };
+    if (form == 1) pick(std::true_type{});
+    else if (form == 2) pick(std::false_type{});
+    else if (form == 3) plain_math();
+    else generic_math();
     if constexpr (kLdsStore)
     {
         if (!(kAbl & 256) || sq == 12345.f)
@@ -1033,6 +1204,18 @@ __global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(t
             float tot = 0.f;
             for (int i = 0; i < NW; i++) tot += red[i];
             p.msqPartial[tile] = tot;
+        }
+    }
+    if constexpr (PERSIST)
+    {
+        if (haveNext)
+        {
+            // (the barriers above -- after the staged stores, inside the statistic -- already separate this tile's LDS reads from the next tile's staging)
+            gbase += nMacro;
+            firstTile = false;
+            tile = tileNext; mt = mtNext; nt = tile - mt * p.nTiles;
+            m0 = m0Next; co0 = co0Next; aM0 = m0;
+            goto next_tile;
         }
     }
 }

@@ -38,6 +38,7 @@ _SIGNATURES = {
     'lvg_tapconv_epilogue': [_vp] * 8 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_conv3d_frames': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_conv3d_frames_workgroups': [_i64] + [_i32] * 7,
+    'lvg_conv3d_frames_set_plan': [_i32] * 4,
     'lvg_conv3d_frames_workgroups_f32out': [_i64] + [_i32] * 7,
     'lvg_conv3d_frames_ex': [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     'lvg_conv3d_frames_wgrad': [_vp] * 4 + [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp],

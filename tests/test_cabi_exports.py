@@ -58,14 +58,19 @@ def test_planning_queries_without_a_gpu(monkeypatch):
     """The launch-planning queries of the C ABI are host arithmetic (no device work): tile / slot / split counts for the shapes of
     BASELINE.json configs[1], and 0 = "no kernel for this shape" where the callers keep the library route."""
     from torch_utils.ops import _hip
-    for var in ('LVG_CONV_BM', 'LVG_CONV_BN', 'LVG_CONV_NB', 'LVG_WGRAD_SPLITS', 'LVG_WGRAD_TARGET'):
+    for var in ('LVG_CONV_BM', 'LVG_CONV_BN', 'LVG_CONV_NB', 'LVG_CONV_PERSIST', 'LVG_WGRAD_SPLITS', 'LVG_WGRAD_TARGET'):
         monkeypatch.delenv(var, raising=False)
     lib = _hip.lib()
     wg = lib.lvg_conv3d_frames_workgroups
     # 640 frames of 9x16, 512 -> 512 channels, 3x3x3 taps: 128-pixel x 128-channel tiles
     assert wg(640, 9, 16, 512, 512, 3, 3, 3) == (640 * 9 * 16 // 128) * 4
-    # 64 output channels: 64-channel tiles; 32 input channels / 7x7 taps: no kernel
-    assert wg(1024, 36, 64, 64, 64, 1, 3, 3) == 1024 * 36 * 64 // 128
+    # 64 output channels: 64-channel tiles, 256 pixels each on wide frames with enough tiles (128 otherwise); 32 input channels / 7x7 taps: no kernel
+    assert wg(1024, 36, 64, 64, 64, 1, 3, 3) == 1024 * 36 * 64 // 256
+    assert wg(32, 36, 64, 64, 64, 1, 3, 3) == 32 * 36 * 64 // 128
+    # the plan can be forced (A/B measurements, the bitwise-agreement tests) and released again
+    assert lib.lvg_conv3d_frames_set_plan(128, 0, 0, 0) == 0 and wg(1024, 36, 64, 64, 64, 1, 3, 3) == 1024 * 36 * 64 // 128
+    assert lib.lvg_conv3d_frames_set_plan(100, 0, 0, 0) != 0
+    assert lib.lvg_conv3d_frames_set_plan(0, 0, 0, 0) == 0 and wg(1024, 36, 64, 64, 64, 1, 3, 3) == 1024 * 36 * 64 // 256
     assert wg(1024, 64, 64, 32, 64, 1, 3, 3) == 0 and wg(16, 8, 8, 64, 64, 1, 7, 7) == 0
     # weight gradient: one full round of workgroups, rounded down (2 per CU; 1 for 64-pixel-wide frames), at least 8 K-steps each
     sp = lib.lvg_conv3d_frames_wgrad_splits

@@ -188,17 +188,44 @@ def test_hip_wgrad_matches_oracle_gpu(oracle, case, dtype, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_tile_variants_agree_bitwise_gpu(monkeypatch):
+def test_tile_variants_agree_bitwise_gpu():
     """Every tile shape / weight-ring depth runs the same arithmetic in the same order."""
+    from torch_utils.ops import _hip
     x, weight, pre, b, res, post = _case(3, 4, 2, 128, 128, 9, 16, 3, 3, 3, torch.bfloat16, 'cuda')
     a = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
-    for bm, bn, nb, pb in [(128, 64, 2, 2), (256, 128, 3, 2), (256, 64, 2, 2), (128, 128, 3, 2)]:
-        monkeypatch.setenv('LVG_CONV_BM', str(bm))
-        monkeypatch.setenv('LVG_CONV_BN', str(bn))
-        monkeypatch.setenv("LVG_CONV_NB", str(nb))
-        monkeypatch.setenv("LVG_CONV_PB", str(pb))
-        r = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
-        assert torch.equal(a, r), (bm, bn, nb, pb)
+    try:
+        for bm, bn, nb in [(128, 64, 2), (256, 128, 3), (256, 64, 2), (128, 128, 3), (128, 128, 2)]:
+            assert _hip.lib().lvg_conv3d_frames_set_plan(bm, bn, nb, 0) == 0
+            r = cf.conv3d_frames_forward(x, weight, 2, pre, b, res, post, act='lrelu', clamp=2.0)[0]
+            assert torch.equal(a, r), (bm, bn, nb)
+    finally:
+        _hip.lib().lvg_conv3d_frames_set_plan(0, 0, 0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(44, 4, 64, 64, 36, 64, 1), (52, 4, 64, 64, 32, 32, 5), (88, 4, 128, 64, 18, 32, 3), (44, 4, 64, 64, 36, 63, 1)])
+def test_persistent_workgroups_compute_the_same_bits_gpu(case):
+    """The persistent form of the 64-channel tiles (a workgroup walks many tiles: next band prefetched during the K-steps, weight ring running
+    on, output staged in the finished band buffer) against one workgroup per tile: every output -- activation, saved sum, the per-tile
+    partial sums of squares -- bit for bit, with residual, bias and both scales; ragged last tile and odd width included."""
+    from torch_utils.ops import _hip
+    t, n, ci, co, h, w, kt = case
+    x, weight, pre, b, res, post = _case(5, t, n, ci, co, h, w, kt, 3, 3, torch.bfloat16, 'cuda', with_res=True)
+    lib = _hip.lib()
+    outs = {}
+    try:
+        for bm in (256, 128):
+            for persist in (0, 1):
+                assert lib.lvg_conv3d_frames_set_plan(bm, 0, 0, persist) == 0
+                outs[bm, persist] = cf.conv3d_frames_forward(x, weight, n, pre, b, res, post, act='lrelu', clamp=2.0, want_msq=True)
+    finally:
+        lib.lvg_conv3d_frames_set_plan(0, 0, 0, 0)
+    torch.cuda.synchronize()
+    for bm in (256, 128):
+        for got, want, name in zip(outs[bm, 1], outs[bm, 0], ['out', 'ysum', 'msq']):
+            assert torch.isfinite(want.float()).all()
+            assert torch.equal(got, want), (bm, name, float((got.float() - want.float()).abs().max()))
+    assert torch.equal(outs[256, 1][0], outs[128, 1][0])
 
 
 @pytest.mark.gpu
