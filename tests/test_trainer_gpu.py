@@ -61,20 +61,22 @@ def test_update_r1_gradients_match_reference_golden():
 def test_graph_mode_trains_like_eager_mode():
     """use_graphs=True replays the compute of update_G / update_D from hipGraphs, with the host-side draws (crop offsets, temporal stretch)
     handed over through static buffers. With the device-side randomness taken out (fixed temporal noise per shape, no DiffAugment -- captured
-    and eager execution number the device generator differently) both modes must compute the same step: gradients of the first step within
-    bf16 / atomic-order noise, the running magnitudes after three steps (one update per update_D: the eager warm-up before the capture is
-    rolled back), one graph per phase and micro-batch shape."""
+    and eager execution number the device generator differently) both modes compute the same step. The yardstick is the distance between
+    TWO EAGER runs: the library convolutions of the 3 x 4-pixel layers sum split-K partials with atomics, so identical inputs give outputs
+    a few bf16 ulps apart and 16-bit gradients that differ by ~10 % of a tensor's maximum from run to run (tools/determinism_ops.py, profiles/r04_determinism_first_op.log);
+    the graph run must lie within three times that distance of an eager run -- gradients of the first step, running magnitudes after
+    three steps (one update per update_D: the eager warm-up before the capture is rolled back), one graph per phase and micro-batch shape."""
     from lvg.train_lres import LowResTrainer
     kw = dict(seq_length=8, height=36, width=64, device='cuda', compute_dtype=torch.bfloat16, G_grad_accum=2, D_grad_accum=2,
               overlap_grad_sync=False, with_ema=True, temp_scale_augment=1.0, diffaug_policy='')
-    torch.manual_seed(0)
-    eager = LowResTrainer(**kw)
-    torch.manual_seed(0)
-    graph = LowResTrainer(use_graphs=True, **kw)
-    assert graph.use_graphs and not eager.use_graphs
-    real = torch.rand(4, 3, 8, 36, 64, device='cuda') * 2 - 1
-    grads = {}
-    for name, tr in (('eager', eager), ('graph', graph)):
+    real = None
+    grads, mags, trainers = {}, {}, {}
+    for name, use_graphs in (('eager', False), ('eager2', False), ('graph', True)):
+        torch.manual_seed(0)
+        tr = LowResTrainer(use_graphs=use_graphs, **kw)
+        assert tr.use_graphs == use_graphs
+        if real is None:
+            real = torch.rand(4, 3, 8, 36, 64, device='cuda') * 2 - 1
         draw, fixed = tr.G.sample_temporal_emb, {}
 
         def same_noise(batch, seq, generator=None, draw=draw, fixed=fixed):
@@ -87,14 +89,17 @@ def test_graph_mode_trains_like_eager_mode():
         grads[name] = (tr.G_sync.flat.clone(), tr.D_sync.flat.clone())
         for step in (2, 3):
             tr.train_step(step=step, real_video=real, r1_interval=0)
+        mags[name] = torch.stack([b.float().reshape(()) for n, b in tr.G.named_buffers() if n.endswith('magnitude_ema')])
+        trainers[name] = tr
     torch.cuda.synchronize()
-    for e, g in zip(grads['eager'], grads['graph']):
+    for e, e2, g in zip(grads['eager'], grads['eager2'], grads['graph']):
         assert torch.isfinite(g).all() and float(e.abs().max()) > 0
-        assert float((e - g).abs().max()) <= 2e-2 * float(e.abs().max()), (float((e - g).abs().max()), float(e.abs().max()))
-    mag_e = torch.stack([b.float().reshape(()) for n, b in eager.G.named_buffers() if n.endswith('magnitude_ema')])
-    mag_g = torch.stack([b.float().reshape(()) for n, b in graph.G.named_buffers() if n.endswith('magnitude_ema')])
-    assert float((mag_e - 1).abs().max()) > 1e-4
-    assert float((mag_e - mag_g).abs().max()) <= 0.25 * float((mag_e - 1).abs().max()), (mag_e, mag_g)
+        noise = float((e - e2).abs().max())
+        assert float((e - g).abs().max()) <= 3 * noise + 1e-3 * float(e.abs().max()), (float((e - g).abs().max()), noise, float(e.abs().max()))
+    moved = float((mags['eager'] - 1).abs().max())
+    assert moved > 1e-4
+    assert float((mags['eager'] - mags['graph']).abs().max()) <= 3 * float((mags['eager'] - mags['eager2']).abs().max()) + 0.1 * moved, (mags['eager'], mags['graph'])
+    graph = trainers['graph']
     for p in list(graph.G.parameters()) + list(graph.D.parameters()):
         assert torch.isfinite(p).all()
     assert {k[0] for k in graph._graphs if isinstance(k, tuple)} >= {'G', 'Dgen', 'D'}
