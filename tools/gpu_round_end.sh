@@ -1,18 +1,9 @@
-# Round-end evidence in one gpurun call: rocprofv3 stats of the default bench, timed-window table,
-# PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately, eager launches).
+# Round-end evidence in one gpurun call: the GPU suite, smoke, the default bench line as the driver runs it, a rocprofv3 --kernel-trace --stats
+# summary of the main leg, and the HBM traffic passes (tools/gpu_traffic.sh).
+bash tools/gpu_full_suite.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
-rm -f gpurun_out/prof_bench/bench_kernel_trace.csv
-export LVG_BENCH_NO_ROOFLINE=1
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_window -o win -- python bench.py --no-cpu-baseline > gpurun_out/window.log 2>&1
-python tools/trace_window.py gpurun_out/prof_window/win_kernel_trace.csv $(python -c "
-import json
-for l in open('gpurun_out/window.log'):
-    if l.startswith('{'):
-        d=json.loads(l); print(d['ms_per_step']*d['steps'], d['steps'])") > gpurun_out/window_stats.csv 2>&1
-rm -f gpurun_out/prof_window/win_kernel_trace.csv
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --graph off --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --graph off --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1
-find gpurun_out -name "*kernel_trace.csv" -delete
-du -sh gpurun_out/*; grep -o '"value": [0-9.]*' gpurun_out/bench.log gpurun_out/window.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python bench.py --no-extra-legs --no-cpu-baseline > gpurun_out/r04_bench_stats_run.log 2>&1
+find gpurun_out/prof_bench -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_bench_default_kernel_stats.csv \;
+rm -rf gpurun_out/prof_bench
+bash tools/gpu_traffic.sh > gpurun_out/r04_traffic_run.log 2>&1
+tail -3 gpurun_out/r04_traffic_run.log | cut -c1-300
