@@ -573,12 +573,13 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
 def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):
     """BASELINE.json configs[4] at N = 1: the step body of train_sres.py:241-264 (SuperResTrainer.train_step: update_G, update_D, R1 on every
     16th step, ADA probability update on every 4th, generator EMA) on synthetic (low-resolution clip with context, high-resolution clip)
-    pairs, total batch 16 in micro-batches of 2 segments, ADA pipeline and conditioning augmentation on. Eager launches."""
+    pairs, total batch 16 in micro-batches of 2 segments, ADA pipeline and conditioning augmentation on. Graph replay per phase (LVG_TRAIN_GRAPHS=0: eager)."""
     from lvg.train_sres import SuperResTrainer
     torch.manual_seed(0)
     accum = max(1, total_batch // 2)
+    graphs = os.environ.get('LVG_TRAIN_GRAPHS', '1') != '0'      # one rank: the compute of both updates replayed from hipGraphs (SuperResTrainer(use_graphs=True))
     tr = SuperResTrainer(device=dev, compute_dtype=torch.float16, G_grad_accum=accum, D_grad_accum=accum, augment_p_init=0.2,
-                         overlap_grad_sync=True, with_ema=True)
+                         overlap_grad_sync=True, with_ema=True, use_graphs=graphs)
     lr = torch.rand(total_batch, 3, tr.context_seq_length, 36, 64, device=dev) * 2 - 1
     hr = torch.rand(total_batch, 3, tr.seq_length, 144, 256, device=dev) * 2 - 1
     step_no = 1
@@ -604,7 +605,8 @@ def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):
         extra = {'r1_update_ms': round(r1_ms, 2), 'value_with_r1_every_16': round(total_batch * 8 / (dt + r1_ms * 1e-3 / 16), 2)}
     del tr
     return {**extra, 'metric': 'frames/sec train_sres iteration (update_G + update_D + R1/16 + ADA/4 + EMA), 8-frame 144x256 segments', 'value': round(total_batch * 8 / dt, 2),
-            'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'warmup': warmup, 'dtype': 'f16', 'launch_mode': 'eager', 'n_gpus': 1,
+            'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'warmup': warmup, 'dtype': 'f16',
+            'launch_mode': 'hipgraph per phase (update_G micro-batch, fake generation, update_D micro-batch); optimizer, R1, ADA update eager' if graphs else 'eager', 'n_gpus': 1,
             'config': {'workload': f'train_sres.py step body, total batch {total_batch} ({accum} micro-batches of 2 segments), ADA p = 0.2 + conditioning augmentation, '
                                    f'R1 steps in the timed region: {r1_steps}, ADA updates: {ada_steps}', 'global_batch': total_batch}}
 

@@ -33,8 +33,23 @@ WARP_GRAD = os.environ.get('LVG_ADA_WARP_GRAD', 'adjoint')        # 'composed': 
 SYM2 = (-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025)
 
 
+_CONST = {}             # (values, shape, dtype, device) -> tensor
+
+
+def _cached(values, device, dtype=torch.float32) -> torch.Tensor:
+    """A constant tensor from python numbers, built ONCE per (values, device): building it from a list is a host-to-device copy, which a stream
+    capture does not allow -- the pipeline must be replayable from a hipGraph (lvg.phase_graphs) after one eager pass. Read-only by contract."""
+    arr = np.asarray(values, dtype=np.float64)
+    device = torch.device('cpu' if device is None else device)
+    key = (arr.tobytes(), arr.shape, dtype, device)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.tensor(arr, dtype=dtype, device=device)
+    return t
+
+
 def _const(value, like: torch.Tensor) -> torch.Tensor:
-    return torch.as_tensor(value, dtype=torch.float32, device=like.device)
+    return _cached(value, like.device)
 
 
 _MAT_BASE = {}          # (constant pattern, device) -> the matrix with zeros where per-sample tensors go
@@ -46,7 +61,7 @@ def _mat(rows: Sequence[Sequence], device=None) -> torch.Tensor:
     `full_like` per constant entry plus a stack: ~2 x the launches, and the pipeline is a chain of a hundred such tiny launches)."""
     tensors = [e for row in rows for e in row if isinstance(e, torch.Tensor)]
     if not tensors:
-        return torch.tensor(np.asarray(rows, dtype=np.float32), device=device)
+        return _cached(rows, device)
     ref = tensors[0]
     r, c = len(rows), len(rows[0])
     const = tuple(0.0 if isinstance(e, torch.Tensor) else float(e) for row in rows for e in row)
@@ -205,7 +220,7 @@ class AugmentPipe(torch.nn.Module):
         clamped to the image size -- an int32 tensor on g_inv's device (reference ada_augment.py:275-284; no host read here)."""
         dev = g_inv.device
         cx, cy = (width - 1) / 2, (height - 1) / 2
-        corners = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dtype=torch.float32, device=dev)
+        corners = _cached([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dev)
         reach = (g_inv @ corners.t())[:, :2, :].permute(1, 0, 2).flatten(1)               # [xy, N*4]
         reach = torch.cat([-reach, reach]).max(dim=1).values                              # [x0, y0, x1, y1]
         pad_f = self.Hz_geom.shape[0] // 4
@@ -260,7 +275,7 @@ class AugmentPipe(torch.nn.Module):
             nonlocal c_mat
             c_mat = m if c_mat is None else m @ c_mat
 
-        luma = torch.tensor([1, 1, 1, 0], dtype=torch.float32, device=dev) / math.sqrt(3)
+        luma = _cached([1 / math.sqrt(3)] * 3 + [0], dev)
         if self.brightness > 0:
             b = torch.randn([n], device=dev) * self.brightness_std
             b = self._gate(self.brightness, [n], b, 0)
@@ -299,7 +314,7 @@ class AugmentPipe(torch.nn.Module):
     def _band_gains(self, n: int, dev, q) -> torch.Tensor:
         bands = self.Hz_fbank.shape[0]
         assert len(self.imgfilter_bands) == bands
-        power = torch.tensor([10, 1, 1, 1], dtype=torch.float32, device=dev) / 13     # expected 1/f power per band
+        power = _cached([10 / 13, 1 / 13, 1 / 13, 1 / 13], dev)                         # expected 1/f power per band
         gains = torch.ones([n, bands], device=dev)
         for i, strength in enumerate(self.imgfilter_bands):
             t_i = torch.exp2(torch.randn([n], device=dev) * self.imgfilter_std)

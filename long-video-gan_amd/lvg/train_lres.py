@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import ddp
 from .optim import FlatAdam
+from .phase_graphs import PhaseGraphs
 from .augment import crop_time, diff_augment, temporal_scale_apply, temporal_scale_augment, temporal_scale_params
 from .models import lres as lres_models
 from .models.lres import VideoDiscriminator, VideoGenerator
@@ -50,6 +51,7 @@ class LowResTrainer:
         # static device buffers. Bucket all-reduces from autograd hooks would be captured too, so the exchange runs after the replay.
         self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
         self._graphs = {}
+        self._phase_graphs = PhaseGraphs(lambda: (self.G_sync.flat, self.D_sync.flat, *self.G.buffers()), self._graphs)
         if self.use_graphs:
             overlap_grad_sync = False
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
@@ -96,25 +98,9 @@ class LowResTrainer:
                 d.copy_(s, non_blocking=True)
 
     def _replay(self, key, fn):
-        """Run `fn` from its graph. First time `key` is seen: one eager run on a side stream (lazy initialisation, library plans) whose
-        side effects on the gradient buffers and the generator's running statistics are rolled back, then the capture. `fn` must read its
-        inputs from static tensors and leave its outputs in static tensors."""
-        g = self._graphs.get(key)
-        if g is None:
-            keep = [t for t in (self.G_sync.flat, self.D_sync.flat, *self.G.buffers())]
-            saved = [t.clone() for t in keep]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                fn()
-            torch.cuda.current_stream().wait_stream(side)
-            for t, v in zip(keep, saved):
-                t.copy_(v)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()
-            self._graphs[key] = g
-        g.replay()
+        """Run `fn` from its graph (lvg.phase_graphs: eager warm-up rolled back on the gradient buffers and the generator's running
+        statistics, capture, replay)."""
+        self._phase_graphs.replay(key, fn)
 
     # ------------------------------------------------------------------------------------------
     def _ema_beta(self, step: int) -> float:

@@ -17,6 +17,7 @@ from torch_utils.ops import conv2d_gradfix, grid_sample_gradfix
 
 from . import ddp
 from .optim import FlatAdam
+from .phase_graphs import PhaseGraphs
 from .ada_augment import AugmentPipe
 from .models import sres
 
@@ -32,7 +33,7 @@ class SuperResTrainer:
                  augment_p_init: float = 0.0, augment_p_max: float = 0.5, augment_p_update_rate: float = 0.000125,
                  augment_real_sign_target: Optional[float] = 0.6, augment_kwargs: Optional[dict] = None,
                  in_augment_p: float = 0.5, in_augment_strength: float = 8.0, overlap_grad_sync: bool = True,
-                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True):
+                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True, use_graphs: bool = False):
         conv2d_gradfix.enabled = True            # as train_sres.py:81-82: R1 differentiates twice through
         grid_sample_gradfix.enabled = True       # the resampling convs and ADA's grid_sample
         self.seq_length, self.temporal_context, self.channels = seq_length, temporal_context, channels
@@ -58,6 +59,13 @@ class SuperResTrainer:
                               ema_params=self.G_ema.parameters() if self.G_ema is not None else None)
         self.D_opt = FlatAdam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
         self._step = 0
+        # use_graphs: the compute of a micro-batch of update_G / update_D and the fake generation are captured once per shape into hipGraphs
+        # and replayed (every random draw of this trainer is made on the device: lvg.phase_graphs); the exchange -- an RCCL collective cannot be
+        # captured, so no overlap with backward in this mode --, the optimizer steps, R1 and the ADA update stay eager.
+        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
+        self._static = {}
+        if self.use_graphs:
+            overlap_grad_sync = False
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
         self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
 
@@ -75,6 +83,16 @@ class SuperResTrainer:
                                           xfrac=1, xfrac_std=0.002 * k, noise=1, noise_std=0.01 * k)
             self.in_augment.to(self.device).requires_grad_(False).train()
             self.in_augment.p.fill_(in_augment_p)
+        self._phase_graphs = PhaseGraphs(lambda: (self.G_sync.flat, self.D_sync.flat, self._real_sign_sum, *self.G.buffers()))
+
+    def _static_like(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """A persistent input buffer of a captured phase, filled with `t`."""
+        key = (name, tuple(t.shape), t.dtype)
+        buf = self._static.get(key)
+        if buf is None:
+            buf = self._static[key] = torch.empty_like(t, memory_format=torch.contiguous_format)
+        buf.copy_(t)
+        return buf
 
     # ------------------------------------------------------------------------------------------
     def crop_to_seq_length(self, video: torch.Tensor) -> torch.Tensor:
@@ -113,6 +131,11 @@ class SuperResTrainer:
         for k, lr in enumerate(chunks):
             if k == len(chunks) - 1 and self.G_sync.overlap:
                 self.G_sync.arm()
+            if self.use_graphs:
+                lr_in = self._static_like('G.lr', lr)
+                self._phase_graphs.replay(('G', tuple(lr.shape)),
+                                          lambda: F.softplus(-self.run_D(self.crop_to_seq_length(lr_in), self.G(lr_in))).mean().backward())
+                continue
             logits = self.run_D(self.crop_to_seq_length(lr), self.G(lr))
             F.softplus(-logits).mean().backward()
         self.G.requires_grad_(False)
@@ -125,6 +148,8 @@ class SuperResTrainer:
         assert fake_lr_video.size(0) == real_lr_video.size(0) == real_hr_video.size(0)
         assert fake_lr_video.size(0) % self.D_grad_accum == 0
         fake_lr_video, real_lr_video = self._jitter(fake_lr_video), self._jitter(real_lr_video)
+        if self.use_graphs:
+            return self._update_D_graphs(fake_lr_video, real_lr_video, real_hr_video)
         fake_hr_video = self.G(fake_lr_video, magnitude_ema_beta=self.G_magnitude_ema_beta)    # G frozen: no graph is built
         fake_lr_video, real_lr_video = self.crop_to_seq_length(fake_lr_video), self.crop_to_seq_length(real_lr_video)
         self.D.requires_grad_(True)
@@ -137,7 +162,34 @@ class SuperResTrainer:
                 self.D_sync.arm()
             F.softplus(-real_logits).mean().backward()
             with torch.no_grad():
-                self._real_sign_sum += torch.stack((real_logits.sign().sum(), real_logits.new_tensor(float(real_logits.numel()))))
+                self._real_sign_sum += torch.stack((real_logits.sign().sum(), torch.full((), float(real_logits.numel()), dtype=real_logits.dtype, device=real_logits.device)))
+        self.D.requires_grad_(False)
+        self.D_sync.finish(gain=1 / self.D_grad_accum)
+        self.D_opt.step()
+
+    def _update_D_graphs(self, fake_lr_video: torch.Tensor, real_lr_video: torch.Tensor, real_hr_video: torch.Tensor) -> None:
+        """update_D (inputs already jittered) with the fake generation and every (fake, real) micro-batch replayed from graphs."""
+        gen_in = self._static_like('D.gen_lr', fake_lr_video)
+        out = self._static.setdefault(('D.gen_out', tuple(fake_lr_video.shape)), {})
+
+        def generate():
+            out['hr'] = self.G(gen_in, magnitude_ema_beta=self.G_magnitude_ema_beta)
+        self._phase_graphs.replay(('Dgen', tuple(fake_lr_video.shape)), generate)
+        fake_hr_video = out['hr']
+        fake_lr_video, real_lr_video = self.crop_to_seq_length(fake_lr_video), self.crop_to_seq_length(real_lr_video)
+        self.D.requires_grad_(True)
+        self.D_sync.zero()
+        parts = [t.chunk(self.D_grad_accum) for t in (fake_lr_video, fake_hr_video, real_lr_video, real_hr_video)]
+        for f_lr, f_hr, r_lr, r_hr in zip(*parts):
+            ins = [self._static_like(n, t) for n, t in (('D.f_lr', f_lr), ('D.f_hr', f_hr), ('D.r_lr', r_lr), ('D.r_hr', r_hr))]
+
+            def passes():
+                F.softplus(self.run_D(ins[0], ins[1])).mean().backward()
+                real_logits = self.run_D(ins[2], ins[3])
+                F.softplus(-real_logits).mean().backward()
+                with torch.no_grad():
+                    self._real_sign_sum += torch.stack((real_logits.sign().sum(), torch.full((), float(real_logits.numel()), dtype=real_logits.dtype, device=real_logits.device)))
+            self._phase_graphs.replay(('D', tuple(f_lr.shape)), passes)
         self.D.requires_grad_(False)
         self.D_sync.finish(gain=1 / self.D_grad_accum)
         self.D_opt.step()

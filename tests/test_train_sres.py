@@ -105,3 +105,51 @@ def test_run_D_applies_one_transform_to_both_clips_cpu():
 @pytest.mark.gpu
 def test_train_step_gpu_fp16():
     _step('cuda', torch.float16)
+
+
+@pytest.mark.gpu
+def test_graph_mode_trains_like_eager_mode_gpu():
+    """use_graphs=True replays the compute of update_G / update_D (and the fake generation) from hipGraphs. With every random draw off
+    (no ADA, no conditioning jitter, no conditioning dropout, one fixed latent per batch size) the two modes compute the same step; the yardstick is the distance between
+    two eager runs (library kernels with atomics keep the networks from being bit-reproducible): gradients of the first step,
+    the sign statistics of the real logits, one graph per phase."""
+    kw = dict(SMALL, augment_p_init=0.0, augment_real_sign_target=None, in_augment_strength=0.0, lr_cond_prob=1.0,
+              G_grad_accum=2, D_grad_accum=2)
+    lr = hr = None
+    grads, signs, trainers = {}, {}, {}
+    for name, use_graphs in (('eager', False), ('eager2', False), ('graph', True)):
+        torch.manual_seed(0)
+        tr = SuperResTrainer(device='cuda', compute_dtype=torch.float16, use_graphs=use_graphs, **kw)
+        assert tr.use_graphs == use_graphs and tr.augment is None and tr.in_augment is None
+        if lr is None:
+            lr = torch.rand(4, 3, 4, 9, 16, device='cuda') * 2 - 1
+            hr = torch.rand(4, 3, 2, 36, 64, device='cuda') * 2 - 1
+        draw, fixed = tr.G.sample_latent_z, {}
+
+        def same_z(batch_size, generator_z=None, draw=draw, fixed=fixed):      # (captured and eager execution number the device generator differently)
+            if batch_size not in fixed:
+                fixed[batch_size] = draw(batch_size, torch.Generator(device='cuda').manual_seed(7 + batch_size))
+            return fixed[batch_size]
+        tr.G.sample_latent_z = same_z
+        torch.manual_seed(5)
+        tr.train_step(step=1, lr_video=lr, hr_video=hr, r1_interval=0, ada_interval=0)
+        grads[name] = (tr.G_sync.flat.clone(), tr.D_sync.flat.clone())
+        signs[name] = tr._real_sign_sum.clone()
+        for step in (2, 3):
+            tr.train_step(step=step, lr_video=lr, hr_video=hr, r1_interval=0, ada_interval=0)
+        trainers[name] = tr
+    torch.cuda.synchronize()
+    for e, e2, g in zip(grads['eager'], grads['eager2'], grads['graph']):
+        assert torch.isfinite(g).all() and float(e.abs().max()) > 0
+        noise = float((e - e2).abs().max())
+        assert float((e - g).abs().max()) <= 5 * noise + 0.05 * float(e.abs().max()), (float((e - g).abs().max()), noise, float(e.abs().max()))
+    assert float(signs['graph'][1]) == float(signs['eager'][1]) == 4.0          # four real logits counted once (the capture's warm-up is rolled back)
+    graph = trainers['graph']
+    for p in list(graph.G.parameters()) + list(graph.D.parameters()):
+        assert torch.isfinite(p).all()
+    assert {k[0] for k in graph._phase_graphs.graphs} == {'G', 'Dgen', 'D'}
+
+
+def test_graph_mode_is_ignored_without_a_gpu_cpu():
+    tr = SuperResTrainer(device='cpu', compute_dtype=torch.float32, use_graphs=True, **SMALL)
+    assert tr.use_graphs is False

@@ -64,7 +64,8 @@ def test_graph_mode_trains_like_eager_mode():
     and eager execution number the device generator differently) both modes compute the same step. The yardstick is the distance between
     TWO EAGER runs: the library convolutions of the 3 x 4-pixel layers sum split-K partials with atomics, so identical inputs give outputs
     a few bf16 ulps apart and 16-bit gradients that differ by ~10 % of a tensor's maximum from run to run (tools/determinism_ops.py, profiles/r04_determinism_first_op.log);
-    the graph run must lie within three times that distance of an eager run -- gradients of the first step, running magnitudes after
+    the graph run must lie within five times that distance (+ 5 % of the tensor's maximum: one pair of eager runs is a noisy yardstick;
+    a capture that ran a phase twice or not at all is off by the whole gradient) of an eager run -- gradients of the first step, running magnitudes after
     three steps (one update per update_D: the eager warm-up before the capture is rolled back), one graph per phase and micro-batch shape."""
     from lvg.train_lres import LowResTrainer
     kw = dict(seq_length=8, height=36, width=64, device='cuda', compute_dtype=torch.bfloat16, G_grad_accum=2, D_grad_accum=2,
@@ -95,7 +96,7 @@ def test_graph_mode_trains_like_eager_mode():
     for e, e2, g in zip(grads['eager'], grads['eager2'], grads['graph']):
         assert torch.isfinite(g).all() and float(e.abs().max()) > 0
         noise = float((e - e2).abs().max())
-        assert float((e - g).abs().max()) <= 3 * noise + 1e-3 * float(e.abs().max()), (float((e - g).abs().max()), noise, float(e.abs().max()))
+        assert float((e - g).abs().max()) <= 5 * noise + 0.05 * float(e.abs().max()), (float((e - g).abs().max()), noise, float(e.abs().max()))
     moved = float((mags['eager'] - 1).abs().max())
     assert moved > 1e-4
     assert float((mags['eager'] - mags['graph']).abs().max()) <= 3 * float((mags['eager'] - mags['eager2']).abs().max()) + 0.1 * moved, (mags['eager'], mags['graph'])
