@@ -51,6 +51,7 @@ struct Plan
     int bm, bn, pb, bandRows, nABuf, nBBuf, ldsBytes;
     int64_t mTiles;
     int persistGrid;            // > 0: the persistent kernel with this many workgroups (igemm_kernel.h, PERSIST)
+    bool static1;               // the one-workgroup-per-CU static-tap form of the 256 x 64 tile (igemm_kernel.h, STATIC1)
 };
 
 int device_cus()
@@ -116,6 +117,11 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
     // prologue (band from HBM) -> K loop -> stores one after the other (memory operations alone 254 us, arithmetic alone ~160 us, together
     // 410 us on 64 -> 64 @ 36 x 64: profiles/r04_conv_abl64.log). LVG_CONV_PERSIST=0 switches it off (A/B).
     pl.persistGrid = 0;
+    // 256 x 64 tiles with two bands (more than one 64-channel chunk or temporal tap) need > 80 KB of LDS: one workgroup per CU whatever the
+    // registers, so they take the static-tap loop (LVG_CONV_STATIC1=0: the generic loop, A/B)
+    static const int static1On = env_int("LVG_CONV_STATIC1", 1);
+    pl.static1 = static1On && !outF32 && pl.bm == 256 && pl.bn == 64 && nb == 2 && kh == 3 && kw == 3 && pl.ldsBytes > 80 * 1024
+                 && pl.bandRows / 8 <= 2 * 9 * 3;                       // (band pieces per band wave and K-step: the static loop's 3 slots)
     const int persistOn = overrides().persist;
     if (persistOn && !outF32 && ntap > 1 && pl.bn == 64 && nb == 2)
     {
@@ -146,10 +152,10 @@ bool shape_ok(int64_t frames, int h, int w, int ci, int co, int kt, int kh, int 
     return xstride >= ci && xstride % 8 == 0 && (kt / 2 + 1) * M < ((int64_t)1 << 31) && M * xstride * 2 < ((int64_t)1 << 32);
 }
 
-template <class T, int BM, int BN, int PB, int NB, bool OUTF = false, bool PERSIST = false>
+template <class T, int BM, int BN, int PB, int NB, bool OUTF = false, bool PERSIST = false, bool STATIC1 = false>
 int launch(const ConvArgs& a, const Plan& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB, false, OUTF, PERSIST>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, PB, NB, false, OUTF, PERSIST && !STATIC1, STATIC1>;
     if (pl.ldsBytes > 64 * 1024)
     {
         // opt in to > 64 KiB of dynamic LDS; the attribute is per device, setting it again is cheap
@@ -170,6 +176,7 @@ int launch_ring(const ConvArgs& a, const Plan& pl, hipStream_t s)
 {
     if constexpr (NB == 2)
     {
+        if (pl.static1 && pl.persistGrid == 0) return launch<T, 256, 64, 2, 2, false, false, true>(a, pl, s);
         if (pl.persistGrid > 0) return pl.bm == 256 ? launch<T, 256, 64, 2, 2, false, true>(a, pl, s) : launch<T, 128, 64, 2, 2, false, true>(a, pl, s);
     }
     if (pl.bm == 256) return pl.bn == 128 ? launch<T, 256, 128, 2, NB>(a, pl, s) : launch<T, 256, 64, 2, NB>(a, pl, s);

@@ -157,10 +157,14 @@ constexpr int kPatchPitch = kTileW + 2;
 // tiles, and the epilogue stages the output rows in the band buffer the tile has just finished with -- so the HBM reads of tile i + 1, the
 // matrix work of tile i and the stores of tile i - 1 overlap inside ONE workgroup (the layers with few K-steps per tile -- 64 channels --
 // spent their time in the serial prologue -> K loop -> stores of each workgroup: profiles/r04_conv_abl64.log).
-template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false, bool PERSIST = false>
-__global__ __launch_bounds__(BM / (32 * PB) * 128, 2) void conv3d_igemm_kernel(typename ConvArgsOf<T2D>::type p)
+// STATIC1 (time-major kernel, 64-channel tiles): the static-tap K loop for tiles whose LDS footprint (two bands) leaves room for ONE workgroup per
+// CU anyway -- the loop's 236 registers, which cost the two-workgroup case its occupancy, are free there (eight waves = two per SIMD = 256
+// registers each), and the generic loop's band waves (137-165 scalar + 88 vector instructions per K-step against 8 MFMAs) paced those tiles.
+template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false, bool PERSIST = false, bool STATIC1 = false>
+__global__ __launch_bounds__(BM / (32 * PB) * 128, STATIC1 ? 1 : 2) void conv3d_igemm_kernel(typename ConvArgsOf<T2D>::type p)
 {
     static_assert(!PERSIST || (!T2D && !OUTF), "persistent form: time-major frames, 16-bit output");
+    static_assert(!STATIC1 || (!T2D && !OUTF && !PERSIST && NB == 2), "one-workgroup static form: time-major frames, 16-bit output, ring of two");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW  = BM / (32 * PB) * 2;      // waves: BM / (32 PB) along the pixels x 2 along the output channels
     constexpr int NCB = BN / 64;                 // 32-channel MFMA blocks per wave
@@ -648,7 +652,7 @@ next_tile:                                                            // PERSIST
             }
         }
     }
-    else if (!PERSIST && !T2D && kStatic3D && (BN == 128 || kStatic3DBn64) && NB == 2 && split && p.kh == 3 && p.kw == 3 && nAI <= NWA * 9 * ((BN == 128 || BM == 256) ? 3 : 4))
+    else if (!PERSIST && !T2D && kStatic3D && (BN == 128 || kStatic3DBn64 || STATIC1) && NB == 2 && split && p.kh == 3 && p.kw == 3 && nAI <= NWA * 9 * ((BN == 128 || BM == 256) ? 3 : 4))
     {
         // ---- time-major frames, 3 x 3 spatial taps (any number of temporal taps): the static-tap loop of the 2-D kernel with the 'same'
         // padding masks kept. Per (tap, pixel block) the band row and its swizzle phase are precomputed as ONE address word; a K-step
