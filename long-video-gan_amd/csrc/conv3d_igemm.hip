@@ -120,7 +120,7 @@ int make_plan(int64_t M, int W, int Ci, int Co, int kt, int kh, int kw, Plan& pl
     // 256 x 64 tiles with two bands (more than one 64-channel chunk or temporal tap) need > 80 KB of LDS: one workgroup per CU whatever the
     // registers, so they take the static-tap loop (LVG_CONV_STATIC1=0: the generic loop, A/B)
     static const int static1On = env_int("LVG_CONV_STATIC1", 1);
-    pl.static1 = static1On && !outF32 && pl.bm == 256 && pl.bn == 64 && nb == 2 && kh == 3 && kw == 3 && pl.ldsBytes > 80 * 1024
+    pl.static1 = static1On && !outF32 && pl.bm == 256 && pl.bn == 64 && nb == 2 && kh == 3 && kw == 3 && (pl.ldsBytes > 80 * 1024 || static1On == 2)   // (2: also the single-band tiles, measurement)
                  && pl.bandRows / 8 <= 2 * 9 * 3;                       // (band pieces per band wave and K-step: the static loop's 3 slots)
     const int persistOn = overrides().persist;
     if (persistOn && !outF32 && ntap > 1 && pl.bn == 64 && nb == 2)
