@@ -1,0 +1,61 @@
+"""Golden vectors for the trainer-side augmentation glue of the low-resolution GAN, produced by the REFERENCE code: the temporal stretch +
+pad / crop inside VideoGAN.run_D (model/video_gan_lres.py:236-265) and DiffAugment (model/diff_augment.py), run on CPU with seeded generators.
+The trainer object is NOT constructed (it builds the networks and the optimizers): `run_D` is called on a bare instance that carries the
+attributes the method reads, with the discriminator replaced by the identity, so the returned "logits" are the augmented clip.
+Run in the build container only:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_trainer_glue.py [/root/reference]"""
+
+import os
+import sys
+
+import numpy as np
+
+REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import importlib  # noqa: E402
+import types  # noqa: E402
+
+import torch  # noqa: E402
+
+# the reference's utils.py imports I/O packages this image does not have (imageio, wandb, ...): empty stand-ins -- none of them is touched by run_D
+for _ in range(16):
+    try:
+        video_gan_lres = importlib.import_module('model.video_gan_lres')
+        break
+    except ModuleNotFoundError as err:
+        assert err.name and not err.name.startswith(('model', 'torch_utils', 'dnnlib', 'utils')), err
+        sys.modules[err.name] = types.ModuleType(err.name)
+
+assert os.path.realpath(video_gan_lres.__file__).startswith(os.path.realpath(REF))
+cls = [c for c in vars(video_gan_lres).values() if isinstance(c, type) and hasattr(c, 'run_D') and c.__module__ == video_gan_lres.__name__][0]
+
+out = {}
+cases = [('a1_t16', 1.0, 16, 16), ('a05_t16', 0.5, 16, 16), ('a2_t24', 2.0, 24, 24)]
+for name, amount, frames, seq in cases:
+    gan = object.__new__(cls)
+    gan.channels, gan.seq_length, gan.height, gan.width = 3, seq, 6, 7
+    gan.diffaug_policy, gan.temp_scale_augment = '', amount
+    gan.D = lambda v: v
+    video = torch.randn(5, 3, frames, 6, 7, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(11)
+    got = cls.run_D(gan, video)
+    out[name + '_out'] = got.numpy().astype(np.float32)
+    out[name + '_next_rand'] = torch.rand(3).numpy()              # what the CPU generator yields next: pins the NUMBER of draws
+    out[name + '_spec'] = np.asarray(repr(dict(amount=amount, frames=frames, seq_length=seq, video_seed=4, seed=11, shape=(5, 3, frames, 6, 7))))
+# DiffAugment (model/diff_augment.py): each policy alone and the trainer's default chain, seeded CPU generator
+diff_augment = importlib.import_module('model.diff_augment')
+assert os.path.realpath(diff_augment.__file__).startswith(os.path.realpath(REF))
+clip = torch.randn(4, 3, 5, 12, 20, generator=torch.Generator().manual_seed(8))
+for policy in ('color', 'translation', 'cutout', 'color,translation,cutout'):
+    torch.manual_seed(21)
+    got = diff_augment.DiffAugment(clip, policy)
+    key = 'diffaug_' + policy.replace(',', '_')
+    out[key + '_out'] = got.numpy().astype(np.float32)
+    out[key + '_next_rand'] = torch.rand(3).numpy()
+out['diffaug_spec'] = np.asarray(repr(dict(clip_seed=8, seed=21, shape=(4, 3, 5, 12, 20))))
+np.savez_compressed(os.path.join(HERE, 'trainer_glue.npz'), **out)
+print({k: (v.shape if v.ndim else str(v)) for k, v in out.items()})

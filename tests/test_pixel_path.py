@@ -258,3 +258,35 @@ def test_graph_mode_is_ignored_without_a_gpu_cpu():
     from lvg.train_lres import LowResTrainer
     tr = LowResTrainer(seq_length=8, height=36, width=64, device='cpu', compute_dtype=torch.float32, use_graphs=True, with_ema=False)
     assert tr.use_graphs is False
+
+
+@pytest.mark.parametrize('name,amount,frames', [('a1_t16', 1.0, 16), ('a05_t16', 0.5, 16), ('a2_t24', 2.0, 24)])
+def test_temporal_stretch_matches_the_reference_trainer_cpu(name, amount, frames):
+    """lvg.augment.temporal_scale_augment against the output of the REFERENCE's VideoGAN.run_D (video_gan_lres.py:236-265, identity in
+    place of the discriminator: tests/golden/make_golden_trainer_glue.py) under the same seed: same values (1e-5; measured 5e-6 -- float64
+    interpolation weights here, float32 inside F.interpolate) and the same number of draws from the CPU generator."""
+    from conftest import load_golden
+    from lvg import augment
+    g = load_golden('trainer_glue')
+    video = torch.randn(5, 3, frames, 6, 7, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(11)
+    got = augment.temporal_scale_augment(video, frames, amount)
+    after = torch.rand(3).numpy()
+    assert np.abs(got.numpy() - g[name + '_out']).max() <= 1e-5
+    assert np.array_equal(after, g[name + '_next_rand'])
+
+
+@pytest.mark.parametrize('policy', ['color', 'translation', 'cutout', 'color,translation,cutout'])
+def test_diff_augment_matches_the_reference_cpu(policy):
+    """lvg.augment.diff_augment against the reference's DiffAugment (model/diff_augment.py) on a seeded CPU generator: the same draws in
+    the same order, the same arithmetic -- bit for bit."""
+    from conftest import load_golden
+    from lvg import augment
+    g = load_golden('trainer_glue')
+    clip = torch.randn(4, 3, 5, 12, 20, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(21)
+    got = augment.diff_augment(clip, policy)
+    after = torch.rand(3).numpy()
+    key = 'diffaug_' + policy.replace(',', '_')
+    assert np.array_equal(got.numpy(), g[key + '_out'])
+    assert np.array_equal(after, g[key + '_next_rand'])
