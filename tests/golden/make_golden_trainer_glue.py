@@ -57,5 +57,26 @@ for policy in ('color', 'translation', 'cutout', 'color,translation,cutout'):
     out[key + '_out'] = got.numpy().astype(np.float32)
     out[key + '_next_rand'] = torch.rand(3).numpy()
 out['diffaug_spec'] = np.asarray(repr(dict(clip_seed=8, seed=21, shape=(4, 3, 5, 12, 20))))
+# generator EMA (video_gan_lres.py:207-214): the reference's update_G_ema on a bare instance whose G / G_ema are two float64 one-parameter-one-buffer
+# modules; the weight it applied at a step is read back from what the lerp did to them
+class _Tiny(torch.nn.Module):
+    def __init__(self, v):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.full((3,), v, dtype=torch.float64))
+        self.register_buffer('b', torch.full((2,), v * 2, dtype=torch.float64))
+
+
+steps = [0, 1, 7, 100, 5000, 24999, 25000, 25001, 400000]
+betas = []
+for step in steps:
+    gan = object.__new__(cls)
+    gan.G_ema_beta, gan.G_ema_warmup_steps = 0.99985, 25000
+    gan.G, gan.G_ema = _Tiny(1.0), _Tiny(0.0)
+    cls.update_G_ema(gan, step)
+    w = float(gan.G_ema.w[0])                         # = 1 - beta
+    assert abs(float(gan.G_ema.b[0]) - 2 * w) < 1e-12  # buffers take the same step
+    betas.append(1.0 - w)
+out['ema_steps'] = np.asarray(steps, dtype=np.int64)
+out['ema_betas'] = np.asarray(betas, dtype=np.float64)
 np.savez_compressed(os.path.join(HERE, 'trainer_glue.npz'), **out)
 print({k: (v.shape if v.ndim else str(v)) for k, v in out.items()})

@@ -290,3 +290,17 @@ def test_diff_augment_matches_the_reference_cpu(policy):
     key = 'diffaug_' + policy.replace(',', '_')
     assert np.array_equal(got.numpy(), g[key + '_out'])
     assert np.array_equal(after, g[key + '_next_rand'])
+
+
+def test_generator_ema_schedule_matches_the_reference_cpu():
+    """The weight of the generator EMA at a step (both trainers) against what the REFERENCE's update_G_ema (video_gan_lres.py:207-214) did to a
+    float64 stand-in pair of modules (tests/golden/make_golden_trainer_glue.py): warm-up ramp, the plateau from step 25 000 on."""
+    from conftest import load_golden
+    from lvg.train_lres import LowResTrainer
+    from lvg.train_sres import SuperResTrainer
+    g = load_golden('trainer_glue')
+    for cls in (LowResTrainer, SuperResTrainer):
+        tr = object.__new__(cls)
+        tr.G_ema_beta, tr.G_ema_warmup_steps = 0.99985, 25000
+        for step, beta in zip(g['ema_steps'], g['ema_betas']):
+            assert abs(cls._ema_beta(tr, int(step)) - float(beta)) < 1e-12, (cls.__name__, int(step))
