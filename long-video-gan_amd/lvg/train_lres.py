@@ -26,8 +26,10 @@ class LowResTrainer:
                  G_grad_accum: int = 1, D_lrate: float = 0.002, D_beta2: float = 0.99, D_grad_accum: int = 1,
                  r1_gamma: float = 10.0, G_random_temp_translate: bool = True, temp_scale_augment: float = 1.0,
                  diffaug_policy: str = 'color,translation,cutout', overlap_grad_sync: bool = True,
-                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True, use_graphs: bool = False):
+                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True, use_graphs: bool = False,
+                 G_warmup_steps: int = 0, D_warmup_steps: int = 0):
         self.seq_length, self.height, self.width = seq_length, height, width
+        self.G_lrate, self.D_lrate, self.G_warmup_steps, self.D_warmup_steps = G_lrate, D_lrate, G_warmup_steps, D_warmup_steps
         self.device, self.dtype = torch.device(device), compute_dtype
         self.G_magnitude_ema_beta, self.G_ema_beta, self.G_ema_warmup_steps = G_magnitude_ema_beta, G_ema_beta, G_ema_warmup_steps
         self.G_grad_accum, self.D_grad_accum, self.r1_gamma = G_grad_accum, D_grad_accum, r1_gamma
@@ -106,6 +108,11 @@ class LowResTrainer:
     def _ema_beta(self, step: int) -> float:
         halflife = math.log(self.G_ema_beta, 0.5) * (self.G_ema_warmup_steps + 1) / (step + 1)
         return min(0.5 ** halflife, self.G_ema_beta)
+
+    def update_lrates(self, step: int) -> None:
+        """Linear learning-rate warm-up of both optimizers (reference video_gan_lres.py:89-96)."""
+        self.G_opt.lr = self.G_lrate * min((step + 1) / (self.G_warmup_steps + 1), 1.0)
+        self.D_opt.lr = self.D_lrate * min((step + 1) / (self.D_warmup_steps + 1), 1.0)
 
     def update_G(self, batch: int, ema_step: Optional[int] = None) -> None:
         """`ema_step`: fold this iteration's generator-EMA update of the PARAMETERS into the optimizer pass (they do not
@@ -211,6 +218,7 @@ class LowResTrainer:
 
     def train_step(self, step: int, real_video: torch.Tensor, r1_interval: int = 16) -> None:
         """One iteration of the reference loop (train_lres.py:216-230)."""
+        self.update_lrates(step)
         self.update_G(real_video.size(0), ema_step=step)
         self.update_D(real_video)
         if r1_interval > 0 and step % r1_interval == 0:

@@ -33,7 +33,9 @@ class SuperResTrainer:
                  augment_p_init: float = 0.0, augment_p_max: float = 0.5, augment_p_update_rate: float = 0.000125,
                  augment_real_sign_target: Optional[float] = 0.6, augment_kwargs: Optional[dict] = None,
                  in_augment_p: float = 0.5, in_augment_strength: float = 8.0, overlap_grad_sync: bool = True,
-                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True, use_graphs: bool = False):
+                 G_kwargs: Optional[dict] = None, D_kwargs: Optional[dict] = None, with_ema: bool = True, use_graphs: bool = False,
+                 G_warmup_steps: int = 0, D_warmup_steps: int = 0):
+        self.G_lrate, self.D_lrate, self.G_warmup_steps, self.D_warmup_steps = G_lrate, D_lrate, G_warmup_steps, D_warmup_steps
         conv2d_gradfix.enabled = True            # as train_sres.py:81-82: R1 differentiates twice through
         grid_sample_gradfix.enabled = True       # the resampling convs and ADA's grid_sample
         self.seq_length, self.temporal_context, self.channels = seq_length, temporal_context, channels
@@ -119,6 +121,11 @@ class SuperResTrainer:
     def _ema_beta(self, step: int) -> float:
         halflife = math.log(self.G_ema_beta, 0.5) * (self.G_ema_warmup_steps + 1) / (step + 1)
         return min(0.5 ** halflife, self.G_ema_beta)
+
+    def update_lrates(self, step: int) -> None:
+        """Linear learning-rate warm-up of both optimizers (reference video_gan_sres.py:140-146)."""
+        self.G_opt.lr = self.G_lrate * min((step + 1) / (self.G_warmup_steps + 1), 1.0)
+        self.D_opt.lr = self.D_lrate * min((step + 1) / (self.D_warmup_steps + 1), 1.0)
 
     def update_G(self, lr_video: torch.Tensor, ema_step: Optional[int] = None) -> None:
         """`ema_step`: fold this iteration's generator-EMA update of the parameters into the optimizer pass."""
@@ -237,6 +244,7 @@ class SuperResTrainer:
 
     def train_step(self, step: int, lr_video: torch.Tensor, hr_video: torch.Tensor, r1_interval: int = 16, ada_interval: int = 4) -> None:
         """One iteration of the reference loop (train_sres.py:241-264) on one (lr with context, hr) batch."""
+        self.update_lrates(step)
         self.update_G(lr_video, ema_step=step)
         self.update_D(lr_video, lr_video, hr_video)
         if r1_interval > 0 and step % r1_interval == 0:

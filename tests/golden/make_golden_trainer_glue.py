@@ -78,5 +78,19 @@ for step in steps:
     betas.append(1.0 - w)
 out['ema_steps'] = np.asarray(steps, dtype=np.int64)
 out['ema_betas'] = np.asarray(betas, dtype=np.float64)
+# learning-rate warm-up (video_gan_lres.py:89-96) on stand-in optimizers
+class _Opt:
+    def __init__(self):
+        self.param_groups = [dict(lr=None)]
+
+
+lr_rows = []
+for step in (0, 1, 49, 50, 51, 1000):
+    gan = object.__new__(cls)
+    gan.G_lrate, gan.D_lrate, gan.G_warmup_steps, gan.D_warmup_steps = 0.003, 0.002, 50, 0
+    gan.G_opt, gan.D_opt = _Opt(), _Opt()
+    cls.update_lrates(gan, step)
+    lr_rows.append((step, gan.G_opt.param_groups[0]['lr'], gan.D_opt.param_groups[0]['lr']))
+out['lrate_rows'] = np.asarray(lr_rows, dtype=np.float64)
 np.savez_compressed(os.path.join(HERE, 'trainer_glue.npz'), **out)
 print({k: (v.shape if v.ndim else str(v)) for k, v in out.items()})

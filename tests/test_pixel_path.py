@@ -304,3 +304,20 @@ def test_generator_ema_schedule_matches_the_reference_cpu():
         tr.G_ema_beta, tr.G_ema_warmup_steps = 0.99985, 25000
         for step, beta in zip(g['ema_steps'], g['ema_betas']):
             assert abs(cls._ema_beta(tr, int(step)) - float(beta)) < 1e-12, (cls.__name__, int(step))
+
+
+def test_learning_rate_warmup_matches_the_reference_cpu():
+    """update_lrates of both trainers against the reference's (video_gan_lres.py:89-96, on stand-in optimizers: the golden rows)."""
+    from conftest import load_golden
+    from lvg.train_lres import LowResTrainer
+    from lvg.train_sres import SuperResTrainer
+
+    class Opt:
+        lr = None
+    for cls in (LowResTrainer, SuperResTrainer):
+        tr = object.__new__(cls)
+        tr.G_lrate, tr.D_lrate, tr.G_warmup_steps, tr.D_warmup_steps = 0.003, 0.002, 50, 0
+        tr.G_opt, tr.D_opt = Opt(), Opt()
+        for step, g_lr, d_lr in load_golden('trainer_glue')['lrate_rows']:
+            cls.update_lrates(tr, int(step))
+            assert tr.G_opt.lr == g_lr and tr.D_opt.lr == d_lr, (cls.__name__, step)
