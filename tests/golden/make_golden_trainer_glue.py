@@ -92,5 +92,38 @@ for step in (0, 1, 49, 50, 51, 1000):
     cls.update_lrates(gan, step)
     lr_rows.append((step, gan.G_opt.param_groups[0]['lr'], gan.D_opt.param_groups[0]['lr']))
 out['lrate_rows'] = np.asarray(lr_rows, dtype=np.float64)
+# the step body itself (video_gan_lres.py:100-203): the reference's update_G / update_D / update_r1 / update_G_ema on the stand-in networks of
+# tests/helpers/stub_nets.py (a one-rank gloo group serves utils.sync_grads), every random draw from the seeded default generator
+sys.path.insert(0, os.path.dirname(HERE))
+from helpers.stub_nets import StubG, StubD  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+if not dist.is_initialized():
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29731', rank=0, world_size=1)
+SEQ, BATCH = 8, 4
+gan = object.__new__(cls)
+gan.seq_length, gan.height, gan.width, gan.channels = SEQ, 6, 8, 3
+gan.G_grad_accum, gan.D_grad_accum, gan.G_random_temp_translate, gan.G_magnitude_ema_beta = 2, 2, True, 0.999
+gan.G_ema_beta, gan.G_ema_warmup_steps = 0.99985, 25000
+gan.temp_scale_augment, gan.diffaug_policy, gan.r1_gamma = 1.0, 'color,translation,cutout', 10.0
+gan.G, gan.G_ema, gan.D = StubG(), StubG(), StubD(SEQ)
+for net in (gan.G, gan.G_ema, gan.D):
+    net.requires_grad_(False)
+gan.G_opt = torch.optim.Adam(gan.G.parameters(), lr=0.003, betas=(0.0, 0.99))
+gan.D_opt = torch.optim.Adam(gan.D.parameters(), lr=0.002, betas=(0.0, 0.99))
+real = torch.rand(BATCH, 3, SEQ, 6, 8, generator=torch.Generator().manual_seed(9)) * 2 - 1
+torch.manual_seed(33)
+for step in (0, 1):                                  # the loop of train_lres.py:216-230 with r1_interval = 2: R1 on step 0
+    cls.update_G(gan, BATCH)
+    cls.update_D(gan, real)
+    if step % 2 == 0:
+        cls.update_r1(gan, real, gain=2)
+    cls.update_G_ema(gan, step)
+for net_name in ('G', 'D', 'G_ema'):
+    for n, t in list(getattr(gan, net_name).named_parameters()) + list(getattr(gan, net_name).named_buffers()):
+        out[f'step_{net_name}_{n}'] = t.detach().numpy().astype(np.float64)
+out['step_next_rand'] = torch.rand(3).numpy()
+out['step_spec'] = np.asarray(repr(dict(seq_length=SEQ, batch=BATCH, real_seed=9, seed=33, steps=2, r1_interval=2)))
+dist.destroy_process_group()
 np.savez_compressed(os.path.join(HERE, 'trainer_glue.npz'), **out)
 print({k: (v.shape if v.ndim else str(v)) for k, v in out.items()})

@@ -321,3 +321,46 @@ def test_learning_rate_warmup_matches_the_reference_cpu():
         for step, g_lr, d_lr in load_golden('trainer_glue')['lrate_rows']:
             cls.update_lrates(tr, int(step))
             assert tr.G_opt.lr == g_lr and tr.D_opt.lr == d_lr, (cls.__name__, step)
+
+
+def test_step_body_matches_the_reference_trainer_on_stand_in_networks_cpu():
+    """LowResTrainer.update_G / update_D / update_r1 / update_G_ema against the REFERENCE's LowResVideoGAN methods (video_gan_lres.py:100-214),
+    both driving the stand-in networks of tests/helpers/stub_nets.py for two iterations of the loop of train_lres.py:216-230 (R1 on the
+    first) from the same seed: micro-batch accumulation and gains, the random crop of the generated clips, DiffAugment, the temporal
+    stretch, the three losses, gradient exchange semantics (mean, gain, nan_to_num), Adam with beta1 = 0, the generator EMA of parameters
+    and buffers, the running magnitude -- and the ORDER and NUMBER of every random draw (the networks draw from the same generator).
+    Fixture: tests/golden/make_golden_trainer_glue.py ran the reference's code on CPU."""
+    from conftest import load_golden
+    from helpers.stub_nets import StubG, StubD
+    from lvg import ddp
+    from lvg.optim import FlatAdam
+    from lvg.train_lres import LowResTrainer
+    g = load_golden('trainer_glue')
+    spec = g['step_spec']
+    seq, batch = spec['seq_length'], spec['batch']
+    tr = object.__new__(LowResTrainer)
+    tr.seq_length, tr.height, tr.width, tr.device, tr.dtype = seq, 6, 8, torch.device('cpu'), torch.float32
+    tr.G_grad_accum, tr.D_grad_accum, tr.G_random_temp_translate, tr.G_magnitude_ema_beta = 2, 2, True, 0.999
+    tr.G_ema_beta, tr.G_ema_warmup_steps = 0.99985, 25000
+    tr.temp_scale_augment, tr.diffaug_policy, tr.r1_gamma = 1.0, 'color,translation,cutout', 10.0
+    tr.G_lrate, tr.D_lrate, tr.G_warmup_steps, tr.D_warmup_steps = 0.003, 0.002, 0, 0
+    tr.use_graphs, tr._graphs = False, {}
+    tr.G, tr.G_ema, tr.D = StubG(), StubG(), StubD(seq)
+    for net in (tr.G, tr.G_ema, tr.D):
+        net.requires_grad_(False)
+    tr.G_opt = FlatAdam(tr.G.parameters(), lr=0.003, betas=(0.0, 0.99), ema_params=tr.G_ema.parameters())
+    tr.D_opt = FlatAdam(tr.D.parameters(), lr=0.002, betas=(0.0, 0.99))
+    tr.G_sync = ddp.FlatGradSync(tr.G.parameters(), overlap=False)
+    tr.D_sync = ddp.FlatGradSync(tr.D.parameters(), overlap=False)
+    real = torch.rand(batch, 3, seq, 6, 8, generator=torch.Generator().manual_seed(spec['real_seed'])) * 2 - 1
+    torch.manual_seed(spec['seed'])
+    for step in range(spec['steps']):
+        tr.train_step(step, real, r1_interval=spec['r1_interval'])
+    after = torch.rand(3).numpy()
+    assert np.array_equal(after, g['step_next_rand'])                    # the same number of draws from the shared generator
+    for net_name in ('G', 'D', 'G_ema'):
+        net = getattr(tr, net_name)
+        for n, t in list(net.named_parameters()) + list(net.named_buffers()):
+            want = g[f'step_{net_name}_{n}']
+            got = t.detach().double().numpy()
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (net_name, n, float(np.abs(got - want).max()))
