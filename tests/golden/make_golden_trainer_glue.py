@@ -124,6 +124,56 @@ for net_name in ('G', 'D', 'G_ema'):
         out[f'step_{net_name}_{n}'] = t.detach().numpy().astype(np.float64)
 out['step_next_rand'] = torch.rand(3).numpy()
 out['step_spec'] = np.asarray(repr(dict(seq_length=SEQ, batch=BATCH, real_seed=9, seed=33, steps=2, r1_interval=2)))
+
+# the super-resolution step body (video_gan_sres.py:150-276): update_G / update_D / update_r1 / update_ada / update_G_ema of the reference's
+# SuperResVideoGAN with the REFERENCE's AugmentPipe (discriminator-side ADA at p = 0.3 adapted every 2 steps, conditioning-side jitter) on the
+# stand-in networks, the loop of train_sres.py:241-264 for three iterations (R1 on steps 0 and 2, ADA on steps 0 and 2)
+from helpers.stub_nets import StubSresG, StubSresD  # noqa: E402
+from helpers.ada_cfg import TRAIN_SRES_KW  # noqa: E402
+video_gan_sres = importlib.import_module('model.video_gan_sres')
+assert os.path.realpath(video_gan_sres.__file__).startswith(os.path.realpath(REF))
+scls = video_gan_sres.SuperResVideoGAN
+training_stats = importlib.import_module('torch_utils.training_stats')
+importlib.import_module('torch_utils.ops.conv2d_gradfix').enabled = True          # as train_sres.py:81-82: R1 differentiates twice through
+importlib.import_module('torch_utils.ops.grid_sample_gradfix').enabled = True     # the resampling convolutions and ADA's grid_sample
+SSEQ, CTX, SB = 2, 1, 4
+sg = object.__new__(scls)
+sg.seq_length, sg.temporal_context, sg.context_seq_length, sg.channels = SSEQ, CTX, SSEQ + 2 * CTX, 3
+sg.lr_height, sg.lr_width, sg.hr_height, sg.hr_width = 9, 16, 36, 64
+sg.G_grad_accum, sg.D_grad_accum, sg.G_magnitude_ema_beta = 2, 2, 0.999
+sg.G_ema_beta, sg.G_ema_warmup_steps, sg.r1_gamma, sg.lr_cond_prob = 0.99985, 25000, 1.0, 0.5
+sg.augment_p_max, sg.augment_p_update_rate, sg.augment_real_sign_target = 0.5, 0.01, 0.6
+sg.G, sg.G_ema, sg.D = StubSresG(CTX), StubSresG(CTX), StubSresD(SSEQ)
+for net in (sg.G, sg.G_ema, sg.D):
+    net.requires_grad_(False)
+sg.G_opt = torch.optim.Adam(sg.G.parameters(), lr=0.003, betas=(0.0, 0.99))
+sg.D_opt = torch.optim.Adam(sg.D.parameters(), lr=0.002, betas=(0.0, 0.99))
+sg.augment = video_gan_sres.AugmentPipe(**TRAIN_SRES_KW).requires_grad_(False).train()
+sg.augment.p.fill_(0.3)
+sg.real_sign_collector = training_stats.Collector(regex='loss/D_sign_real')
+k = 8.0
+sg.in_augment = video_gan_sres.AugmentPipe(scale=1, scale_std=0.01 * k, rotate=1, rotate_max=0.002 * k, aniso=1, aniso_std=0.01 * k,
+                                           xfrac=1, xfrac_std=0.002 * k, noise=1, noise_std=0.01 * k).requires_grad_(False).train()
+sg.in_augment.p.fill_(0.5)
+gen = torch.Generator().manual_seed(13)
+lr = torch.rand(SB, 3, SSEQ + 2 * CTX, 9, 16, generator=gen) * 2 - 1
+hr = torch.rand(SB, 3, SSEQ, 36, 64, generator=gen) * 2 - 1
+torch.manual_seed(44)
+for step in range(3):
+    scls.update_G(sg, lr)
+    scls.update_D(sg, lr, lr, hr)
+    if step % 2 == 0:
+        scls.update_r1(sg, scls.crop_to_seq_length(sg, lr), hr, gain=2)
+    if step % 2 == 0:
+        scls.update_ada(sg, gain=2)
+    scls.update_G_ema(sg, step)
+for net_name in ('G', 'D', 'G_ema'):
+    for n, t in list(getattr(sg, net_name).named_parameters()) + list(getattr(sg, net_name).named_buffers()):
+        out[f'sres_{net_name}_{n}'] = t.detach().numpy().astype(np.float64)
+out['sres_augment_p'] = np.asarray(float(sg.augment.p))
+out['sres_next_rand'] = torch.rand(3).numpy()
+out['sres_spec'] = np.asarray(repr(dict(seq_length=SSEQ, temporal_context=CTX, batch=SB, data_seed=13, seed=44, steps=3, r1_interval=2, ada_interval=2,
+                                        augment_p_init=0.3, augment_p_update_rate=0.01, lr_cond_prob=0.5)))
 dist.destroy_process_group()
 np.savez_compressed(os.path.join(HERE, 'trainer_glue.npz'), **out)
 print({k: (v.shape if v.ndim else str(v)) for k, v in out.items()})

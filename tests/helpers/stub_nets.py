@@ -39,3 +39,45 @@ class StubD(nn.Module):
     def forward(self, video: torch.Tensor, **_unused) -> torch.Tensor:
         x = F.softplus(F.conv3d(video, self.conv, self.bias, padding=1))
         return torch.einsum('ncthw,ct->n', x, self.head).unsqueeze(1) / (x.size(3) * x.size(4))
+
+
+class StubSresG(nn.Module):
+    """Super-resolution stand-in: lr clip with temporal context [N, 3, T + 2c, h, w] -> hr clip [N, 3, T, 4h, 4w]; one latent per call from
+    the default generator."""
+
+    def __init__(self, temporal_context: int = 1, seed: int = 3):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.temporal_context = temporal_context
+        self.mix = nn.Parameter(torch.randn(3, 3, 2 * temporal_context + 1, generator=g) * 0.4)
+        self.style = nn.Parameter(torch.randn(3, 4, generator=g) * 0.3)
+        self.register_buffer('magnitude_ema', torch.ones([]))
+
+    def forward(self, lr_video: torch.Tensor, magnitude_ema_beta: float = 1.0, **_unused) -> torch.Tensor:
+        z = torch.randn(lr_video.size(0), 4, device=lr_video.device)
+        x = F.conv3d(lr_video, self.mix[:, :, :, None, None])                        # 'valid' in time: consumes the context
+        x = x * (1 + torch.tanh(z @ self.style.t()))[:, :, None, None, None]
+        if magnitude_ema_beta < 1:
+            with torch.no_grad():
+                self.magnitude_ema.copy_(x.square().mean().lerp(self.magnitude_ema, magnitude_ema_beta))
+        n, c, t, h, w = x.shape
+        up = F.interpolate(x.reshape(n, c * t, h, w), scale_factor=4, mode='bilinear', align_corners=False)
+        return torch.tanh(up.reshape(n, c, t, 4 * h, 4 * w))
+
+
+class StubSresD(nn.Module):
+    def __init__(self, seq_length: int, seed: int = 4):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.conv = nn.Parameter(torch.randn(4, 6, 1, 3, 3, generator=g) * 0.2)
+        self.bias = nn.Parameter(torch.randn(4, generator=g) * 0.1)
+        self.head = nn.Parameter(torch.randn(4, seq_length, generator=g) * 0.3)
+
+    def upsample(self, lr_video: torch.Tensor) -> torch.Tensor:
+        n, c, t, h, w = lr_video.shape
+        up = F.interpolate(lr_video.reshape(n, c * t, h, w), scale_factor=4, mode='bilinear', align_corners=False)
+        return up.reshape(n, c, t, 4 * h, 4 * w)
+
+    def forward(self, lr_video: torch.Tensor, hr_video: torch.Tensor, **_unused) -> torch.Tensor:
+        x = F.softplus(F.conv3d(torch.cat((lr_video, hr_video), dim=1), self.conv, self.bias, padding=(0, 1, 1)))
+        return torch.einsum('ncthw,ct->n', x, self.head).unsqueeze(1) / (x.size(3) * x.size(4))

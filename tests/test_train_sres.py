@@ -153,3 +153,61 @@ def test_graph_mode_trains_like_eager_mode_gpu():
 def test_graph_mode_is_ignored_without_a_gpu_cpu():
     tr = SuperResTrainer(device='cpu', compute_dtype=torch.float32, use_graphs=True, **SMALL)
     assert tr.use_graphs is False
+
+
+def test_step_body_matches_the_reference_trainer_on_stand_in_networks_cpu():
+    """SuperResTrainer.update_G / update_D / update_r1 / update_ada / update_G_ema against the REFERENCE's SuperResVideoGAN methods
+    (video_gan_sres.py:150-276) driving the stand-in networks of tests/helpers/stub_nets.py through three iterations of the loop of
+    train_sres.py:241-264 (R1 and the ADA update on the first and third) from the same seed -- the reference side with the reference's
+    AugmentPipe and its statistics collector, this side with lvg.ada_augment and the on-device sign sums: conditioning jitter on whole
+    batches, micro-batch accumulation and gains, one ADA transform for the (upsampled lr, hr) pair, conditioning dropout, the three losses,
+    gradient exchange semantics, Adam, the ADA probability control, the generator EMA -- and the order and number of every random draw.
+    Fixture: tests/golden/make_golden_trainer_glue.py."""
+    import numpy as np
+    from conftest import load_golden
+    from helpers.stub_nets import StubSresG, StubSresD
+    from lvg import ddp
+    from lvg.ada_augment import AugmentPipe
+    from lvg.optim import FlatAdam
+    g = load_golden('trainer_glue')
+    spec = g['sres_spec']
+    seq, ctx, batch = spec['seq_length'], spec['temporal_context'], spec['batch']
+    tr = object.__new__(SuperResTrainer)
+    tr.seq_length, tr.temporal_context, tr.context_seq_length, tr.channels = seq, ctx, seq + 2 * ctx, 3
+    tr.lr_size, tr.hr_size, tr.device = (9, 16), (36, 64), torch.device('cpu')
+    tr.G_grad_accum, tr.D_grad_accum, tr.G_magnitude_ema_beta = 2, 2, 0.999
+    tr.G_ema_beta, tr.G_ema_warmup_steps, tr.r1_gamma, tr.lr_cond_prob = 0.99985, 25000, 1.0, spec['lr_cond_prob']
+    tr.augment_p_max, tr.augment_p_update_rate, tr.augment_real_sign_target = 0.5, spec['augment_p_update_rate'], 0.6
+    tr.G_lrate, tr.D_lrate, tr.G_warmup_steps, tr.D_warmup_steps = 0.003, 0.002, 0, 0
+    tr.use_graphs, tr._static = False, {}
+    tr.G, tr.G_ema, tr.D = StubSresG(ctx), StubSresG(ctx), StubSresD(seq)
+    for net in (tr.G, tr.G_ema, tr.D):
+        net.requires_grad_(False)
+    tr.G_opt = FlatAdam(tr.G.parameters(), lr=0.003, betas=(0.0, 0.99), ema_params=tr.G_ema.parameters())
+    tr.D_opt = FlatAdam(tr.D.parameters(), lr=0.002, betas=(0.0, 0.99))
+    tr.G_sync = ddp.FlatGradSync(tr.G.parameters(), overlap=False)
+    tr.D_sync = ddp.FlatGradSync(tr.D.parameters(), overlap=False)
+    tr.augment = AugmentPipe(**TRAIN_SRES_KW).requires_grad_(False).train()
+    tr.augment.p.fill_(spec['augment_p_init'])
+    tr._real_sign_sum = torch.zeros(2)
+    k = 8.0
+    tr.in_augment = AugmentPipe(scale=1, scale_std=0.01 * k, rotate=1, rotate_max=0.002 * k, aniso=1, aniso_std=0.01 * k,
+                                xfrac=1, xfrac_std=0.002 * k, noise=1, noise_std=0.01 * k).requires_grad_(False).train()
+    tr.in_augment.p.fill_(0.5)
+    gen = torch.Generator().manual_seed(spec['data_seed'])
+    lr = torch.rand(batch, 3, seq + 2 * ctx, 9, 16, generator=gen) * 2 - 1
+    hr = torch.rand(batch, 3, seq, 36, 64, generator=gen) * 2 - 1
+    from torch_utils.ops import conv2d_gradfix, grid_sample_gradfix
+    conv2d_gradfix.enabled = grid_sample_gradfix.enabled = True
+    torch.manual_seed(spec['seed'])
+    for step in range(spec['steps']):
+        tr.train_step(step, lr, hr, r1_interval=spec['r1_interval'], ada_interval=spec['ada_interval'])
+    after = torch.rand(3).numpy()
+    assert np.array_equal(after, g['sres_next_rand'])                    # the same number of draws from the shared generator
+    assert abs(float(tr.augment.p) - float(g['sres_augment_p'])) < 1e-7
+    for net_name in ('G', 'D', 'G_ema'):
+        net = getattr(tr, net_name)
+        for n, t in list(net.named_parameters()) + list(net.named_buffers()):
+            want = g[f'sres_{net_name}_{n}']
+            got = t.detach().double().numpy()
+            assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (net_name, n, float(np.abs(got - want).max()))
