@@ -65,8 +65,8 @@ def test_graph_mode_trains_like_eager_mode():
     TWO EAGER runs: the library convolutions of the 3 x 4-pixel layers sum split-K partials with atomics, so identical inputs give outputs
     a few bf16 ulps apart and 16-bit gradients that differ by ~10 % of a tensor's maximum from run to run (tools/determinism_ops.py, profiles/r04_determinism_first_op.log);
     the graph run must lie within five times that distance (+ 5 % of the tensor's maximum: one pair of eager runs is a noisy yardstick;
-    a capture that ran a phase twice or not at all is off by the whole gradient) of an eager run -- gradients of the first step, running magnitudes after
-    three steps (one update per update_D: the eager warm-up before the capture is rolled back), one graph per phase and micro-batch shape."""
+    a capture that ran a phase twice or not at all is off by the whole gradient) of an eager run -- gradients and running magnitudes of the first step
+    (one update per update_D: the eager warm-up before the capture is rolled back), two more steps that must stay finite, one graph per phase and micro-batch shape."""
     from lvg.train_lres import LowResTrainer
     kw = dict(seq_length=8, height=36, width=64, device='cuda', compute_dtype=torch.bfloat16, G_grad_accum=2, D_grad_accum=2,
               overlap_grad_sync=False, with_ema=True, temp_scale_augment=1.0, diffaug_policy='')
@@ -88,9 +88,11 @@ def test_graph_mode_trains_like_eager_mode():
         torch.manual_seed(5)
         tr.train_step(step=1, real_video=real, r1_interval=0)
         grads[name] = (tr.G_sync.flat.clone(), tr.D_sync.flat.clone())
+        # (after ONE step: the statistics of the first update_D depend on the initial parameters only; later steps follow trajectories that
+        # Adam with beta1 = 0 -- steps of +-lr by the gradient's sign -- drives apart from run to run)
+        mags[name] = torch.stack([b.float().reshape(()) for n, b in tr.G.named_buffers() if n.endswith('magnitude_ema')])
         for step in (2, 3):
             tr.train_step(step=step, real_video=real, r1_interval=0)
-        mags[name] = torch.stack([b.float().reshape(()) for n, b in tr.G.named_buffers() if n.endswith('magnitude_ema')])
         trainers[name] = tr
     torch.cuda.synchronize()
     for e, e2, g in zip(grads['eager'], grads['eager2'], grads['graph']):
@@ -98,8 +100,8 @@ def test_graph_mode_trains_like_eager_mode():
         noise = float((e - e2).abs().max())
         assert float((e - g).abs().max()) <= 5 * noise + 0.05 * float(e.abs().max()), (float((e - g).abs().max()), noise, float(e.abs().max()))
     moved = float((mags['eager'] - 1).abs().max())
-    assert moved > 1e-4
-    assert float((mags['eager'] - mags['graph']).abs().max()) <= 3 * float((mags['eager'] - mags['eager2']).abs().max()) + 0.1 * moved, (mags['eager'], mags['graph'])
+    assert moved > 1e-4                                                 # one update at beta 0.999 ...
+    assert float((mags['eager'] - mags['graph']).abs().max()) <= 5 * float((mags['eager'] - mags['eager2']).abs().max()) + 0.05 * moved, (mags['eager'], mags['graph'])   # ... not two, not none
     graph = trainers['graph']
     for p in list(graph.G.parameters()) + list(graph.D.parameters()):
         assert torch.isfinite(p).all()
