@@ -81,6 +81,16 @@ def temporal_scale_params(n: int, frames: int, seq_length: int, amount: float):
     return torch.stack(i0s), torch.stack(fracs), torch.stack(valids)
 
 
+def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
+    """A small host tensor of random draws -> `device` without stalling the host: from pageable memory a host-to-device copy blocks until the
+    stream has drained (the trainers issue several per micro-batch); from pinned memory it is asynchronous, and torch's caching host
+    allocator keeps the pinned block alive until the copy has run."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def temporal_scale_apply(video: torch.Tensor, i0: torch.Tensor, frac: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
     """[N, C, T, H, W] -> [N, C, seq_length, H, W]: two gathers along time, one lerp, one mask -- for all samples at once (the reference
     form interpolates, pads, crops and stacks sample by sample: 24 slow launches of a bilinear kernel on a strided view per 8 clips)."""
@@ -100,7 +110,7 @@ def temporal_scale_augment(video: torch.Tensor, seq_length: int, amount: float) 
         return video
     i0, frac, valid = temporal_scale_params(video.size(0), video.size(2), seq_length, amount)
     dev = video.device
-    return temporal_scale_apply(video, i0.to(dev, non_blocking=True), frac.to(dev, non_blocking=True), valid.to(dev, non_blocking=True))
+    return temporal_scale_apply(video, to_device_async(i0, dev), to_device_async(frac, dev), to_device_async(valid, dev))
 
 
 def temporal_scale_augment_reference_form(video: torch.Tensor, seq_length: int, amount: float) -> torch.Tensor:

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from . import ddp
 from .optim import FlatAdam
 from .phase_graphs import PhaseGraphs
-from .augment import crop_time, diff_augment, temporal_scale_apply, temporal_scale_augment, temporal_scale_params
+from .augment import crop_time, diff_augment, temporal_scale_apply, temporal_scale_augment, temporal_scale_params, to_device_async
 from .models import lres as lres_models
 from .models.lres import VideoDiscriminator, VideoGenerator
 
@@ -66,7 +66,7 @@ class LowResTrainer:
         video = self.G(batch, self.seq_length + extra, magnitude_ema_beta=beta, dtype=self.dtype)
         if extra:
             if t0 is None:
-                t0 = self._draw_crop(batch, video.size(2)).to(video.device, non_blocking=True)
+                t0 = to_device_async(self._draw_crop(batch, video.size(2)), video.device)
             video = crop_time(video, t0, self.seq_length)
         return video
 
@@ -97,7 +97,7 @@ class LowResTrainer:
     def _fill_stretch(self, dst, batch: int) -> None:
         if self.temp_scale_augment > 0:
             for d, s in zip(dst, temporal_scale_params(batch, self.seq_length, self.seq_length, self.temp_scale_augment)):
-                d.copy_(s, non_blocking=True)
+                d.copy_(s.pin_memory() if d.is_cuda else s, non_blocking=True)
 
     def _replay(self, key, fn):
         """Run `fn` from its graph (lvg.phase_graphs: eager warm-up rolled back on the gradient buffers and the generator's running
@@ -127,7 +127,7 @@ class LowResTrainer:
                 b = batch // self.G_grad_accum
                 draws = self._static_draws('G', b)
                 if self.G_random_temp_translate:                           # host draws in eager order: crop, then the stretch
-                    draws['t0'].copy_(self._draw_crop(b, self.seq_length + self.G.total_temporal_scale), non_blocking=True)
+                    draws['t0'].copy_(self._draw_crop(b, self.seq_length + self.G.total_temporal_scale).pin_memory(), non_blocking=True)
                 self._fill_stretch(draws['stretch'][0], b)
                 self._replay(('G', b), lambda: F.softplus(-self.run_D(self._gen(b, t0=draws['t0']), stretch=draws['stretch'][0])).mean().backward())
                 continue
@@ -165,7 +165,7 @@ class LowResTrainer:
         st = self._graphs.setdefault(('Dio', n, b), dict(fake=None, fake_in=torch.empty(b, *real_video.shape[1:], dtype=self.dtype, device=self.device),
                                                          real_in=torch.empty(b, *real_video.shape[1:], dtype=real_video.dtype, device=self.device)))
         if self.G_random_temp_translate:
-            gen['t0'].copy_(self._draw_crop(n, self.seq_length + self.G.total_temporal_scale), non_blocking=True)
+            gen['t0'].copy_(self._draw_crop(n, self.seq_length + self.G.total_temporal_scale).pin_memory(), non_blocking=True)
 
         def generate():
             with torch.no_grad():
