@@ -225,10 +225,11 @@ class SuperResTrainer:
         if self.augment is None or self.augment_real_sign_target is None:
             return
         stats = ddp.sharded_all_mean(self._real_sign_sum.clone()) if torch.distributed.is_initialized() else self._real_sign_sum
-        if float(stats[1]) > 0:
-            mean_sign = float(stats[0] / stats[1])
-            step = math.copysign(self.augment_p_update_rate, mean_sign - self.augment_real_sign_target) * gain
-            self.augment.p.add_(step).clamp_(0, self.augment_p_max)
+        # on the device, no host read: step = copysign(rate, mean sign - target) * gain where anything was counted, else 0
+        # (the reference reads the mean back through its statistics collector, video_gan_sres.py:256-262; copysign keeps its sign rule at 0)
+        diff = stats[0] / stats[1].clamp(min=1) - self.augment_real_sign_target
+        step = torch.copysign(torch.full_like(diff, self.augment_p_update_rate * gain), diff) * (stats[1] > 0)
+        self.augment.p.add_(step.to(self.augment.p.dtype)).clamp_(0, self.augment_p_max)
         self._real_sign_sum.zero_()
 
     @torch.no_grad()
