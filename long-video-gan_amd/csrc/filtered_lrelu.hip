@@ -639,7 +639,7 @@ static std::atomic<int> g_flrelu_impl{0};
 
 extern "C" int lvg_filtered_lrelu_set_impl(int impl)
 {
-    if (impl < 0 || impl > 3) return LVG_ERR_INVALID;     // 0 default, 1 fp32-VALU kernel, 2 round-2 MFMA kernel, 3 wave-per-tile MFMA kernel
+    if (impl < 0 || impl > 4) return LVG_ERR_INVALID;     // 0 default, 1 fp32-VALU kernel, 2 round-2 MFMA kernel, 3 wave-per-tile MFMA kernel, 4 row-band MFMA kernel (falls back to 3 for what it does not take)
     return g_flrelu_impl.exchange(impl);
 }
 
@@ -713,10 +713,14 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     static const bool env_wave = []() { const char* e = getenv("LVG_FLRELU_WAVE"); return !(e && e[0] == '0'); }();
     const int impl = g_flrelu_impl.load(std::memory_order_relaxed);
     const bool use_mfma = impl == 0 ? env_mfma : impl >= 2;
-    const bool use_wave = impl == 0 ? env_wave : impl == 3;
+    const bool use_wave = impl == 0 ? env_wave : impl >= 3;
+    // LVG_FLRELU_BAND=1 puts the row-band kernel (round 5, float16) into the default route.
+    static const bool env_band = []() { const char* e = getenv("LVG_FLRELU_BAND"); return e && e[0] == '1'; }();
+    const bool use_band = impl == 0 ? (env_band && env_wave) : impl == 4;
     if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
     {
-        int rc = use_wave ? lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st) : LVG_ERR_UNSUPPORTED;
+        int rc = use_band ? lvg_flrelu_band_launch(p, cfg, sign_mode, dtype, st) : LVG_ERR_UNSUPPORTED;
+        if (rc == LVG_ERR_UNSUPPORTED && use_wave) rc = lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st);
         if (rc == LVG_ERR_UNSUPPORTED) rc = lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);      // (slope > 1: the round-2 kernel)
         if (rc != LVG_ERR_UNSUPPORTED) return rc;      // (planes of 2 GiB and more: the VALU kernel below)
     }

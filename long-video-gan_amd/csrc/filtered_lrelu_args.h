@@ -31,3 +31,6 @@ enum { LVG_FLRELU_CFG_NONE = 0, LVG_FLRELU_CFG_POINTWISE, LVG_FLRELU_CFG_U2D2, L
 int lvg_flrelu_mfma_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
 // filtered_lrelu_wave.hip (round 4: one wave per tile, no workgroup barrier). Same arguments.
 int lvg_flrelu_wave_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
+// filtered_lrelu_band.hip (round 5: one workgroup per plane, rows through an LDS ring by LDS-DMA, streaming vertical stages; float16 only).
+// LVG_ERR_UNSUPPORTED for what it does not take: the caller falls back to the wave kernel. Same arguments.
+int lvg_flrelu_band_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
