@@ -127,9 +127,11 @@ int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t* s,
                        int dtype, void* stream);
 
 /*
- * Which fused kernel serves float16 / bfloat16 tensors: 0 = default (the wave-per-tile MFMA kernel, csrc/filtered_lrelu_wave.hip;
- * LVG_FLRELU_WAVE=0: the round-2 MFMA kernel, csrc/filtered_lrelu_mfma.hip; LVG_FLRELU_MFMA=0: the VALU kernel), 1 = the fp32-VALU
- * kernel (csrc/filtered_lrelu.hip, the only one for float32), 2 = the round-2 MFMA kernel, 3 = the wave-per-tile kernel.
+ * Which fused kernel serves float16 / bfloat16 tensors: 0 = default (float16 planes of two / three column strips: the row-band MFMA
+ * kernel, csrc/filtered_lrelu_band.hip, LVG_FLRELU_BAND=0 switches it off; everything else: the wave-per-tile MFMA kernel,
+ * csrc/filtered_lrelu_wave.hip; LVG_FLRELU_WAVE=0: the round-2 MFMA kernel, csrc/filtered_lrelu_mfma.hip; LVG_FLRELU_MFMA=0: the VALU
+ * kernel), 1 = the fp32-VALU kernel (csrc/filtered_lrelu.hip, the only one for float32), 2 = the round-2 MFMA kernel, 3 = the
+ * wave-per-tile kernel, 4 = the row-band kernel for everything it can take (falls back to 3).
  * Process-wide; returns the previous setting. No reference counterpart: a measurement / bisecting hook for tests and bench.py.
  */
 int lvg_filtered_lrelu_set_impl(int impl);

@@ -714,12 +714,15 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     const int impl = g_flrelu_impl.load(std::memory_order_relaxed);
     const bool use_mfma = impl == 0 ? env_mfma : impl >= 2;
     const bool use_wave = impl == 0 ? env_wave : impl >= 3;
-    // LVG_FLRELU_BAND=1 puts the row-band kernel (round 5, float16) into the default route.
-    static const bool env_band = []() { const char* e = getenv("LVG_FLRELU_BAND"); return e && e[0] == '1'; }();
-    const bool use_band = impl == 0 ? (env_band && env_wave) : impl == 4;
+    // The row-band kernel (round 5, float16) takes the planes it measured faster on (its launcher decides: planes of two or three
+    // column strips, profiles/r05_band_*.log); LVG_FLRELU_BAND=0 keeps it out of the default route, =2 sends it everything it can take
+    // (A/B measurements). impl 4 (lvg_filtered_lrelu_set_impl) = everything it can take.
+    static const int env_band = []() { const char* e = getenv("LVG_FLRELU_BAND"); return e ? atoi(e) : 1; }();
+    const bool use_band = impl == 0 ? (env_band > 0 && env_wave) : impl == 4;
+    const bool band_all = impl == 4 || env_band >= 2;
     if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
     {
-        int rc = use_band ? lvg_flrelu_band_launch(p, cfg, sign_mode, dtype, st) : LVG_ERR_UNSUPPORTED;
+        int rc = use_band ? lvg_flrelu_band_launch(p, cfg, sign_mode, dtype, band_all ? 1 : 0, st) : LVG_ERR_UNSUPPORTED;
         if (rc == LVG_ERR_UNSUPPORTED && use_wave) rc = lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st);
         if (rc == LVG_ERR_UNSUPPORTED) rc = lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);      // (slope > 1: the round-2 kernel)
         if (rc != LVG_ERR_UNSUPPORTED) return rc;      // (planes of 2 GiB and more: the VALU kernel below)

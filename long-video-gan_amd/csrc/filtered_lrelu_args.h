@@ -33,4 +33,5 @@ int lvg_flrelu_mfma_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStrea
 int lvg_flrelu_wave_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
 // filtered_lrelu_band.hip (round 5: one workgroup per plane, rows through an LDS ring by LDS-DMA, streaming vertical stages; float16 only).
 // LVG_ERR_UNSUPPORTED for what it does not take: the caller falls back to the wave kernel. Same arguments.
-int lvg_flrelu_band_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
+// `all` = 0: only the shapes it measured faster on than the wave kernel (else LVG_ERR_UNSUPPORTED); 1: everything it can take.
+int lvg_flrelu_band_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all, hipStream_t stream);

@@ -145,8 +145,10 @@ def _check_backward(oracle, x, b, y, fu, fd, up, down, pad, gain, slope, dtype, 
         sh, swb, sw_active = oracle.sign_shape(yh, yw, down, nd, nd)
         assert s_gpu.shape == mask_ref.shape == (x.shape[0], x.shape[1], sh, swb)
         diff = _mask_pixels(s_gpu, sw_active) != _mask_pixels(mask_ref, sw_active)
-        # a pre-activation within float32 rounding of 0 may land on the other side in float64
-        assert diff.mean() <= 2e-4, (name, float(diff.mean()))
+        # a pre-activation within rounding of 0 (or of the clamp) may land on the other side in float64. float32 kernels round at
+        # 2^-24: 2e-4 of the pixels at most. The 16-bit MFMA kernels carry T' and U in float16 (2^-11): measured 0.5e-4 .. 2.2e-4 of the
+        # pixels (clamp 2.5 doubles the tie zone; tools/flrelu_check prints the fraction per case), gate at twice the worst
+        assert diff.mean() <= (2e-4 if dtype == torch.float32 else 4.5e-4), (name, float(diff.mean()))
         assert not s_gpu[..., (sw_active + 3) >> 2:].any(), 'padding bytes of the mask must be 0'
 
 
@@ -207,3 +209,61 @@ def test_bias_gradient_plane_sums(shape, dtype):
     eps = {torch.float32: 2.0 ** -23, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
     scale = dx.double().abs().sum([0, 2, 3])
     assert ((got.double() - want).abs() <= eps * want.abs() + 2.0 ** -22 * scale + 1e-30).all()
+
+
+@pytest.fixture
+def band_kernel_everywhere():
+    """Route every float16 call the row-band kernel can take to it (lvg_filtered_lrelu_set_impl(4); what it cannot take falls back to the
+    wave kernel), instead of only the plane widths it is the default for."""
+    from torch_utils.ops import _hip
+    prev = _hip.lib().lvg_filtered_lrelu_set_impl(4)
+    assert prev >= 0
+    yield
+    _hip.lib().lvg_filtered_lrelu_set_impl(prev)
+
+
+# Geometry the row-band kernel (csrc/filtered_lrelu_band.hip) has code paths for: one to six column strips, planes shorter than a
+# block of 32 output rows / exactly one block / two blocks finishing in the same step, more planes than workgroups are resident
+# (several planes per workgroup: LDS ring, bias rows and mask prefetch cross plane boundaries), the up-4 and down-4 chunk patterns,
+# negative padding (crop), wide margins of the backward passes.
+BAND = [
+    ('one_strip', [3, 7, 40, 54], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('two_strips_u4', [2, 3, 40, 54], 4, 2, 24, 12, [-6, -9, -6, -9]),
+    ('three_strips', [1, 4, 94, 150], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('five_strips_crop', [1, 3, 166, 278], 2, 2, 12, 12, [-11, -12, -11, -12]),
+    ('five_strips_u4', [1, 3, 94, 150], 4, 2, 24, 12, [-6, -9, -6, -9]),
+    ('exactly_32_rows', [1, 3, 34, 62], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('37_rows', [1, 3, 39, 118], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('tall', [1, 2, 300, 20], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('many_planes', [16, 512, 18, 22], 2, 2, 12, 12, [9, 8, 9, 8]),
+]
+
+
+@pytest.mark.parametrize('clamp', [2.5, 256.0], ids=['clamp2.5', 'clamp256'])
+@pytest.mark.parametrize('case', BAND, ids=[s[0] for s in BAND])
+def test_band_kernel_forward_backward_vs_oracle(case, clamp, oracle, band_kernel_everywhere):
+    """The row-band kernel on everything it can take, float16: forward with the mask against the float64 oracle, the mask against the
+    oracle's, the backward pass (sign-READ mode, filter roles swapped: for up 4 / down 2 layers that is the up 2 / down 4 instance)
+    against the oracle run on the mask the GPU wrote. clamp 2.5 exercises the clamp and its mask bit, clamp 256 the proof that skips them."""
+    import scipy.signal
+    name, shape, up, down, nu, nd, pad = case
+    dtype = torch.float16
+    fu = scipy.signal.firwin(numtaps=nu, cutoff=0.9 / up, width=0.6 / up, fs=2.0).astype(np.float32)
+    fd = scipy.signal.firwin(numtaps=nd, cutoff=0.9 / down, width=0.6 / down, fs=2.0).astype(np.float32)
+    rs = np.random.RandomState(21)
+    x = dev(rs.randn(*shape), dtype, True)
+    b = dev(rs.randn(shape[1]) * 0.3, dtype, True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        y = filtered_lrelu.filtered_lrelu(x, torch.tensor(fu, device=DEV), torch.tensor(fd, device=DEV), b,
+                                          up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=clamp)
+        ref, so = oracle.filtered_lrelu(host(x), fu, fd, host(b), up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2,
+                                        clamp=clamp, write_signs=True)
+        assert tuple(y.shape) == ref.shape and y.dtype == dtype
+        np.testing.assert_allclose(host(y), ref, err_msg=name, **TOL[dtype])
+        _check_backward(oracle, x, b, y, fu, fd, up, down, pad, np.sqrt(2), 0.2, dtype, name, mask_ref=so)
+        # no-mask forward (inference): same values as the mask-writing forward
+        with torch.no_grad():
+            y2 = filtered_lrelu.filtered_lrelu(x, torch.tensor(fu, device=DEV), torch.tensor(fd, device=DEV), b,
+                                               up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=clamp)
+        assert torch.equal(y2, y.detach())

@@ -100,7 +100,8 @@ static int g_impl_mask = 0xe;     // bit i: run impl i (FLRELU_IMPLS=3,2,1)
 
 static int run_check(const Case& cs, int dtype)
 {
-    const float gain = sqrtf(2.0f), slope = 0.2f, clamp = 2.5f;
+    static const float clamp_env = getenv("FLRELU_CLAMP") ? (float)atof(getenv("FLRELU_CLAMP")) : 2.5f;      // (256: no pixel reaches the clamp, the kernels' no-clamp paths run)
+    const float gain = sqrtf(2.0f), slope = 0.2f, clamp = clamp_env;
     const int n = cs.n, c = cs.c, xh = cs.h, xw = cs.w, up = cs.up, down = cs.down, nu = cs.nu, nd = cs.nd;
     std::vector<float> fu = lowpass(nu, 0.9 / up), fd = lowpass(nd, 0.9 / down);
     const int cw = xw * up + cs.px0 + cs.px1 - (nu - 1), chh = xh * up + cs.py0 + cs.py1 - (nu - 1);
@@ -338,6 +339,18 @@ int main(int argc, char** argv)
         for (const Case& cs : big)
             for (int mode = 0; mode <= 2; mode++) run_time(cs, 1, mode);
         run_time(big[0], 2, 1);
+    }
+    if (what == "timesmall")
+    {
+        const Case small[] = {
+            {"L4", 8, 512, 40, 54, 2, 2, 12, 12, 9, 8, 9, 8},
+            {"L6", 8, 512, 58, 86, 2, 2, 12, 12, 9, 8, 9, 8},
+            {"L5", 8, 512, 40, 54, 4, 2, 24, 12, -6, -9, -6, -9},
+            {"L7", 8, 512, 58, 86, 4, 2, 24, 12, -6, -9, -6, -9},
+            {"L9", 8, 362, 94, 150, 2, 2, 12, 12, 9, 8, 9, 8},
+        };
+        for (const Case& cs : small)
+            for (int mode = 0; mode <= 2; mode++) run_time(cs, 1, mode);
     }
     if (what == "one")      // one <L8|L10|L13> <dtype 1|2> <mode 0|1|2> <impl 1|2> [reps]: for rocprofv3
     {
