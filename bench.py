@@ -520,13 +520,16 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
         # of the step is paid once instead of twice: VERDICT r03 item 4b)
         accum = max(1, B // 8)
     torch.manual_seed(0)
-    # one rank: nothing to overlap, so the compute of update_G / update_D is replayed from hipGraphs (LowResTrainer(use_graphs=True); the host
-    # draws of the augmentations go through static buffers). More ranks: eager launches with the bucketed exchange overlapped with backward.
-    graphs = world == 1 and os.environ.get('LVG_TRAIN_GRAPHS', '1') != '0'
+    # At every world size the compute of update_G / update_D is replayed from hipGraphs (LowResTrainer(use_graphs=True); the host draws of
+    # the augmentations go through static buffers); the collectives stay outside the captured phases: the gradient exchange follows a
+    # phase's replays, the generator's running statistics are exchanged in one all-reduce after the fake-generation replay
+    # (lvg.phase_graphs). LVG_TRAIN_GRAPHS=0: eager launches with the bucketed exchange overlapped with backward (A/B).
+    graphs = os.environ.get('LVG_TRAIN_GRAPHS', '1') != '0'
     tr = LowResTrainer(seq_length=frames_per_clip, device=dev, compute_dtype=dtype, G_grad_accum=accum, D_grad_accum=accum,
                        overlap_grad_sync=True, with_ema=True, use_graphs=graphs)
     torch.manual_seed(1 + rank)
     real = torch.rand(B, 3, frames_per_clip, 36, 64, device=dev) * 2 - 1
+    tr.G_sync.exposed_events, tr.D_sync.exposed_events = [], []      # device time of the part of the exchange nothing hides (N > 1)
 
     def barrier():
         if world > 1:
@@ -536,11 +539,13 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
     for _ in range(warmup):
         tr.train_step(step_no, real); step_no += 1
     barrier()
+    tr.G_sync.exposed_events.clear(); tr.D_sync.exposed_events.clear()
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.train_step(step_no, real); step_no += 1
     barrier()
     elapsed = time.perf_counter() - t0
+    exposed_ms = sum(a.elapsed_time(b) for a, b in tr.G_sync.exposed_events + tr.D_sync.exposed_events) / steps
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -567,7 +572,9 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
         'config': {'workload': f'train_lres.py step body, total batch {total_batch} ({B}/GPU, {accum} micro-batches), G at {frames_per_clip + 32} frames cropped to {frames_per_clip}, '
                                f'DiffAugment + temporal-scale augment, R1 steps in the timed region: {r1_steps}', 'global_batch': total_batch,
                    'frames_per_clip': frames_per_clip, 'parallelism': f'dp{world}',
-                   'grad_sync': 'FlatGradSync, one rank: no exchange' if world == 1 else 'FlatGradSync(overlap=True), 128 MB buckets'}}
+                   'grad_sync': 'FlatGradSync, one rank: no exchange' if world == 1 else
+                                ('FlatGradSync, 128 MB buckets, exchange after the replayed phases (R1: overlapped with its backward pass)' if graphs else 'FlatGradSync(overlap=True), 128 MB buckets')},
+        'grad_sync': {'exposed_ms_per_step': round(exposed_ms, 3), 'note': 'device time of the all-reduces / waits of FlatGradSync.finish() per iteration (update_G + update_D [+ R1]); 0 at one rank'}}
 
 
 def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):

@@ -12,6 +12,7 @@ view into it, so there is no pack (torch.cat) and no unpack copy per step; bucke
 gradient of the final micro-batch has been accumulated, overlapping with the rest of backward.
 Same mean / gain / nan_to_num semantics."""
 
+import contextlib
 import math
 from typing import Iterable, List, Optional
 
@@ -22,6 +23,79 @@ import torch.nn as nn
 
 def _world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+# ---------------------------------------------------------------------------------------------
+# Running statistics that are averaged over ranks inside a forward pass (the generators' input-magnitude EMAs, the mapping
+# network's w_avg: reference model/generator_lres.py:298-312, model/generator_sres.py:116-123, 278-286). Each is a collective in
+# the middle of the pass in the reference. Inside a `deferred_stat_sync()` scope a layer instead folds in its LOCAL statistic and
+# records (buffer, local statistic, beta, previous buffer value); ONE all-reduce afterwards (`finish_stat_sync`) redoes every
+# buffer with the mean over ranks -- the reference's arithmetic, bit-identical on every rank. The only difference is that the gain
+# used in THIS pass saw the local statistic: a relative change of (1 - beta) * (local / global - 1) ~ 1e-5, nothing at world size 1.
+# It is what lets a pass be captured into a hipGraph (an RCCL collective inside a capture aborts on this stack): the recorded
+# tensors are static outputs of the graph, the all-reduce runs after the replay (lvg.phase_graphs).
+
+_pending_stats = None       # list of (buffer, local, beta, previous, form) while a deferred scope is open
+
+LERP_TOWARDS = 0            # buffer.lerp_(stat, 1 - beta)        (lres MagnitudeEMA)
+LERP_FROM = 1               # buffer.copy_(stat.lerp(buffer, beta))  (sres w_avg / magnitude_ema)
+
+
+@contextlib.contextmanager
+def deferred_stat_sync():
+    """Scope in which `ema_of_rank_mean` records local statistics instead of all-reducing them. Yields the list of records."""
+    global _pending_stats
+    assert _pending_stats is None, 'deferred_stat_sync scopes do not nest'
+    _pending_stats = []
+    try:
+        yield _pending_stats
+    finally:
+        _pending_stats = None
+
+
+def ema_of_rank_mean(buffer: torch.Tensor, local: torch.Tensor, beta: float, form: int = LERP_TOWARDS) -> None:
+    """buffer <- exponential moving average step towards the mean over ranks of `local` (a detached float32 tensor of buffer's
+    shape), written in the arithmetic form of the reference call site."""
+    stat = local
+    if _world() > 1:
+        if _pending_stats is not None:
+            _pending_stats.append((buffer, local, beta, buffer.clone(), form))
+        else:
+            stat = local.clone()
+            dist.all_reduce(stat)
+            stat = stat / _world()
+    if form == LERP_TOWARDS:
+        buffer.lerp_(stat.to(buffer.dtype), 1.0 - beta)
+    else:
+        buffer.copy_(stat.lerp(buffer, beta))
+
+
+def stack_pending(pending):
+    """(local statistics, previous buffer values) of a deferred scope as two flat vectors (cheap to keep in a captured graph)."""
+    return (torch.cat([l.reshape(-1).float() for _, l, _, _, _ in pending]), torch.cat([p.reshape(-1).float() for _, _, _, p, _ in pending]))
+
+
+def finish_stat_sync(pending, stacked=None) -> None:
+    """One all-reduce for every statistic recorded in a deferred scope, then each buffer is REDONE from its previous value and the
+    mean over ranks, in the form of its call site."""
+    world = _world()
+    if not pending or world <= 1:
+        return
+    local, prev = stack_pending(pending) if stacked is None else stacked
+    glob = local.clone()
+    dist.all_reduce(glob)
+    glob = glob / world
+    sizes = [b.numel() for b, _, _, _, _ in pending]
+    # (weights formed in Python floats and rounded once, like the scalar arguments of the eager calls)
+    w_to = torch.tensor([1.0 - bt for (_, _, bt, _, _), n in zip(pending, sizes) for _ in range(n)], dtype=glob.dtype, device=glob.device)
+    w_from = torch.tensor([bt for (_, _, bt, _, _), n in zip(pending, sizes) for _ in range(n)], dtype=glob.dtype, device=glob.device)
+    towards = torch.lerp(prev, glob, w_to)                # prev.lerp(stat, 1 - beta)
+    frm = torch.lerp(glob, prev, w_from)                  # stat.lerp(prev, beta)
+    o = 0
+    for (buf, _, _, _, form), n in zip(pending, sizes):
+        src = towards if form == LERP_TOWARDS else frm
+        buf.copy_(src[o:o + n].view_as(buf))
+        o += n
 
 
 def sharded_all_mean(tensor: torch.Tensor, shard_size: int = 2 ** 23) -> torch.Tensor:
@@ -93,6 +167,9 @@ class FlatGradSync:
         # zero_grad(set_to_none=True) and sync_grads / Adam skip parameters whose grad is None (utils.py:106);
         # finish() restores exactly that for parameters autograd never touched.
         self._fired = [False] * len(self.params)
+        # measurement hook (bench.py): a list to which finish() appends (start, end) device events around the part of the exchange
+        # that is not hidden behind backward (everything when nothing was armed), or None
+        self.exposed_events = None
         for i, p in enumerate(self.params):
             # hooks can only be registered on tensors that require grad; the trainers keep their networks
             # frozen (requires_grad False) outside the update that trains them, so flip it for the call
@@ -172,6 +249,10 @@ class FlatGradSync:
         With `drop_unused`, parameters that received no gradient since zero() end with grad None (so the
         optimizer leaves their state alone, like the reference's zero_grad(set_to_none=True))."""
         self._adopt_replaced_grads()
+        timed = self.exposed_events is not None and self.flat.is_cuda and _world() > 1
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self._armed:
             # buckets whose hooks never fired (unused parameters) still have to be reduced
             for b in range(len(self.buckets)):
@@ -185,6 +266,9 @@ class FlatGradSync:
             for b in range(len(self.buckets)):
                 s, e, _ = self.buckets[b]
                 dist.all_reduce(self.flat[s:e])
+        if timed:
+            e1.record()
+            self.exposed_events.append((e0, e1))
         scale = (1.0 / _world()) * (1.0 if gain is None else float(gain))
         if scale != 1.0:
             self.flat.mul_(scale)

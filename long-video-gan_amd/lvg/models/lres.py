@@ -28,6 +28,8 @@ import torch.nn.functional as F
 import torch_utils.distributed as dist_utils
 import contextlib
 
+from .. import ddp
+
 from torch_utils.ops import bias_act, conv3d_frames, style_prep, upfirdn2d, weight_prep
 from torch_utils.ops.modconv_epilogue import dual_supported, modconv_epilogue, modconv_epilogue_dual, tap_gather_backward, tap_gather_forward
 
@@ -129,13 +131,11 @@ class MagnitudeEMA(nn.Module):
 
     Across ranks the reference all-reduces the statistic inside every layer's forward
     (model/generator_lres.py:298-312: 21 one-float collectives per generator pass). Inside a
-    `deferred_magnitude_sync()` scope the layer instead folds in its LOCAL mean and records it; one
-    batched all-reduce afterwards (`finish_magnitude_sync`) corrects every buffer to the global-mean
-    update, so buffers end up identical on all ranks and identical to the reference's. The only
-    difference is that the gain used in THIS forward pass saw the local mean: a relative change of
+    `deferred_magnitude_sync()` scope (= lvg.ddp.deferred_stat_sync) the layer instead folds in its LOCAL
+    mean and records it; one batched all-reduce afterwards (`finish_magnitude_sync`) corrects every buffer to
+    the global-mean update, so buffers end up identical on all ranks and identical to the reference's. The
+    only difference is that the gain used in THIS forward pass saw the local mean: a relative change of
     (1 - beta) * (local/global - 1) ~ 1e-5, and nothing at world size 1."""
-
-    pending = None          # list of (module, local mean, beta, previous EMA) while a deferred scope is open
 
     def __init__(self, dist_sync: bool = True):
         super().__init__()
@@ -145,15 +145,10 @@ class MagnitudeEMA(nn.Module):
     def update(self, mean_square: torch.Tensor, beta: float) -> torch.Tensor:
         """Fold a freshly measured mean square (float32 scalar tensor) into the EMA; returns the gain."""
         mag = mean_square.detach()
-        world = dist_utils.get_world_size()
-        if self.dist_sync and world > 1:
-            if MagnitudeEMA.pending is not None:
-                MagnitudeEMA.pending.append((self, mag, beta, self.magnitude_ema.clone()))
-            else:
-                mag = mag.clone()
-                torch.distributed.all_reduce(mag)
-                mag = mag / world
-        self.magnitude_ema.lerp_(mag.to(self.magnitude_ema.dtype), 1.0 - beta)
+        if self.dist_sync:
+            ddp.ema_of_rank_mean(self.magnitude_ema, mag, beta, ddp.LERP_TOWARDS)
+        else:
+            self.magnitude_ema.lerp_(mag.to(self.magnitude_ema.dtype), 1.0 - beta)
         return self.magnitude_ema.rsqrt()
 
     def forward(self, x: torch.Tensor, beta: float = 1.0) -> torch.Tensor:
@@ -162,36 +157,10 @@ class MagnitudeEMA(nn.Module):
         return self.magnitude_ema.rsqrt()
 
 
-@contextlib.contextmanager
-def deferred_magnitude_sync():
-    """Scope in which MagnitudeEMA layers record their local statistic instead of all-reducing it."""
-    assert MagnitudeEMA.pending is None, 'deferred_magnitude_sync scopes do not nest'
-    MagnitudeEMA.pending = []
-    try:
-        yield MagnitudeEMA.pending
-    finally:
-        MagnitudeEMA.pending = None
-
-
-def stack_pending(pending):
-    """(local means, previous EMAs) of a deferred scope as two vectors (cheap to keep in a captured graph)."""
-    return torch.stack([m for _, m, _, _ in pending]), torch.stack([p for _, _, _, p in pending])
-
-
-def finish_magnitude_sync(pending, stacked=None) -> None:
-    """One all-reduce for every statistic recorded in a deferred scope, then each buffer is REDONE as
-    lerp(previous EMA, global mean, 1 - beta): the reference's arithmetic, bit-identical on every rank."""
-    world = dist_utils.get_world_size()
-    if not pending or world <= 1:
-        return
-    local, prev = stack_pending(pending) if stacked is None else stacked
-    glob = local.clone()
-    torch.distributed.all_reduce(glob)
-    glob = glob / world
-    weight = torch.tensor([1.0 - beta for _, _, beta, _ in pending], dtype=glob.dtype, device=glob.device)
-    new = torch.lerp(prev.to(glob.dtype), glob, weight)
-    for (mod, _, _, _), v in zip(pending, new.unbind(0)):
-        mod.magnitude_ema.copy_(v)
+# the deferred exchange of the running statistics lives in lvg.ddp (shared with the super-resolution generator)
+deferred_magnitude_sync = ddp.deferred_stat_sync
+stack_pending = ddp.stack_pending
+finish_magnitude_sync = ddp.finish_stat_sync
 
 
 class FullyConnectedLayer(nn.Module):

@@ -36,6 +36,7 @@ import torch.nn.functional as F
 import torch_utils.distributed as dist_utils
 from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, modconv2d_layout, upfirdn2d, weight_prep
 
+from .. import ddp
 from .lres import FullyConnectedLayer, _linear_filter
 
 # 16-bit layers of the generator: dense convolution on channels-last (MFMA implicit-GEMM) kernels between the fused
@@ -140,12 +141,8 @@ class MappingNetwork(nn.Module):
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
         if update_emas:
-            mean = x.detach().mean(dim=0)
-            world = dist_utils.get_world_size()
-            if world > 1:
-                torch.distributed.all_reduce(mean)
-                mean = mean / world
-            self.w_avg.copy_(mean.lerp(self.w_avg, self.w_avg_beta))
+            # (mean over ranks: inside lvg.ddp.deferred_stat_sync() the exchange is batched after the pass)
+            ddp.ema_of_rank_mean(self.w_avg, x.detach().mean(dim=0), self.w_avg_beta, ddp.LERP_FROM)
         ws = x.unsqueeze(1).repeat(1, self.num_ws, 1)
         if truncation_psi != 1:
             cut = self.num_ws if truncation_cutoff is None else truncation_cutoff
@@ -270,11 +267,7 @@ class SynthesisLayer(nn.Module):
                 mag = sum(parts) / float(sum(t.numel() for t in (x, cond) if t is not None))
             else:
                 mag = x.detach().float().square().mean()
-            world = dist_utils.get_world_size()
-            if world > 1:
-                torch.distributed.all_reduce(mag)
-                mag = mag / world
-            self.magnitude_ema.copy_(mag.lerp(self.magnitude_ema, self.magnitude_ema_beta))
+            ddp.ema_of_rank_mean(self.magnitude_ema, mag.detach(), self.magnitude_ema_beta, ddp.LERP_FROM)
         input_gain = self.magnitude_ema.rsqrt()
 
         if fused:

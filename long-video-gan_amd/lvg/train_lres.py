@@ -47,17 +47,18 @@ class LowResTrainer:
         self.D_opt = FlatAdam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
         self._step = 0
         # use_graphs: the compute of update_G / update_D (generator pass, augmentation, discriminator pass, backward) is captured ONCE per
-        # micro-batch shape into hipGraphs and replayed; what stays eager is what cannot be captured on this stack or must see host values:
-        # the gradient exchange (an RCCL collective inside a captured graph aborts), the optimizer steps, R1. The host-side random draws of
-        # the reference (crop offsets, temporal stretch) are drawn in the same order as in eager mode and handed to the graphs through
-        # static device buffers. Bucket all-reduces from autograd hooks would be captured too, so the exchange runs after the replay.
-        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
+        # micro-batch shape into hipGraphs and replayed, at ANY world size; what stays eager is what cannot be captured on this stack or
+        # must see host values: every collective (an RCCL collective inside a captured graph aborts) -- the gradient exchange runs after a
+        # phase's replays, the running statistics a generator pass averages over ranks are exchanged in one all-reduce after its replay
+        # (lvg.phase_graphs) --, the optimizer steps, R1 (whose exchange still overlaps with its backward pass). The host-side random
+        # draws of the reference (crop offsets, temporal stretch) are drawn in the same order as in eager mode and handed to the graphs
+        # through static device buffers. use_graphs='segmented': the same protocol without capturing (any device; tests).
+        self.use_graphs = bool(use_graphs) and (self.device.type == 'cuda' or use_graphs == 'segmented')
         self._graphs = {}
-        self._phase_graphs = PhaseGraphs(lambda: (self.G_sync.flat, self.D_sync.flat, *self.G.buffers()), self._graphs)
-        if self.use_graphs:
-            overlap_grad_sync = False
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
         self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
+        self._phase_graphs = PhaseGraphs(lambda: (self.G_sync.flat, self.D_sync.flat, *self.G.buffers(), *self.D.buffers()), self._graphs,
+                                         syncs=(self.G_sync, self.D_sync), capture=self.device.type == 'cuda' and use_graphs != 'segmented')
 
     # ------------------------------------------------------------------------------------------
     def _gen(self, batch: int, beta: float = 1.0, t0: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -94,10 +95,15 @@ class LowResTrainer:
             self._graphs[('draws', key, batch)] = buf
         return buf
 
+    @staticmethod
+    def _fill(dst: torch.Tensor, host: torch.Tensor) -> None:
+        """A host-side draw into its static device buffer, through pinned memory (no host stall per copy)."""
+        dst.copy_(host.pin_memory() if dst.is_cuda else host, non_blocking=True)
+
     def _fill_stretch(self, dst, batch: int) -> None:
         if self.temp_scale_augment > 0:
             for d, s in zip(dst, temporal_scale_params(batch, self.seq_length, self.seq_length, self.temp_scale_augment)):
-                d.copy_(s.pin_memory() if d.is_cuda else s, non_blocking=True)
+                self._fill(d, s)
 
     def _replay(self, key, fn):
         """Run `fn` from its graph (lvg.phase_graphs: eager warm-up rolled back on the gradient buffers and the generator's running
@@ -121,13 +127,13 @@ class LowResTrainer:
         self.G.requires_grad_(True)
         self.G_sync.zero()
         for k in range(self.G_grad_accum):
-            if k == self.G_grad_accum - 1 and self.G_sync.overlap:
-                self.G_sync.arm()
+            if k == self.G_grad_accum - 1 and self.G_sync.overlap and not self.use_graphs:
+                self.G_sync.arm()                                          # (replayed phases run no hooks: their exchange follows them)
             if self.use_graphs:
                 b = batch // self.G_grad_accum
                 draws = self._static_draws('G', b)
                 if self.G_random_temp_translate:                           # host draws in eager order: crop, then the stretch
-                    draws['t0'].copy_(self._draw_crop(b, self.seq_length + self.G.total_temporal_scale).pin_memory(), non_blocking=True)
+                    self._fill(draws['t0'], self._draw_crop(b, self.seq_length + self.G.total_temporal_scale))
                 self._fill_stretch(draws['stretch'][0], b)
                 self._replay(('G', b), lambda: F.softplus(-self.run_D(self._gen(b, t0=draws['t0']), stretch=draws['stretch'][0])).mean().backward())
                 continue
@@ -165,7 +171,7 @@ class LowResTrainer:
         st = self._graphs.setdefault(('Dio', n, b), dict(fake=None, fake_in=torch.empty(b, *real_video.shape[1:], dtype=self.dtype, device=self.device),
                                                          real_in=torch.empty(b, *real_video.shape[1:], dtype=real_video.dtype, device=self.device)))
         if self.G_random_temp_translate:
-            gen['t0'].copy_(self._draw_crop(n, self.seq_length + self.G.total_temporal_scale).pin_memory(), non_blocking=True)
+            self._fill(gen['t0'], self._draw_crop(n, self.seq_length + self.G.total_temporal_scale))
 
         def generate():
             with torch.no_grad():

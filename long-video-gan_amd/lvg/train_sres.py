@@ -62,12 +62,13 @@ class SuperResTrainer:
         self.D_opt = FlatAdam(self.D.parameters(), lr=D_lrate, betas=(0.0, D_beta2))
         self._step = 0
         # use_graphs: the compute of a micro-batch of update_G / update_D and the fake generation are captured once per shape into hipGraphs
-        # and replayed (every random draw of this trainer is made on the device: lvg.phase_graphs); the exchange -- an RCCL collective cannot be
-        # captured, so no overlap with backward in this mode --, the optimizer steps, R1 and the ADA update stay eager.
-        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
+        # and replayed, at any world size (every random draw of this trainer is made on the device; the statistics a generator pass averages
+        # over ranks -- w_avg, the layers' magnitude EMAs -- are exchanged in one all-reduce after its replay: lvg.phase_graphs); the gradient
+        # exchange -- an RCCL collective cannot be captured -- follows a phase's replays, the optimizer steps, R1 (exchange overlapped with
+        # its backward pass) and the ADA update stay eager. use_graphs='segmented': the same protocol without capturing (any device; tests).
+        self.use_graphs = bool(use_graphs) and (self.device.type == 'cuda' or use_graphs == 'segmented')
+        self._capture = self.device.type == 'cuda' and use_graphs != 'segmented'
         self._static = {}
-        if self.use_graphs:
-            overlap_grad_sync = False
         self.G_sync = ddp.FlatGradSync(self.G.parameters(), overlap=overlap_grad_sync)
         self.D_sync = ddp.FlatGradSync(self.D.parameters(), overlap=overlap_grad_sync)
 
@@ -85,7 +86,12 @@ class SuperResTrainer:
                                           xfrac=1, xfrac_std=0.002 * k, noise=1, noise_std=0.01 * k)
             self.in_augment.to(self.device).requires_grad_(False).train()
             self.in_augment.p.fill_(in_augment_p)
-        self._phase_graphs = PhaseGraphs(lambda: (self.G_sync.flat, self.D_sync.flat, self._real_sign_sum, *self.G.buffers()))
+        # what a phase may update in place: the gradient buffers, the sign statistic, every buffer of the networks and of the augmentation
+        # pipelines (derived, not listed by hand: ADVICE r04)
+        self._phase_graphs = PhaseGraphs(lambda: (self.G_sync.flat, self.D_sync.flat, self._real_sign_sum, *self.G.buffers(), *self.D.buffers(),
+                                                  *(self.augment.buffers() if self.augment is not None else ()),
+                                                  *(self.in_augment.buffers() if self.in_augment is not None else ())),
+                                         syncs=(self.G_sync, self.D_sync), capture=self._capture)
 
     def _static_like(self, name: str, t: torch.Tensor) -> torch.Tensor:
         """A persistent input buffer of a captured phase, filled with `t`."""
@@ -136,8 +142,8 @@ class SuperResTrainer:
         self.G_sync.zero()
         chunks = lr_video.chunk(self.G_grad_accum)
         for k, lr in enumerate(chunks):
-            if k == len(chunks) - 1 and self.G_sync.overlap:
-                self.G_sync.arm()
+            if k == len(chunks) - 1 and self.G_sync.overlap and not self.use_graphs:
+                self.G_sync.arm()                                          # (replayed phases run no hooks: their exchange follows them)
             if self.use_graphs:
                 lr_in = self._static_like('G.lr', lr)
                 self._phase_graphs.replay(('G', tuple(lr.shape)),

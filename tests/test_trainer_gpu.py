@@ -61,20 +61,24 @@ def test_update_r1_gradients_match_reference_golden():
 def test_graph_mode_trains_like_eager_mode():
     """use_graphs=True replays the compute of update_G / update_D from hipGraphs, with the host-side draws (crop offsets, temporal stretch)
     handed over through static buffers. With the device-side randomness taken out (fixed temporal noise per shape, no DiffAugment -- captured
-    and eager execution number the device generator differently) both modes compute the same step. The yardstick is the distance between
-    TWO EAGER runs: the library convolutions of the 3 x 4-pixel layers sum split-K partials with atomics, so identical inputs give outputs
-    a few bf16 ulps apart and 16-bit gradients that differ by ~10 % of a tensor's maximum from run to run (tools/determinism_ops.py, profiles/r04_determinism_first_op.log);
-    the graph run must lie within five times that distance (+ 5 % of the tensor's maximum: one pair of eager runs is a noisy yardstick;
-    a capture that ran a phase twice or not at all is off by the whole gradient) of an eager run -- gradients and running magnitudes of the first step
-    (one update per update_D: the eager warm-up before the capture is rolled back), two more steps that must stay finite, one graph per phase and micro-batch shape."""
+    and eager execution number the device generator differently) both modes compute the same step, and in FLOAT32 the step is
+    deterministic enough to be the yardstick (measured, tools/diag_graph_determinism.py, profiles/r05_graph_determinism.log: two eager
+    runs agree to 1e-6 of the largest generator gradient; the discriminator's bias gradients are sums with atomics and differ by 1e-4 ..
+    2.5e-4 of the largest gradient between two EAGER runs; the running magnitudes agree exactly):
+      generator gradients   eager vs graph  <= 2e-5 of the largest gradient   (measured 2e-7 .. 1e-6)
+      discriminator         eager vs graph  <= 2e-3                           (measured 4e-6 .. 4e-5; eager vs eager up to 2.5e-4)
+      running magnitudes    equal to 1e-6   (ONE update per update_D: the eager warm-up before the capture is rolled back)
+    A stale draw buffer, a wrong stretch index or a phase that ran twice / not at all is off by 1e-2 .. 1 on these scales. Then the same
+    step in bfloat16 (the bench's arithmetic): 16-bit gradients differ by ~10 % of their maximum between two eager runs, so that part only
+    checks what it can: finite after three steps, one graph per phase and micro-batch shape."""
     from lvg.train_lres import LowResTrainer
-    kw = dict(seq_length=8, height=36, width=64, device='cuda', compute_dtype=torch.bfloat16, G_grad_accum=2, D_grad_accum=2,
+    kw = dict(seq_length=8, height=36, width=64, device='cuda', G_grad_accum=2, D_grad_accum=2,
               overlap_grad_sync=False, with_ema=True, temp_scale_augment=1.0, diffaug_policy='')
     real = None
     grads, mags, trainers = {}, {}, {}
-    for name, use_graphs in (('eager', False), ('eager2', False), ('graph', True)):
+    for name, use_graphs, dtype in (('eager', False, torch.float32), ('graph', True, torch.float32), ('graph16', True, torch.bfloat16)):
         torch.manual_seed(0)
-        tr = LowResTrainer(use_graphs=use_graphs, **kw)
+        tr = LowResTrainer(use_graphs=use_graphs, compute_dtype=dtype, **kw)
         assert tr.use_graphs == use_graphs
         if real is None:
             real = torch.rand(4, 3, 8, 36, 64, device='cuda') * 2 - 1
@@ -95,14 +99,15 @@ def test_graph_mode_trains_like_eager_mode():
             tr.train_step(step=step, real_video=real, r1_interval=0)
         trainers[name] = tr
     torch.cuda.synchronize()
-    for e, e2, g in zip(grads['eager'], grads['eager2'], grads['graph']):
+    for (e, g), gate, what in zip(zip(grads['eager'], grads['graph']), (2e-5, 2e-3), ('generator', 'discriminator')):
         assert torch.isfinite(g).all() and float(e.abs().max()) > 0
-        noise = float((e - e2).abs().max())
-        assert float((e - g).abs().max()) <= 5 * noise + 0.05 * float(e.abs().max()), (float((e - g).abs().max()), noise, float(e.abs().max()))
+        assert float((e - g).abs().max()) <= gate * float(e.abs().max()), (what, float((e - g).abs().max()), float(e.abs().max()))
     moved = float((mags['eager'] - 1).abs().max())
     assert moved > 1e-4                                                 # one update at beta 0.999 ...
-    assert float((mags['eager'] - mags['graph']).abs().max()) <= 5 * float((mags['eager'] - mags['eager2']).abs().max()) + 0.05 * moved, (mags['eager'], mags['graph'])   # ... not two, not none
-    graph = trainers['graph']
-    for p in list(graph.G.parameters()) + list(graph.D.parameters()):
-        assert torch.isfinite(p).all()
-    assert {k[0] for k in graph._graphs if isinstance(k, tuple)} >= {'G', 'Dgen', 'D'}
+    assert float((mags['eager'] - mags['graph']).abs().max()) <= 1e-6, (mags['eager'], mags['graph'])   # ... not two, not none
+    for name in ('graph', 'graph16'):
+        graph = trainers[name]
+        assert torch.isfinite(grads[name][0]).all() and torch.isfinite(grads[name][1]).all()
+        for p in list(graph.G.parameters()) + list(graph.D.parameters()):
+            assert torch.isfinite(p).all()
+        assert {k[0] for k in graph._graphs if isinstance(k, tuple)} >= {'G', 'Dgen', 'D'}
