@@ -263,7 +263,9 @@ int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int wd, int ci, int 
 /* Measurement / test control (no counterpart in the reference): force the tile of lvg_conv3d_frames -- bm pixels (128 | 256) x bn output
  * channels (64 | 128), weight ring depth nb (2 | 3); 0 = the kernel's own choice -- and switch the persistent-workgroup form of the
  * 64-channel tiles on / off. Every form computes the same bits (tests/test_conv3d_frames.py). Initial values: LVG_CONV_BM / _BN / _NB /
- * _PERSIST from the environment. */
+ * _PERSIST from the environment. NOT thread-safe against concurrent lvg_conv3d_frames / lvg_conv3d_frames_workgroups calls: the plan is
+ * process-wide state read by both (a caller sizes msq_partial with one and launches with the other); change it only while no other
+ * thread is inside the library. */
 int lvg_conv3d_frames_set_plan(int bm, int bn, int nb, int persist);
 
 /*

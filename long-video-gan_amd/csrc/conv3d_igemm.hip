@@ -42,6 +42,7 @@
 //    on the 512-channel layers (profiles/r02_conv_direct_weights.log) -- fragment-shaped loads (32 rows x 32 bytes per
 //    instruction, every weight byte fetched by two waves) saturate the texture-address path long before the matrix pipe.
 
+#include <atomic>
 #include "igemm_kernel.h"
 
 namespace {
@@ -56,14 +57,17 @@ struct Plan
 
 int device_cus()
 {
-    static int cus = 0;
-    if (cus == 0)
+    // per device (one process may drive devices of different sizes)
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0)
     {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-        cus = n;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        cus[dev & 63].store(n, std::memory_order_relaxed);
     }
-    return cus;
+    return n;
 }
 
 int env_int(const char* name, int dflt)

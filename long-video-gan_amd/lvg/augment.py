@@ -61,7 +61,11 @@ def temporal_scale_params(n: int, frames: int, seq_length: int, amount: float):
     """The host-side random draws of `temporal_scale_augment` for `n` clips of `frames` frames, in the reference's order (per sample: the
     stretch, the pad offset, the crop offset; video_gan_lres.py:242-263), turned into what the device needs: for every output frame the
     source frame below it, the interpolation weight of the next one and whether it lies inside the stretched clip (else zero padding).
-    -> (i0 [n, seq_length] int64, frac [n, seq_length] float32, valid [n, seq_length] float32), CPU tensors."""
+    -> (i0 [n, seq_length] int64, frac [n, seq_length] float32, valid [n, seq_length] float32), CPU tensors.
+    Parity is with the reference's interpolation as torch's CPU kernel computes it (the golden fixtures come from the reference on the
+    CPU): source positions in float64, and the plain copy `upsample_bilinear2d` makes when the stretched length equals the clip's (scales
+    in [1, 1 + 1/T)). The reference on a GPU would use float32 source indices and no such shortcut there: a difference below 1/T in one
+    interpolation weight, for that range of scales only."""
     i0s, fracs, valids = [], [], []
     steps = torch.arange(seq_length, dtype=torch.float64)
     for _ in range(n):

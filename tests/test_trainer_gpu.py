@@ -111,3 +111,76 @@ def test_graph_mode_trains_like_eager_mode():
         for p in list(graph.G.parameters()) + list(graph.D.parameters()):
             assert torch.isfinite(p).all()
         assert {k[0] for k in graph._graphs if isinstance(k, tuple)} >= {'G', 'Dgen', 'D'}
+
+
+def _worker_graph_two_ranks(rank, world, port, out):
+    """Two ranks on ONE device (gloo carries the device tensors through the host): LowResTrainer and SuperResTrainer with use_graphs=True.
+    What is checked is the protocol at N > 1 with real captures: no collective ends up inside a captured phase (that aborts / hangs),
+    the deferred statistics and the gradients are exchanged after the replays, and after two steps both ranks hold identical networks."""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'long-video-gan_amd'))
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lvg.train_lres import LowResTrainer
+        from lvg.train_sres import SuperResTrainer
+        from helpers.ada_cfg import TRAIN_SRES_KW
+        torch.cuda.set_device(0)
+
+        def digest(nets):
+            t = torch.cat([x.detach().flatten().double() for net in nets for x in list(net.parameters()) + list(net.buffers())])
+            d = torch.stack([t.sum(), t.abs().sum(), t.square().sum()]).cpu()
+            both = [torch.zeros_like(d) for _ in range(world)]
+            dist.all_gather(both, d)
+            assert torch.isfinite(d).all() and torch.equal(both[0], both[1]), f'ranks differ: {both}'
+
+        torch.manual_seed(20 + rank)                                    # different init per rank: the broadcast must fix it
+        tr = LowResTrainer(seq_length=8, device='cuda', compute_dtype=torch.bfloat16, use_graphs=True, with_ema=True)
+        assert tr.use_graphs
+        real = torch.rand(1, 3, 8, 36, 64, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3 + rank)) * 2 - 1
+        for step in (1, 2):
+            tr.train_step(step, real, r1_interval=2)                    # (step 2 runs R1: eager, exchange overlapped with its backward pass)
+        emas = torch.stack([b.float().reshape(()) for n, b in tr.G.named_buffers() if n.endswith('magnitude_ema')])
+        assert float((emas - 1).abs().max()) > 0                        # the deferred statistics were exchanged and applied
+        digest((tr.G, tr.D, tr.G_ema))
+        assert {k[0] for k in tr._graphs if isinstance(k, tuple)} >= {'G', 'Dgen', 'D'}
+        del tr
+
+        torch.manual_seed(40 + rank)
+        ts = SuperResTrainer(device='cuda', compute_dtype=torch.float16, use_graphs=True, seq_length=2, temporal_context=1, lr_height=9, lr_width=16,
+                             hr_height=36, hr_width=64, G_kwargs=dict(latent_z_dim=32, latent_w_dim=48, channel_base=1024, channel_max=24, num_fp16_res=2),
+                             D_kwargs=dict(channels_base=1024, channels_max=32, num_fp16_res=0), augment_kwargs=TRAIN_SRES_KW, augment_p_init=0.3)
+        g = torch.Generator(device='cuda').manual_seed(7 + rank)
+        lr = torch.rand(2, 3, 4, 9, 16, device='cuda', generator=g) * 2 - 1
+        hr = torch.rand(2, 3, 2, 36, 64, device='cuda', generator=g) * 2 - 1
+        for step in (0, 1):
+            ts.train_step(step=step, lr_video=lr, hr_video=hr, r1_interval=16, ada_interval=4)
+        digest((ts.G, ts.D, ts.G_ema, ts.augment))
+        out.put((rank, 'ok'))
+    except Exception:
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graph_trainers_two_ranks_on_one_device():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_graph_two_ranks, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == 'ok', f'rank {rank}: {msg}'
