@@ -430,7 +430,10 @@ def main():
                 # BASELINE.json configs[2] and configs[4] at N = 1 (the driver's multi-GPU runs use --workload train_lres)
                 legs += [('train_lres', lambda: _train_lres_run(1, 0, dev, dtype, T, steps=2, warmup=1, dtype_name=args.dtype)),
                          ('train_sres', lambda: _train_sres_leg(dev))]
+            only = [n for n in os.environ.get('LVG_BENCH_LEGS', '').split(',') if n]      # (A/B measurements: run just these legs)
             for name, leg in legs:
+                if only and name not in only:
+                    continue
                 try:
                     result[name] = leg()
                 except Exception as err:  # pylint: disable=broad-except

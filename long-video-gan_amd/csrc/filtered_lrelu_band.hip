@@ -37,6 +37,9 @@
 #ifndef LVG_BAND_SCHED_FENCE
 #define LVG_BAND_SCHED_FENCE 1
 #endif
+#ifndef LVG_BAND_SLOTS
+#define LVG_BAND_SLOTS 3     // ring slots (K-chunks of 16 input rows): two in use, the rest in flight
+#endif
 #ifndef LVG_BAND_PIPE
 #define LVG_BAND_PIPE 1      // stage B of column block b + 1 issued before the activation of block b (16 more registers)
 #endif
@@ -50,7 +53,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 template <bool B> struct BoolC { static constexpr bool value = B; };
 template <int V> struct IntC { static constexpr int value = V; };
 
-constexpr int kSlots = 3;          // ring slots (K-chunks of 16 input rows): two in use, one in flight
+constexpr int kSlots = LVG_BAND_SLOTS;          // ring slots (K-chunks of 16 input rows): two in use, one in flight
 constexpr int kAyRows = 12;        // rows of the bias-coefficient table: v-blocks that touch rows above the image, one for the interior, those that touch rows below
 constexpr int kMaxPieces = 4;      // DMA instructions of one chunk a wave may have to issue
 constexpr int kRingPad = 512;      // zeros behind the ring: transpose reads of the last slot's last rows run past the row's end
@@ -846,11 +849,17 @@ int lvg_flrelu_band_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all,
     if (dtype != LVG_F16) return LVG_ERR_UNSUPPORTED;
     if (!all)
     {
-        // Measured against the wave kernel (profiles/r05_band_d.log, r05_band_small.log): faster where a plane is three column strips
-        // (12 balanced waves per CU: 148-wide outputs, both directions, all three rate pairs), on a par at two strips for up 2 / down 2;
-        // slower at one strip (7 waves per CU) and at five (10 waves per CU, uneven over the SIMDs).
+        // Measured against the wave kernel at the batch of the training step (16 frames: beyond the Infinity Cache;
+        // profiles/r05_band_cold.log, r05_band_small_layers_time.log, r05_sres_ab_perlayer.log): faster where the strips of a plane give
+        // workgroups of three or four waves -- 12 waves per CU, three per SIMD -- in the forward modes (148-wide outputs: -16 .. -18 %) and in
+        // the up 2 / down 4 backward (86-wide: 436 -> 356 us); on a par or behind at one strip (7 waves per CU), at five (10 waves, uneven over
+        // the SIMDs), at six, and in the up 2 / down 2 backward (its mask reads miss the caches one v-block at a time).
         const int tw = cfg == LVG_FLRELU_CFG_U2D4 ? 26 : 56, ns = (p.yw + tw - 1) / tw;
-        if (!(ns == 3 || (ns == 2 && cfg == LVG_FLRELU_CFG_U2D2))) return LVG_ERR_UNSUPPORTED;
+        bool take = false;
+        if (cfg == LVG_FLRELU_CFG_U2D2) take = mode != LVG_SIGNS_READ && (ns == 2 || ns == 3);
+        if (cfg == LVG_FLRELU_CFG_U4D2) take = mode != LVG_SIGNS_READ && ns == 3;
+        if (cfg == LVG_FLRELU_CFG_U2D4) take = ns == 4;
+        if (!take) return LVG_ERR_UNSUPPORTED;
     }
     switch (cfg)
     {

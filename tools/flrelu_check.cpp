@@ -352,6 +352,16 @@ int main(int argc, char** argv)
         for (const Case& cs : small)
             for (int mode = 0; mode <= 2; mode++) run_time(cs, 1, mode);
     }
+    if (what == "timecold")     // the bench's batch (16 frames): 450 .. 680 MB per call, beyond the 256 MiB Infinity Cache
+    {
+        const Case cold[] = {
+            {"L8x16", 16, 512, 94, 150, 2, 2, 12, 12, 9, 8, 9, 8},
+            {"L7x16", 16, 512, 58, 86, 4, 2, 24, 12, -6, -9, -6, -9},
+            {"L13x16", 16, 128, 166, 278, 2, 2, 12, 12, -11, -12, -11, -12},
+        };
+        for (const Case& cs : cold)
+            for (int mode = 0; mode <= 2; mode++) run_time(cs, 1, mode);
+    }
     if (what == "one")      // one <L8|L10|L13> <dtype 1|2> <mode 0|1|2> <impl 1|2> [reps]: for rocprofv3
     {
         const Case big[] = {
