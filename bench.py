@@ -428,7 +428,9 @@ def main():
                     ('sres', lambda: _sres_leg(dev, timer))]
             if not os.environ.get('LVG_BENCH_NO_TRAIN_LEGS'):
                 # BASELINE.json configs[2] and configs[4] at N = 1 (the driver's multi-GPU runs use --workload train_lres)
-                legs += [('train_lres', lambda: _train_lres_run(1, 0, dev, dtype, T, steps=2, warmup=1, dtype_name=args.dtype)),
+                # 16 timed iterations each: ONE R1 step (every 16th) falls inside the timed region, so `value` is the rate of the real
+                # schedule, measured, not an amortisation done by hand
+                legs += [('train_lres', lambda: _train_lres_run(1, 0, dev, dtype, T, steps=16, warmup=1, dtype_name=args.dtype)),
                          ('train_sres', lambda: _train_sres_leg(dev))]
             only = [n for n in os.environ.get('LVG_BENCH_LEGS', '').split(',') if n]      # (A/B measurements: run just these legs)
             for name, leg in legs:
@@ -541,6 +543,9 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
     step_no = 1
     for _ in range(warmup):
         tr.train_step(step_no, real); step_no += 1
+    r1_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 16 == 0)
+    if r1_steps:
+        tr.update_r1(real, gain=16)                                         # (first R1 pass: lazy initialisation outside the timed region)
     barrier()
     tr.G_sync.exposed_events.clear(); tr.D_sync.exposed_events.clear()
     t0 = time.perf_counter()
@@ -553,17 +558,16 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    r1_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 16 == 0)
-    extra = {}
+    # one R1 update on its own (warm), for the record; short runs that saw no R1 step (every 16th) also get the amortised rate
+    tr.update_r1(real, gain=16)
+    barrier()
+    t1 = time.perf_counter()
+    tr.update_r1(real, gain=16)
+    barrier()
+    r1_ms = (time.perf_counter() - t1) * 1e3
+    extra = {'r1_update_ms': round(r1_ms, 2)}
     if r1_steps == 0:
-        # short runs see no R1 step (every 16th): time one R1 update on its own and report the amortised rate next to the plain one
-        tr.update_r1(real, gain=16)
-        barrier()
-        t1 = time.perf_counter()
-        tr.update_r1(real, gain=16)
-        barrier()
-        r1_ms = (time.perf_counter() - t1) * 1e3
-        extra = {'r1_update_ms': round(r1_ms, 2), 'value_with_r1_every_16': round(total_batch * frames_per_clip / (elapsed / steps + r1_ms * 1e-3 / 16), 2)}
+        extra['value_with_r1_every_16'] = round(total_batch * frames_per_clip / (elapsed / steps + r1_ms * 1e-3 / 16), 2)
     del tr
     return {
         **extra,
@@ -580,7 +584,7 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
         'grad_sync': {'exposed_ms_per_step': round(exposed_ms, 3), 'note': 'device time of the all-reduces / waits of FlatGradSync.finish() per iteration (update_G + update_D [+ R1]); 0 at one rank'}}
 
 
-def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):
+def _train_sres_leg(dev, steps=16, warmup=1, total_batch=16):
     """BASELINE.json configs[4] at N = 1: the step body of train_sres.py:241-264 (SuperResTrainer.train_step: update_G, update_D, R1 on every
     16th step, ADA probability update on every 4th, generator EMA) on synthetic (low-resolution clip with context, high-resolution clip)
     pairs, total batch 16 in micro-batches of 2 segments, ADA pipeline and conditioning augmentation on. Graph replay per phase (LVG_TRAIN_GRAPHS=0: eager)."""
@@ -595,6 +599,8 @@ def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):
     step_no = 1
     for _ in range(warmup):
         tr.train_step(step_no, lr, hr); step_no += 1
+    if any(k % 16 == 0 for k in range(warmup + 1, warmup + steps + 1)):
+        tr.update_r1(tr.crop_to_seq_length(lr), hr, gain=16)               # (first R1 pass: lazy initialisation outside the timed region)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -603,16 +609,16 @@ def _train_sres_leg(dev, steps=3, warmup=1, total_batch=16):
     dt = (time.perf_counter() - t0) / steps
     r1_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 16 == 0)
     ada_steps = sum(1 for k in range(warmup + 1, warmup + steps + 1) if k % 4 == 0)
-    extra = {}
+    lr_c = tr.crop_to_seq_length(lr)
+    tr.update_r1(lr_c, hr, gain=16)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    tr.update_r1(lr_c, hr, gain=16)
+    torch.cuda.synchronize()
+    r1_ms = (time.perf_counter() - t1) * 1e3
+    extra = {'r1_update_ms': round(r1_ms, 2)}
     if r1_steps == 0:
-        lr_c = tr.crop_to_seq_length(lr)
-        tr.update_r1(lr_c, hr, gain=16)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        tr.update_r1(lr_c, hr, gain=16)
-        torch.cuda.synchronize()
-        r1_ms = (time.perf_counter() - t1) * 1e3
-        extra = {'r1_update_ms': round(r1_ms, 2), 'value_with_r1_every_16': round(total_batch * 8 / (dt + r1_ms * 1e-3 / 16), 2)}
+        extra['value_with_r1_every_16'] = round(total_batch * 8 / (dt + r1_ms * 1e-3 / 16), 2)
     del tr
     return {**extra, 'metric': 'frames/sec train_sres iteration (update_G + update_D + R1/16 + ADA/4 + EMA), 8-frame 144x256 segments', 'value': round(total_batch * 8 / dt, 2),
             'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'warmup': warmup, 'dtype': 'f16',
@@ -682,32 +688,63 @@ def _forward_only_leg(G, B, T, dtype, steps=6):
             'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'hipgraph'}
 
 
-def _fp32_leg(G, D, T, B=2, steps=3):
+def _fp32_leg(G, D, T, B=8, steps=3):
     """The same generator update in FLOAT32 (the reference trains the low-resolution networks in float32 with TF32 off,
-    train_lres.py:268-269): forward + backward through the discriminator on the float32 route of the hand-written kernels
-    (16-bit operand splits on the matrix cores, float32 accumulation: DESIGN 4.13), eager launches, gradients discarded.
-    Reported beside the bf16 main line, never instead of it."""
+    train_lres.py:268-269), at the main line's batch and launch mode: forward + backward through the discriminator on the
+    float32 route of the hand-written kernels (16-bit operand splits on the matrix cores, float32 accumulation: DESIGN 4.13),
+    replayed from a hipGraph, gradients discarded. Reported beside the bf16 main line, never instead of it.
+    Its roofline: the step's dense-contraction FLOPs (the same count as the bf16 step) over the step time, against the float32
+    MFMA peak (157 TFLOP/s: what exact-float32 matrix instructions would allow) and against a sixth of the 16-bit peak (the split
+    route spends up to six 16-bit products per float32 product)."""
+    from torch.utils.flop_counter import FlopCounterMode
     from lvg.models import lres
+    from torch_utils.ops import conv3d_frames
     saved = [p.grad for p in G.parameters()]
     def one():
         for p in G.parameters():
             p.grad = None
         video = G(B, T, dtype=torch.float32)
         F.softplus(-D(video, dtype=torch.float32)).mean().backward()
+    mode = 'eager'
     try:
         one()
+        conv3d_frames.stats['flops'] = 0
+        with FlopCounterMode(display=False) as fc:
+            one()
+        flops = float(fc.get_total_flops()) + float(conv3d_frames.stats['flops'])
+        torch.cuda.synchronize()
+        run = one
+        if os.environ.get('LVG_FP32_GRAPH', '1') != '0':
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    one()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one()
+                g.replay()
+                run, mode = g.replay, 'hipgraph'
+            except Exception:  # pylint: disable=broad-except
+                run, mode = one, 'eager'
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            one()
+            run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
     finally:
-        for p, g in zip(G.parameters(), saved):
-            p.grad = g
+        for p, g_ in zip(G.parameters(), saved):
+            p.grad = g_
+    tf = flops / dt / 1e12
     return {'metric': 'frames/sec lres-G 128x36x64 forward+backward (generator update)', 'dtype': 'fp32', 'value': round(B * T / dt, 1), 'unit': 'frames/s',
-            'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'eager',
-            'route': 'split-operand float32 on the hand-written kernels' if lres.SPLIT_F32 else 'library float32'}
+            'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': mode,
+            'route': 'split-operand float32 on the hand-written kernels' if lres.SPLIT_F32 else 'library float32',
+            'roofline': {'bound': 'mfma', 'achieved': round(tf, 1), 'unit': 'TFLOP/s (float32-equivalent: the FLOPs of the float32 contraction / step time)',
+                         'peak_f32_mfma': 157.3, 'frac_of_f32_mfma': round(tf / 157.3, 4),
+                         'peak_split_route': round(MFMA_PEAK_TFLOPS / 6, 1), 'frac_of_split_route': round(tf / (MFMA_PEAK_TFLOPS / 6), 4),
+                         'flops_per_step': int(flops), 'scope': 'all dense contractions of the step / whole step time (end to end)'}}
 
 
 def _mfma_leg(step, sec_per_step):
@@ -848,12 +885,21 @@ def _cpu_baseline(forward_only):
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_step.py')] + (['--forward-only'] if forward_only else [])
     env = dict(os.environ, CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    # The reference's OWN CPU path cannot run on the driver's box (no reference checkout there): its figures measured in the build
+    # container are BASELINE.md's, quoted beside whatever kind of baseline was timed here.
+    quoted = {'source': 'BASELINE.md (reference networks on their upfirdn2d ref path, Xeon 2.1 GHz container, torch CPU)',
+              'generator_lres_forward_16_frames': {'frames_per_s': 32.7, 'threads': 8, 'seconds': 0.489},
+              'generator_lres_forward_16_frames_1_thread': {'frames_per_s': 6.5, 'threads': 1, 'seconds': 2.476},
+              'generator_lres_forward_128_frames': {'frames_per_s': 78.8, 'threads': 8, 'seconds': 1.625},
+              'generator_sres_forward_8_frames': {'frames_per_s': 0.23, 'threads': 8, 'seconds': 34.4}}
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
-        return json.loads(out.stdout.strip().splitlines()[-1])
+        res = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as err:  # pylint: disable=broad-except
-        return {'value': None, 'unit': 'frames/s', 'cores': None, 'kind': 'port',
-                'sample': f'not measured: {type(err).__name__} (limit 150 s)'}
+        res = {'value': None, 'unit': 'frames/s', 'cores': None, 'kind': 'port',
+               'sample': f'not measured: {type(err).__name__} (limit 150 s)'}
+    res['reference_cpu_measured_in_build_container'] = quoted
+    return res
 
 
 if __name__ == '__main__':
