@@ -440,6 +440,22 @@ int lvg_style_prep_backward(const float* s, const float* amax, const float* w2, 
 int lvg_video_to_uint8(const void* video, void* bytes, int64_t n, int c, int t, int h, int w, int dtype, void* stream);
 int lvg_video_from_uint8(const void* bytes, void* video, const uint8_t* flip, int64_t n, int c, int t, int h, int w, int dtype, void* stream);
 
+/*
+ * Temporal noise filter bank of the low-resolution generator (csrc/noise_bank.hip). Replaces the grouped F.conv1d of
+ * model/generator_lres.py:378-388 (BlurredNoise.blur: every noise row against each of the F right-aligned low-pass
+ * filters of K taps, then the per-filter scale of :383-384):
+ *   out [rows, filters, frames] = scale[f] * sum_k noise[r, t + k] * bank[f, k],   length = frames + taps - 1.
+ * The bank is passed PACKED per group of 32 filters (built once per bank by the caller): group g walks only its last
+ * 2 * pairs[g] taps (pairs[g] = ceil(longest filter of the group / 2) rounded up to a multiple of 64), and
+ *   bankP[(pairOff[g] + p) * 64 + lane] = bank[32 g + lane % 32][taps - 2 pairs[g] + 2 p + lane / 32]   (0 outside the bank),
+ * pairOff [groups + 1] int32 = prefix sums of pairs[], maxPairs = the largest pairs[g]; bankP ends in 8 spare zero lines
+ * of 64 floats (the kernel prefetches one block ahead). Float32 MFMA with float32
+ * accumulation; the K range of a tile is split over four waves and summed in a fixed order (reproducible). All pointers
+ * are device pointers, float32, dense; scale may be NULL.
+ */
+int lvg_noise_filter_bank(const float* noise, const float* bankP, const int* pairOff, const float* scale, float* out,
+                          int rows, int length, int frames, int filters, int taps, int groups, int maxPairs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

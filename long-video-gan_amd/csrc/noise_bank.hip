@@ -35,6 +35,7 @@ struct NoiseBankArgs
 };
 
 constexpr int kWaves = 4;
+constexpr int kBlock = 8;       // K-pairs per loop iteration of a wave (pairs per group: multiples of 2 * kWaves * kBlock)
 
 __global__ __launch_bounds__(256) void noise_bank_kernel(NoiseBankArgs q)
 {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void noise_bank_kernel(NoiseBankArgs q)
     const int rem = (int)(blockIdx.x % (unsigned)perGroup);
     const int rp = rem / q.tBlocks, tb = rem - rp * q.tBlocks;
     const int r0 = 2 * rp, t0 = 32 * tb;
-    const int p0 = q.pairOff[g], pairs = q.pairOff[g + 1] - p0;      // pairs: a multiple of 4 * kWaves
+    const int p0 = q.pairOff[g], pairs = q.pairOff[g + 1] - p0;      // pairs: a multiple of 2 * kBlock * kWaves
     const int k0 = q.K - 2 * pairs;                                  // first tap of the group (may be negative: the packed bank holds zeros there)
     const int seg = 32 + 2 * pairs;                                  // noise samples a row of the tile needs: [t0 + k0, t0 + k0 + seg)
 
@@ -62,28 +63,41 @@ __global__ __launch_bounds__(256) void noise_bank_kernel(NoiseBankArgs q)
     f32x16 acc0, acc1;
     #pragma unroll
     for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    const int per = pairs / kWaves;                                  // this wave's share of the K range (a multiple of 4)
+    const int per = pairs / kWaves;                                  // this wave's share of the K range (a multiple of 2 * kBlock)
     const int pBeg = wave * per;
     const float* bp = q.bankP + ((int64_t)(p0 + pBeg) * 64 + lane);
     const float* a0 = smem + (lane & 31) + (lane >> 5) + 2 * pBeg;
     const float* a1 = a0 + seg;
-    float b[4], bn[4];
-    #pragma unroll
-    for (int j = 0; j < 4; j++) b[j] = bp[j * 64];
-    for (int p = 0; p < per; p += 4)
+    // Eight lines of the bank per block, two register sets: while one block is multiplied the lines of the next are in flight (~1000 matrix cycles to
+    // cover the L2 latency; a single set with a register copy at the end of the iteration made the compiler wait for every load there). The loads are
+    // unconditional: the packed bank ends in kBlock spare lines, so the last prefetch stays inside the allocation.
+    float b0[kBlock], b1[kBlock];
+    auto fetch = [&](float (&b)[kBlock], int p) __attribute__((always_inline))
     {
-        const bool more = p + 4 < per;
         #pragma unroll
-        for (int j = 0; j < 4; j++) bn[j] = more ? bp[(p + 4 + j) * 64] : 0.f;     // next four lines of the bank while these four are multiplied
+        for (int j = 0; j < kBlock; j++) b[j] = bp[(p + j) * 64];
+    };
+    auto multiply = [&](const float (&b)[kBlock], int p) __attribute__((always_inline))
+    {
         #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < kBlock; j++)
         {
             const float x0 = a0[2 * (p + j)], x1 = a1[2 * (p + j)];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b[j], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b[j], acc1, 0, 0, 0);
         }
-        #pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = bn[j];
+    };
+    fetch(b0, 0);
+    for (int p = 0; p < per; p += 2 * kBlock)
+    {
+        fetch(b1, p + kBlock);
+        __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise sinks the loads behind the products they are meant to overlap)
+        multiply(b0, p);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(b0, p + 2 * kBlock);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(b1, p + kBlock);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // sum of the four K ranges: waves 1 .. 3 park their accumulators in LDS, wave 0 adds them in wave order
@@ -143,7 +157,7 @@ extern "C" int lvg_noise_filter_bank(const float* noise, const float* bankP, con
     LVG_REQUIRE(rows >= 0 && frames >= 0 && filters > 0 && taps > 0 && groups > 0 && groups * 32 >= filters && length == frames + taps - 1,
                 "lvg_noise_filter_bank: need length == frames + taps - 1 and 32 * groups >= filters (rows %d, length %d, frames %d, filters %d, taps %d, groups %d)",
                 rows, length, frames, filters, taps, groups);
-    LVG_REQUIRE(maxPairs > 0 && maxPairs % (4 * kWaves) == 0, "lvg_noise_filter_bank: pairs per group must be multiples of %d", 4 * kWaves);
+    LVG_REQUIRE(maxPairs > 0 && maxPairs % (2 * kBlock * kWaves) == 0, "lvg_noise_filter_bank: pairs per group must be multiples of %d", 2 * kBlock * kWaves);
     if (rows == 0 || frames == 0) return LVG_OK;
     NoiseBankArgs q;
     q.noise = noise; q.bankP = bankP; q.pairOff = pairOff; q.scale = scale; q.out = out;

@@ -30,7 +30,7 @@ import contextlib
 
 from .. import ddp
 
-from torch_utils.ops import bias_act, conv3d_frames, style_prep, upfirdn2d, weight_prep
+from torch_utils.ops import bias_act, conv3d_frames, noise_bank, style_prep, upfirdn2d, weight_prep
 from torch_utils.ops.modconv_epilogue import dual_supported, modconv_epilogue, modconv_epilogue_dual, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
@@ -814,6 +814,8 @@ WEIGHT_PREP = os.environ.get('LVG_WEIGHT_PREP', '1') == '1'
 # The style side (per-sample max normalisation, demodulation rsqrt(w2 . s^2 + 1e-8)) likewise (torch_utils/ops/style_prep.py):
 # ~8 launches forward and ~25 backward per layer become 2 + 3. LVG_STYLE_PREP=0 restores the tensor expressions.
 STYLE_PREP = os.environ.get('LVG_STYLE_PREP', '1') == '1'
+# The temporal noise filter bank on the float32 matrix cores (csrc/noise_bank.hip) instead of one dense product over materialised windows.
+NOISE_BANK_HIP = os.environ.get('LVG_NOISE_BANK', '1') == '1'
 
 
 def modulation_terms(weight: torch.Tensor, style: torch.Tensor, demodulate: bool, dtype: Optional[torch.dtype] = None):
@@ -873,6 +875,7 @@ class BlurredNoise(nn.Module):
         if normalize_per_filter > 0:
             self.register_buffer('output_scale', (bank ** 2).sum(dim=1).rsqrt().reshape(1, -1, 1))
         self.register_buffer('blur_filters', bank.unsqueeze(1))
+        self._packed_bank = None          # torch_utils.ops.noise_bank.PackedBank, built on first use (not part of the state)
 
     def forward(self, batch_size: int, seq_length: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         noise = torch.randn(batch_size, self.noise_channels, seq_length + self.kernel_size - 1,
@@ -882,9 +885,20 @@ class BlurredNoise(nn.Module):
     def blur(self, noise: torch.Tensor) -> torch.Tensor:
         n, c, t = noise.shape
         assert c == self.noise_channels
+        bank = self.blur_filters[:, 0, :]
+        rows = noise.reshape(n * c, t)
+        if NOISE_BANK_HIP and noise_bank.supported(rows, bank):
+            # float32 GPU tensors: the staircase bank on the float32 matrix cores, sliding windows read out of the noise row (csrc/noise_bank.hip)
+            if self._packed_bank is None:
+                self._packed_bank = noise_bank.PackedBank()
+            scale = None
+            if self.normalize_per_filter > 0:
+                scale = (1 + self.normalize_per_filter * (self.output_scale - 1)).reshape(-1)
+            y = noise_bank.noise_filter_bank(rows, bank, self._packed_bank.get(bank), scale)
+            return y.reshape(n, c * self.blur_widths, y.size(2))
         # The filter bank as one GEMM over sliding windows of the noise: [n c, T_out, K] @ [K, widths].
         # (The reference's grouped conv1d with 5000-tap kernels lands on MIOpen's naive direct kernel.)
-        win = noise.reshape(n * c, t).unfold(1, self.kernel_size, 1)
+        win = rows.unfold(1, self.kernel_size, 1)
         y = torch.matmul(win, self.blur_filters[:, 0, :].t()).transpose(1, 2)
         if self.normalize_per_filter > 0:
             y = y * (1 + self.normalize_per_filter * (self.output_scale - 1))

@@ -344,6 +344,20 @@ def video_from_uint8(frames, flip=None):
     return out
 
 
+def noise_filter_bank(noise, bank, scale=None):
+    """BlurredNoise.blur (orc_noise_filter_bank; reference generator_lres.py:378-388): noise [R, L], bank [F, K], scale [F] or None ->
+    [R, F, L - K + 1] float64."""
+    noise, bank = _f64(noise), _f64(bank)
+    r, length = noise.shape
+    f, k = bank.shape
+    out = np.empty((r, f, length - k + 1), dtype=np.float64)
+    sc = None if scale is None else _f64(np.asarray(scale).reshape(-1))
+    rc = lib().orc_noise_filter_bank(noise.ctypes.data_as(ctypes.c_void_p), bank.ctypes.data_as(ctypes.c_void_p),
+                                     None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), r, length, f, k)
+    assert rc == 0
+    return out
+
+
 def ada_warp(x, g_inv, f, margins):
     """ADA geometric stage (orc_ada_warp; reference ada_augment.py:271-304): x [N, K, H, W], g_inv [N, 3, 3] (pixel units, centred),
     f [taps] the normalised 1-D low-pass, margins (mx0, my0, mx1, my1) the reflect padding of :283 -> [N, K, H, W]."""
