@@ -20,7 +20,7 @@ B, T = int(os.environ.get('B', 8)), 128
 G = VideoGenerator().cuda().requires_grad_(True)
 D = VideoDiscriminator(seq_length=T, max_edge=64).cuda().requires_grad_(True)
 video = G(B, T, dtype=torch.bfloat16) if 'dtype' in G.forward.__code__.co_varnames else G(B, T)
-F.softplus(-D(video)).mean().backward()
+F.softplus(-D(video, dtype=torch.bfloat16)).mean().backward()       # (the discriminator in the compute dtype too: rounds 3-4 ran it in float32 here)
 torch.cuda.synchronize()
 U._launch = orig
 rows = []
