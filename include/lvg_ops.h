@@ -456,6 +456,22 @@ int lvg_video_from_uint8(const void* bytes, void* video, const uint8_t* flip, in
 int lvg_noise_filter_bank(const float* noise, const float* bankP, const int* pairOff, const float* scale, float* out,
                           int rows, int length, int frames, int filters, int taps, int groups, int maxPairs, void* stream);
 
+/*
+ * 1 x 1 convolutions with a THIN side of 1 .. 4 channels on channels-last 16-bit frames (csrc/pointwise_thin.hip): the
+ * generator's ToRGB (model/generator_lres.py:600-640: a [3, C, 1, 1, 1] weight) and the discriminator's first layer
+ * (model/discriminator_lres.py:169, Conv3dLayer(3, 32, 1, 1)) with their gradients -- HBM streams over the wide tensor.
+ * pixels = frames * H * W; wide = 8 / 16 / 32 / 64 / 128 channels; w float32 [thin, wide]; float32 accumulation.
+ *   lvg_pointwise_thin_out:   y [pixels, thin] = x [pixels, wide] . w^T         (x 16-byte aligned)
+ *   lvg_pointwise_thin_in:    y [pixels, wide] = x [pixels, thin] . w           (y 16-byte aligned)
+ *   lvg_pointwise_thin_wgrad: partial [blocks, thin, wide] float32, sum over blocks = thinT^T . wideT  (wideT [pixels, wide],
+ *                             thinT [pixels, thin]); blocks = lvg_pointwise_thin_wgrad_blocks(pixels, wide); every workgroup
+ *                             owns a contiguous pixel range and reduces in a fixed order (reproducible).
+ */
+int lvg_pointwise_thin_out(const void* x, const float* w, void* y, int64_t pixels, int wide, int thin, int dtype, void* stream);
+int lvg_pointwise_thin_in(const void* x, const float* w, void* y, int64_t pixels, int wide, int thin, int dtype, void* stream);
+int lvg_pointwise_thin_wgrad_blocks(int64_t pixels, int wide);
+int lvg_pointwise_thin_wgrad(const void* wideT, const void* thinT, float* partial, int64_t pixels, int wide, int thin, int dtype, int blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

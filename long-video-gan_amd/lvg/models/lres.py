@@ -30,7 +30,7 @@ import contextlib
 
 from .. import ddp
 
-from torch_utils.ops import bias_act, conv3d_frames, noise_bank, style_prep, upfirdn2d, weight_prep
+from torch_utils.ops import bias_act, conv3d_frames, noise_bank, pointwise_thin, style_prep, upfirdn2d, weight_prep
 from torch_utils.ops.modconv_epilogue import dual_supported, modconv_epilogue, modconv_epilogue_dual, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
@@ -393,6 +393,9 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
     weight [Co, Ci, kt, kh, kw] in the compute dtype."""
     if POINTWISE_GEMM and tuple(weight.shape[2:]) == (1, 1, 1):
         return pointwise_conv(x, weight[:, :, 0, 0, 0])
+    if THIN_POINTWISE and not SECOND_ORDER and tuple(weight.shape[2:]) == (1, 1, 1) and pointwise_thin.supported(x, weight[:, :, 0, 0, 0]):
+        # 3-channel side (ToRGB, the discriminator's first layer): streaming kernels for all three passes (csrc/pointwise_thin.hip)
+        return pointwise_thin.pointwise_thin(x, weight[:, :, 0, 0, 0])
     if SECOND_ORDER and _hand_second_order_takes(x, weight, padding_hw):
         return _HandConv.apply(x, weight, n)
     return _TemporalConvFrames.apply(x, weight, n, tuple(padding_hw))
@@ -585,6 +588,8 @@ POINTWISE_HAND = os.environ.get('LVG_POINTWISE_HAND', '1') == '1'
 # their weight gradient as one GEMM over the pixel matrices: measured SLOWER (50.4 vs 44.3 ms per step, gpurun_out/r03_pair_ab.log: the
 # library GEMM on a [Co, pixels] x [pixels, Ci] product with 10^5 .. 10^6 pixels); kept as a switch
 POINTWISE_WGRAD_GEMM = os.environ.get('LVG_POINTWISE_WGRAD_GEMM', '0') == '1'
+# 1 x 1 convolutions with a 3-channel side on the streaming kernels of csrc/pointwise_thin.hip instead of the library's implicit-GEMM kernels
+THIN_POINTWISE = os.environ.get('LVG_THIN_POINTWISE', '1') == '1'
 
 
 def pointwise_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

@@ -64,6 +64,10 @@ _SIGNATURES = {
     'lvg_weight_prep2d': [_vp] * 5 + [_i32] * 5 + [_f32, _i32, _vp],
     'lvg_weight_prep2d_backward': [_vp] * 5 + [_i32] * 5 + [_f32, _vp],
     'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
+    'lvg_pointwise_thin_out': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    'lvg_pointwise_thin_in': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    'lvg_pointwise_thin_wgrad_blocks': [_i64, _i32],
+    'lvg_pointwise_thin_wgrad': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     'lvg_noise_filter_bank': [_vp] * 5 + [_i32] * 7 + [_vp],
     'lvg_tapconv_epilogue_backward': [_vp] * 10 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
 }

@@ -53,19 +53,36 @@ def pack_bank(bank: torch.Tensor):
 
 
 class PackedBank:
-    """Cache of `pack_bank` keyed by the bank tensor's identity and version (a `load_state_dict` into the buffer bumps the version)."""
+    """Cache of `pack_bank` keyed by the bank tensor's storage and version (a `load_state_dict` into the buffer bumps the version).
+
+    The packed tensors are baked into any hipGraph that captured a forward pass, so they are NEVER replaced while their layout still fits: a repack
+    after a version bump is copied INTO the existing tensors (trainers that capture phases restore every buffer with `copy_` after their eager
+    warm-up pass, which bumps the version of this constant buffer -- replacing the tensors there freed memory an earlier capture still read:
+    a GPU memory fault on its next replay). Tensors of a layout that no longer fits are retired, not freed. While a capture is running a version
+    bump alone does not repack (packing reads the bank on the host)."""
 
     def __init__(self):
-        self.key = None
+        self.where = None
+        self.version = None
         self.value = None
+        self._retired = []
 
     def get(self, bank: torch.Tensor):
-        key = (bank.data_ptr(), bank._version, bank.device, tuple(bank.shape))
-        if key != self.key:
-            assert not (bank.is_cuda and torch.cuda.is_current_stream_capturing()), \
-                'noise_bank: the bank has to be packed (a host read) before the forward pass is captured into a graph: run one eager pass first'
-            self.value = pack_bank(bank)
-            self.key = key
+        where = (bank.data_ptr(), bank.device, tuple(bank.shape))
+        capturing = bank.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.value is not None and where == self.where and (bank._version == self.version or capturing):
+            return self.value
+        assert not capturing, 'noise_bank: the bank has to be packed (a host read) before the forward pass is captured into a graph: run one eager pass first'
+        new = pack_bank(bank)
+        old = self.value
+        if old is not None and old[0].device == new[0].device and old[0].shape == new[0].shape and old[1].shape == new[1].shape and old[2] == new[2]:
+            old[0].copy_(new[0])
+            old[1].copy_(new[1])
+        else:
+            if old is not None:
+                self._retired.append(old)
+            self.value = new
+        self.where, self.version = where, bank._version
         return self.value
 
 

@@ -358,6 +358,17 @@ def noise_filter_bank(noise, bank, scale=None):
     return out
 
 
+def pointwise(x, w):
+    """1 x 1 convolution on channels-last pixels (orc_pointwise): x [M, Ci], w [Co, Ci] -> [M, Co] float64."""
+    x, w = _f64(x), _f64(w)
+    m, ci = x.shape
+    co = w.shape[0]
+    out = np.empty((m, co), dtype=np.float64)
+    rc = lib().orc_pointwise(x.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(m), ci, co)
+    assert rc == 0
+    return out
+
+
 def ada_warp(x, g_inv, f, margins):
     """ADA geometric stage (orc_ada_warp; reference ada_augment.py:271-304): x [N, K, H, W], g_inv [N, 3, 3] (pixel units, centred),
     f [taps] the normalised 1-D low-pass, margins (mx0, my0, mx1, my1) the reflect padding of :283 -> [N, K, H, W]."""

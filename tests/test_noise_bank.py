@@ -137,3 +137,47 @@ def test_generator_takes_the_kernel_gpu(monkeypatch):
     mod = lres.BlurredNoise().cuda()
     out = mod(2, 16)
     assert out.shape == (2, 1024, 16) and len(calls) == 1
+
+
+def test_packed_bank_is_repacked_in_place_cpu():
+    """A version bump of the bank (what a trainer's buffer roll-back does) must not replace the packed tensors: captured graphs hold their addresses."""
+    g, _ = _golden('norm1')                                           # two groups; the first one is shorter than the rows
+    bank = torch.from_numpy(g['norm1/bank']).clone()
+    cache = nb.PackedBank()
+    first = cache.get(bank)
+    ptrs = (first[0].data_ptr(), first[1].data_ptr())
+    assert cache.get(bank) is first
+    bank.copy_(bank.clone())                                          # same values, new version
+    again = cache.get(bank)
+    assert again is first and (again[0].data_ptr(), again[1].data_ptr()) == ptrs
+    bank[0, -1] += 1.0                                                # new values, same layout: visible through the same tensors
+    changed = cache.get(bank)
+    assert changed is first and float(changed[0].abs().sum()) != 0 and torch.equal(changed[0], nb.pack_bank(bank)[0])
+    bank[0, 0] = 1.0                                                  # filter 0 now has K taps: another layout -> new tensors, old ones kept alive
+    other = cache.get(bank)
+    assert other is not first and cache._retired and cache._retired[0] is first
+
+
+@pytest.mark.gpu
+def test_graph_survives_a_repack_gpu():
+    """Regression: capture a pass, bump the bank's version and run an eager pass (which repacks), replay -- the graph must still read valid memory."""
+    from lvg.models import lres
+    mod = lres.BlurredNoise().cuda()
+    noise = torch.randn(1, mod.noise_channels, 64 + mod.kernel_size - 1, device='cuda')
+    want = mod.blur(noise).clone()                                    # eager pass: packs
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = mod.blur(noise)
+    torch.cuda.current_stream().wait_stream(side)
+    mod.blur_filters.copy_(mod.blur_filters.clone())                  # what a roll-back of the buffers does
+    for _ in range(3):
+        eager = mod.blur(noise)                                       # repacks (in place)
+        junk = [torch.empty(1 << 20, device='cuda') for _ in range(8)]   # churn the allocator
+        del junk
+    torch.cuda.empty_cache()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(eager, want)

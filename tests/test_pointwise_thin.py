@@ -1,0 +1,100 @@
+"""1 x 1 convolutions with a 3-channel side (csrc/pointwise_thin.hip, torch_utils/ops/pointwise_thin.py; reference model/generator_lres.py:600-640 ToRGB,
+model/discriminator_lres.py:169 with kernel size 1). CPU: the oracle's definition against F.conv2d. GPU: all three passes against the oracle (one output
+rounding), reproducibility of the weight gradient, and that the networks take the kernels."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from torch_utils.ops import pointwise_thin as pt
+
+
+def test_oracle_is_the_1x1_convolution_cpu(oracle):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 16, 5, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 16, generator=g, dtype=torch.float64)
+    want = F.conv2d(x, w[:, :, None, None]).permute(0, 2, 3, 1).reshape(-1, 3)
+    got = oracle.pointwise(x.permute(0, 2, 3, 1).reshape(-1, 16).numpy(), w.numpy())
+    np.testing.assert_allclose(got, want.numpy(), rtol=1e-12, atol=1e-12)
+
+
+# (frames, H, W, Ci, Co): ToRGB and the discriminator's first layer at small sizes, every wide width, ragged pixel counts
+CASES = [(3, 5, 7, 64, 3), (3, 5, 7, 3, 32), (2, 9, 16, 128, 3), (1, 3, 3, 8, 1), (5, 4, 6, 4, 16), (2, 36, 64, 64, 3), (2, 64, 64, 3, 32), (1, 1, 1, 2, 8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', CASES)
+def test_three_passes_match_oracle_gpu(oracle, case, dtype):
+    f, h, w, ci, co = case
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(f, ci, h, w, generator=g).to(dtype)
+    wt = (torch.randn(co, ci, generator=g) / ci ** 0.5).to(dtype)
+    gy = torch.randn(f, co, h, w, generator=g).to(dtype)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = wt.cuda().requires_grad_(True)
+    if ci == 1 or co == 1 or xd.stride() != (h * w * ci, 1, w * ci, ci):
+        xd = torch.empty_strided((f, ci, h, w), (h * w * ci, 1, w * ci, ci), dtype=dtype, device='cuda').copy_(x).requires_grad_(True)
+    assert pt.supported(xd, wd)
+    y = pt.pointwise_thin(xd, wd)
+    assert y.dtype == dtype and y.stride() == (h * w * co, 1, w * co, co)
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.cuda())
+    xm = x.double().permute(0, 2, 3, 1).reshape(-1, ci).numpy()
+    gm = gy.double().permute(0, 2, 3, 1).reshape(-1, co).numpy()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # one rounding of the output type
+    want_y = oracle.pointwise(xm, wt.double().numpy())
+    got_y = y.detach().double().cpu().permute(0, 2, 3, 1).reshape(-1, co).numpy()
+    assert np.abs(got_y - want_y).max() <= eps * np.abs(want_y).max() + 1e-6
+    want_gx = oracle.pointwise(gm, wt.double().t().contiguous().numpy())
+    got_gx = gx.double().cpu().permute(0, 2, 3, 1).reshape(-1, ci).numpy()
+    assert np.abs(got_gx - want_gx).max() <= eps * np.abs(want_gx).max() + 1e-6
+    want_gw = gm.T @ xm
+    assert np.abs(gw.double().cpu().numpy() - want_gw).max() <= eps * np.abs(want_gw).max() + 1e-5 * np.sqrt(f * h * w)
+    # reproducible: fixed pixel ranges, fixed summation order
+    gw2 = torch.autograd.grad(pt.pointwise_thin(xd, wd), wd, gy.cuda())[0]
+    assert torch.equal(gw, gw2)
+
+
+@pytest.mark.gpu
+def test_networks_take_the_kernels_gpu(monkeypatch):
+    from lvg.models import lres
+    calls = []
+    real = pt.pointwise_thin
+    monkeypatch.setattr(lres.pointwise_thin, 'pointwise_thin', lambda x, w: (calls.append(tuple(w.shape)), real(x, w))[1])
+    torch.manual_seed(0)
+    G = lres.VideoGenerator().cuda()
+    D = lres.VideoDiscriminator(seq_length=16, max_edge=64).cuda()
+    video = G(1, 16, dtype=torch.bfloat16)
+    D(video, dtype=torch.bfloat16).sum().backward()
+    assert (3, 64) in calls and (32, 3) in calls, calls
+
+
+@pytest.mark.gpu
+def test_model_gradients_match_library_route_gpu():
+    """Generator + discriminator, bfloat16: the same update with the thin kernels on and off. Two bf16 evaluations of these networks differ from run
+    to run where library kernels with atomics remain (reproducibility), so the yardstick is the distance between two library-route runs."""
+    from lvg.models import lres
+
+    def run(on):
+        lres.THIN_POINTWISE = on
+        try:
+            torch.manual_seed(0)
+            G = lres.VideoGenerator().cuda()
+            D = lres.VideoDiscriminator(seq_length=16, max_edge=64).cuda()
+            video = G(1, 16, dtype=torch.bfloat16)
+            F.softplus(-D(video, dtype=torch.bfloat16)).mean().backward()
+            return (video.detach().float(), G.to_rgb.weight.grad.detach().float().clone(), D.blocks[0].conv_vid.weight.grad.detach().float().clone())
+        finally:
+            lres.THIN_POINTWISE = True
+
+    thin, lib_a, lib_b = run(True), run(False), run(False)
+    for a, b, c, name in zip(thin, lib_a, lib_b, ('video', 'ToRGB weight gradient', 'first-layer weight gradient')):
+        scale = float(b.abs().max())
+        err, noise = float((a - b).abs().max()) / scale, float((c - b).abs().max()) / scale
+        print(f'[measured] {name}: thin vs library {err:.3g}, library vs library {noise:.3g}')
+        assert err < max(4 * noise, 3e-2), (name, err, noise)
+    # direction of the gradients (insensitive to the handful of elements that carry the run-to-run noise)
+    for a, b in zip(thin[1:], lib_a[1:]):
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.98, cos
