@@ -472,6 +472,19 @@ int lvg_pointwise_thin_in(const void* x, const float* w, void* y, int64_t pixels
 int lvg_pointwise_thin_wgrad_blocks(int64_t pixels, int wide);
 int lvg_pointwise_thin_wgrad(const void* wideT, const void* thinT, float* partial, int64_t pixels, int wide, int thin, int dtype, int blocks, void* stream);
 
+/*
+ * Weight gradient of a 1 x 1 convolution on channels-last 16-bit frames (csrc/pointwise_wgrad.hip): what autograd derives for the skip
+ * convolutions of model/generator_lres.py:558-577 and model/discriminator_lres.py:169 (kernel size 1),
+ *   part [splits, co, ci] float32, sum over splits = sum over pixels dy[m][co] * x[m][ci]
+ * on the matrix cores with the pixel index as K (both operands staged as they lie, transpose reads). ci, co multiples of 64, pixels a
+ * multiple of 8; x_pixel_stride / dy_pixel_stride = elements between consecutive pixels (0: dense; channel slices and pixel-pair views
+ * are fine), multiples of 8; zeros = 128 bytes of zeros in device memory; splits = lvg_pointwise_wgrad_splits(pixels, ci, co)
+ * (0 = unsupported). Every split owns a contiguous pixel range; the caller adds the splits in order (reproducible).
+ */
+int lvg_pointwise_wgrad_splits(int64_t pixels, int ci, int co);
+int lvg_pointwise_wgrad(const void* x, const void* dy, float* part, const void* zeros, int64_t pixels, int ci, int co,
+                        int64_t x_pixel_stride, int64_t dy_pixel_stride, int splits, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -393,6 +393,11 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
     weight [Co, Ci, kt, kh, kw] in the compute dtype."""
     if POINTWISE_GEMM and tuple(weight.shape[2:]) == (1, 1, 1):
         return pointwise_conv(x, weight[:, :, 0, 0, 0])
+    if (POINTWISE_HAND_ALL and POINTWISE_HAND and TAP_STACK and not SECOND_ORDER and tuple(weight.shape[2:]) == (1, 1, 1) and tuple(padding_hw) == (0, 0)
+            and x.dim() == 4 and x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last) and _hand_conv_takes(x, weight, (0, 0))):
+        # every 1 x 1 convolution the hand-written kernels can take (the discriminator's skip convolutions reach this function, the generator's call
+        # pointwise_conv themselves): forward + data gradient on conv3d_igemm, weight gradient on pointwise_wgrad
+        return pointwise_conv(x, weight[:, :, 0, 0, 0])
     if THIN_POINTWISE and not SECOND_ORDER and tuple(weight.shape[2:]) == (1, 1, 1) and pointwise_thin.supported(x, weight[:, :, 0, 0, 0]):
         # 3-channel side (ToRGB, the discriminator's first layer): streaming kernels for all three passes (csrc/pointwise_thin.hip)
         return pointwise_thin.pointwise_thin(x, weight[:, :, 0, 0, 0])
@@ -588,6 +593,10 @@ POINTWISE_HAND = os.environ.get('LVG_POINTWISE_HAND', '1') == '1'
 # their weight gradient as one GEMM over the pixel matrices: measured SLOWER (50.4 vs 44.3 ms per step, gpurun_out/r03_pair_ab.log: the
 # library GEMM on a [Co, pixels] x [pixels, Ci] product with 10^5 .. 10^6 pixels); kept as a switch
 POINTWISE_WGRAD_GEMM = os.environ.get('LVG_POINTWISE_WGRAD_GEMM', '0') == '1'
+# weight gradient of the 1 x 1 convolutions that run forward + data gradient on the hand-written kernel: the K-loop of the weight-gradient kernel
+# without taps (csrc/pointwise_wgrad.hip) instead of the library's split-K kernels and their helper launches
+POINTWISE_WGRAD_HAND = os.environ.get('LVG_POINTWISE_WGRAD_HAND', '1') == '1'
+POINTWISE_HAND_ALL = os.environ.get('LVG_POINTWISE_HAND_ALL', '1') == '1'      # ... also for the 1 x 1 convolutions that arrive through temporal_conv_frames
 # 1 x 1 convolutions with a 3-channel side on the streaming kernels of csrc/pointwise_thin.hip instead of the library's implicit-GEMM kernels
 THIN_POINTWISE = os.environ.get('LVG_THIN_POINTWISE', '1') == '1'
 
@@ -698,6 +707,12 @@ class _TapConvEpilogue(torch.autograd.Function):
             gw = conv3d_frames.conv3d_frames_split32_wgrad(xc, dy, kt, kh, kw, n)
         elif hand_w:
             gw = conv3d_frames.conv3d_frames_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
+        if need[1] and not hand_w and POINTWISE_WGRAD_HAND and kt == kh == kw == 1 and conv3d_frames.pointwise_wgrad_supported(xc, dy):
+            # weight gradient of a 1 x 1 convolution on the matrix cores with the pixel index as K (csrc/pointwise_wgrad.hip): no zero-fill /
+            # cast helper launches of the library's split-K kernels
+            gw = conv3d_frames.pointwise_wgrad(xc, dy).to(weight.dtype).reshape(co, ci, 1, 1, 1)
+            hand_w = True
+            stacked = need[0] and not hand_d
         if stacked and POINTWISE_WGRAD_GEMM and kt == kh == kw == 1 and not (need[0] and not hand_d) and conv3d_frames._pixel_stride(xc) == ci:
             # weight gradient of a 1 x 1 convolution = one GEMM over the pixel matrices (views of the channels-last tensors): no zero-fill /
             # cast helper launches of the library's split-K convolution kernels; float32 accumulation, one rounding to the compute dtype

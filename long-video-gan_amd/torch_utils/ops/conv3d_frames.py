@@ -238,6 +238,36 @@ def _wgrad_ref(x, dy, kt, kh, kw, shift):
     return torch.autograd.grad(y, w, dy.float())[0]
 
 
+def pointwise_wgrad_supported(x, dy):
+    """x [(T N), Ci, H, W], dy [(T N), Co, H, W]: 16-bit channels-last GPU tensors (or channel slices), channels multiples of 64, pixels a multiple of 8."""
+    if not (x.is_cuda and dy.is_cuda and x.dim() == 4 and dy.dim() == 4 and x.dtype == dy.dtype and x.dtype in (torch.float16, torch.bfloat16)):
+        return False
+    if x.shape[0] != dy.shape[0] or x.shape[2:] != dy.shape[2:] or not _init():
+        return False
+    sx, sy = _pixel_stride(x), _pixel_stride(dy)
+    if sx is None or sy is None or sx % 8 or sy % 8 or x.data_ptr() % 16 or dy.data_ptr() % 16:
+        return False
+    pixels = x.shape[0] * x.shape[2] * x.shape[3]
+    return int(_hip.lib().lvg_pointwise_wgrad_splits(pixels, x.shape[1], dy.shape[1])) > 0
+
+
+def pointwise_wgrad(x, dy):
+    """Weight gradient [Co, Ci] (float32) of a 1 x 1 convolution: sum over pixels dy[m][co] x[m][ci] (csrc/pointwise_wgrad.hip)."""
+    assert pointwise_wgrad_supported(x, dy), 'pointwise_wgrad: no hand-written kernel for this shape / dtype / layout'
+    f, ci, h, w = x.shape
+    co = dy.shape[1]
+    pixels = f * h * w
+    splits = int(_hip.lib().lvg_pointwise_wgrad_splits(pixels, ci, co))
+    part = torch.empty((splits, co, ci), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _hip.lib().lvg_pointwise_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), _zeros(x.device).data_ptr(), pixels, ci, co,
+                                            _pixel_stride(x), _pixel_stride(dy), splits, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+    _hip.check(rc, 'lvg_pointwise_wgrad')
+    stats['flops'] += 2 * pixels * co * ci
+    stats['launches'] += 1
+    return part.sum(0) if splits > 1 else part[0]                    # fixed summation order: reproducible
+
+
 def conv3d_frames_wgrad(x, dy, kt, kh, kw, shift):
     """Weight gradient [Co, Ci, kt, kh, kw] (float32) of `conv3d_frames_forward`'s contraction:
     x [(T N), Ci, H, W], dy [(T N), Co, H, W], both channels-last (or channel slices of channels-last tensors)."""

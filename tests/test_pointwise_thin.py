@@ -98,3 +98,52 @@ def test_model_gradients_match_library_route_gpu():
     for a, b in zip(thin[1:], lib_a[1:]):
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         assert cos > 0.98, cos
+
+
+# ---- weight gradient of the wide 1 x 1 convolutions (csrc/pointwise_wgrad.hip) ----------------------------------------------------------------
+# (frames, H, W, Ci, Co): skip convolutions of both networks at small sizes; several channel tiles, a last K-step that is not full, one step only
+WGRAD_CASES = [(3, 4, 8, 64, 64), (2, 9, 16, 128, 64), (5, 3, 8, 64, 192), (1, 2, 4, 64, 64), (7, 5, 8, 256, 128), (16, 36, 64, 64, 64)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_pointwise_wgrad_matches_oracle_gpu(oracle, case, dtype):
+    from torch_utils.ops import conv3d_frames as cf
+    f, h, w, ci, co = case
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(f, ci, h, w, generator=g).to(dtype)
+    dy = torch.randn(f, co, h, w, generator=g).to(dtype)
+    xd, dyd = x.cuda().contiguous(memory_format=torch.channels_last), dy.cuda().contiguous(memory_format=torch.channels_last)
+    assert cf.pointwise_wgrad_supported(xd, dyd)
+    gw = cf.pointwise_wgrad(xd, dyd)
+    assert gw.shape == (co, ci) and gw.dtype == torch.float32
+    xm = x.double().permute(0, 2, 3, 1).reshape(-1, ci).numpy()
+    gm = dy.double().permute(0, 2, 3, 1).reshape(-1, co).numpy()
+    want = oracle.pointwise(gm.T.copy(), xm.T.copy())                 # [co, pixels] x [ci, pixels]^T: the same contraction through the oracle's definition
+    err = np.abs(gw.double().cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 2e-5, err                                            # exact products of 16-bit operands, float32 accumulation
+    assert torch.equal(gw, cf.pointwise_wgrad(xd, dyd))               # fixed pixel ranges, fixed summation order
+    # channel slices of wider tensors (what the tap-stacked backward hands over) and pixel-pair views
+    wide = torch.randn(f, 2 * co, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    sl = wide[:, co:2 * co]
+    assert cf.pointwise_wgrad_supported(xd, sl)
+    want2 = sl.double().permute(0, 2, 3, 1).reshape(-1, co).t() @ xd.double().permute(0, 2, 3, 1).reshape(-1, ci)
+    err2 = float((cf.pointwise_wgrad(xd, sl).double() - want2).abs().max() / want2.abs().max())
+    assert err2 < 2e-5, err2
+
+
+@pytest.mark.gpu
+def test_discriminator_skip_convolutions_take_the_hand_kernels_gpu(monkeypatch):
+    from lvg.models import lres
+    from torch_utils.ops import conv3d_frames as cf
+    shapes = []
+    real = cf.pointwise_wgrad
+    monkeypatch.setattr(cf, 'pointwise_wgrad', lambda x, dy: (shapes.append((x.shape[1], dy.shape[1])), real(x, dy))[1])
+    torch.manual_seed(0)
+    D = lres.VideoDiscriminator(seq_length=16, max_edge=64).cuda()
+    video = torch.randn(1, 3, 16, 36, 64, device='cuda', requires_grad=True)
+    D(video, dtype=torch.bfloat16).sum().backward()
+    # the 32 -> 64 skip runs as pixel pairs (64 -> 128) next to the 64 -> 128 one; the deeper skips of this one-clip batch have fewer tiles than
+    # HAND_CONV_MIN_TILES and stay on the library
+    assert shapes.count((64, 128)) >= 2, shapes
