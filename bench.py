@@ -141,7 +141,15 @@ class OpTimer:
              lambda args, out, kw: kw.get('alg_flops') or 2 * args[0].shape[0] * args[2] * args[3] * args[1].shape[2] * args[1].shape[3] * 9)
         wrap(conv2d_frames, 'conv2d_wgrad', lambda a: 'conv2d_wgrad',
              lambda args, out, kw: kw.get('alg_flops') or 2 * args[1].shape[0] * args[1].shape[1] * args[1].shape[2] * args[1].shape[3] * args[0].shape[3] * 9)
-        self.flop_ops = {'conv3d_igemm', 'conv3d_igemm_1x1', 'conv3d_wgrad', 'conv2d_igemm', 'conv2d_wgrad'}
+        # round 5: noise filter bank (float32 MFMA: FLOPs on the non-zero taps of the bank), the thin 1 x 1 kernels (streams over the wide tensor) and
+        # the weight gradient of the wide 1 x 1 convolutions (a stream over x and dy)
+        from torch_utils.ops import noise_bank, pointwise_thin
+        wrap(noise_bank, 'noise_filter_bank', lambda a: 'noise_filter_bank',
+             lambda args, out, kw: 2 * args[0].shape[0] * out.shape[2] * int((args[1] != 0).sum()))
+        wrap(pointwise_thin, '_apply', lambda a: 'pointwise_thin', lambda args, out, kw: (args[0].numel() + out.numel()) * out.element_size())
+        wrap(pointwise_thin, '_wgrad', lambda a: 'pointwise_thin', lambda args, out, kw: (args[0].numel() + args[1].numel()) * args[0].element_size())
+        wrap(conv3d_frames, 'pointwise_wgrad', lambda a: 'pointwise_wgrad', lambda args, out, kw: (args[0].numel() + args[1].numel()) * args[0].element_size())
+        self.flop_ops = {'conv3d_igemm', 'conv3d_igemm_1x1', 'conv3d_wgrad', 'conv2d_igemm', 'conv2d_wgrad', 'noise_filter_bank'}
 
     def measure(self, reps=3):
         """Time the recorded launches per op: ALL launches of that op from the step, once each and in step

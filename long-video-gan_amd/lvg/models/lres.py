@@ -687,7 +687,10 @@ class _TapConvEpilogue(torch.autograd.Function):
         xc = _cl(x)
         hand_d = need[0] and HAND_CONV_DGRAD and _hand_conv_shape_ok(xc, co, ci, weight, pad)
         hand_w = need[1] and HAND_CONV_WGRAD and _hand_wgrad_shape_ok(xc, co, weight, pad)
-        stacked = (need[0] and not hand_d) or (need[1] and not hand_w)      # MIOpen needs the gradient scattered over the taps
+        # frames of a few pixels (the two 3 x 4-pixel layers): the weight-gradient kernel cannot walk them (its K-step of 64 / W image rows allows two frame
+        # changes), so the taps are unrolled into channels -- cheap at this size -- and the gradient is ONE pixel-index GEMM on pointwise_wgrad
+        small_w = need[1] and not hand_w and _small_frame_wgrad_takes(xc, co, weight, pad)
+        stacked = (need[0] and not hand_d) or (need[1] and not hand_w and not small_w)      # MIOpen needs the gradient scattered over the taps
         if ctx.plain and (kt == 1 or not stacked):
             dz, d_pre, d_post, d_sum = dout.contiguous(memory_format=torch.channels_last), None, None, None     # a bare convolution: nothing to undo
         else:
@@ -707,6 +710,9 @@ class _TapConvEpilogue(torch.autograd.Function):
             gw = conv3d_frames.conv3d_frames_split32_wgrad(xc, dy, kt, kh, kw, n)
         elif hand_w:
             gw = conv3d_frames.conv3d_frames_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
+        if small_w:
+            gw = small_frame_wgrad(xc, dy, kt, kh, kw, n).to(weight.dtype)
+            hand_w = True
         if need[1] and not hand_w and POINTWISE_WGRAD_HAND and kt == kh == kw == 1 and conv3d_frames.pointwise_wgrad_supported(xc, dy):
             # weight gradient of a 1 x 1 convolution on the matrix cores with the pixel index as K (csrc/pointwise_wgrad.hip): no zero-fill /
             # cast helper launches of the library's split-K kernels
@@ -731,6 +737,52 @@ class _TapConvEpilogue(torch.autograd.Function):
             assert act == 'linear' and clamp is None and post is None, 'residual gradient: linear epilogue only'
             d_res = dout
         return gx, gw, (d_pre if need[2] else None), d_b, d_res, (d_post if need[5] else None)
+
+
+# Measured SLOWER than the library's tap-stacked weight gradient (40.33 against 40.13 ms per step, profiles/r05_small_frame_ab.log: 1 728 tiles of 36 K-steps
+# with four MFMAs each) and left switched off; exact (tests/test_pointwise_thin.py).
+SMALL_FRAME_WGRAD = os.environ.get('LVG_SMALL_FRAME_WGRAD', '0') == '1'
+SMALL_FRAME_PIXELS = 16          # frames up to this many pixels take the unrolled form (27 x the activation bytes: 64 MB for the 3 x 4-pixel layers)
+
+
+def _small_frame_wgrad_takes(x: torch.Tensor, co: int, weight: torch.Tensor, padding_hw) -> bool:
+    if not (SMALL_FRAME_WGRAD and POINTWISE_WGRAD_HAND and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)):
+        return False
+    f, ci, h, w = x.shape
+    kt, kh, kw = weight.shape[2:]
+    if h * w > SMALL_FRAME_PIXELS or tuple(padding_hw) != (kh // 2, kw // 2) or kh % 2 == 0 or kw % 2 == 0 or kt % 2 == 0 or kt * kh * kw == 1:
+        return False
+    return ci % 64 == 0 and co % 64 == 0 and (f * h * w) % 8 == 0 and kt * kh * kw * ci <= 65536
+
+
+def unroll_taps(x: torch.Tensor, kt: int, kh: int, kw: int, n: int) -> torch.Tensor:
+    """x [(T N), Ci, H, W] -> [(T N), kt kh kw Ci, H, W] channels-last: channel block (dt, dh, dw) holds x shifted by that tap ('same' zero padding in
+    rows and columns, zero frames outside the clip: a temporal tap is a shift by whole time steps = n frames)."""
+    f, ci, h, w = x.shape
+    pt = kt // 2
+    xp = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2))
+    blocks = []
+    for dt in range(kt):
+        s = (dt - pt) * n                                             # source frame = frame + s
+        if abs(s) >= f:
+            xs = torch.zeros_like(xp)
+        elif s > 0:
+            xs = torch.cat((xp[s:], torch.zeros_like(xp[:s])), dim=0)
+        elif s < 0:
+            xs = torch.cat((torch.zeros_like(xp[:-s]), xp[:f + s]), dim=0)
+        else:
+            xs = xp
+        for dh in range(kh):
+            for dw in range(kw):
+                blocks.append(xs[:, :, dh:dh + h, dw:dw + w])
+    return torch.cat(blocks, dim=1).contiguous(memory_format=torch.channels_last)
+
+
+def small_frame_wgrad(x: torch.Tensor, dy: torch.Tensor, kt: int, kh: int, kw: int, n: int) -> torch.Tensor:
+    """Weight gradient [Co, Ci, kt, kh, kw] (float32) of the frames convolution for frames of a few pixels: gw = dy^T . unroll_taps(x)."""
+    ci, co = x.shape[1], dy.shape[1]
+    gw = conv3d_frames.pointwise_wgrad(unroll_taps(_cl(x), kt, kh, kw, n), dy)          # [Co, kt kh kw Ci]
+    return gw.reshape(co, kt, kh, kw, ci).permute(0, 4, 1, 2, 3)
 
 
 def temporal_conv_epilogue(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw, pre: Optional[torch.Tensor] = None,

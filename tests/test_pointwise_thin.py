@@ -147,3 +147,40 @@ def test_discriminator_skip_convolutions_take_the_hand_kernels_gpu(monkeypatch):
     # the 32 -> 64 skip runs as pixel pairs (64 -> 128) next to the 64 -> 128 one; the deeper skips of this one-clip batch have fewer tiles than
     # HAND_CONV_MIN_TILES and stay on the library
     assert shapes.count((64, 128)) >= 2, shapes
+
+
+# ---- weight gradient of frames of a few pixels: taps unrolled into channels + pointwise_wgrad (lres.small_frame_wgrad) --------------------------
+def test_unrolled_taps_give_the_weight_gradient_cpu(oracle):
+    from lvg.models import lres
+    g = torch.Generator().manual_seed(3)
+    t, n, ci, co, h, w, kt = 5, 2, 4, 3, 3, 4, 3
+    x = torch.randn(t * n, ci, h, w, generator=g, dtype=torch.float64)
+    dy = torch.randn(t * n, co, h, w, generator=g, dtype=torch.float64)
+    col = lres.unroll_taps(x.contiguous(memory_format=torch.channels_last), kt, 3, 3, n)
+    assert col.shape == (t * n, kt * 9 * ci, h, w) and col.is_contiguous(memory_format=torch.channels_last)
+    gw = torch.einsum('fohw,fkhw->ok', dy, col).reshape(co, kt, 3, 3, ci).permute(0, 4, 1, 2, 3)
+    np.testing.assert_allclose(gw.numpy(), oracle.conv3d_frames_wgrad(x.numpy(), dy.numpy(), kt, 3, 3, shift=n), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(6, 4, 64, 64, 3, 4, 3), (8, 2, 128, 64, 3, 4, 1), (4, 2, 64, 128, 2, 4, 5), (24, 8, 512, 512, 3, 4, 3)])
+def test_small_frame_wgrad_matches_oracle_gpu(oracle, case, dtype, monkeypatch):
+    from lvg.models import lres
+    monkeypatch.setattr(lres, 'SMALL_FRAME_WGRAD', True)              # (off by default: measured slower than the library on the two layers it applies to)
+    t, n, ci, co, h, w, kt = case
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(t * n, ci, h, w, generator=g).to(dtype)
+    dy = torch.randn(t * n, co, h, w, generator=g).to(dtype)
+    xd, dyd = x.cuda().contiguous(memory_format=torch.channels_last), dy.cuda().contiguous(memory_format=torch.channels_last)
+    wt = torch.empty(co, ci, kt, 3, 3)
+    assert lres._small_frame_wgrad_takes(xd, co, wt, (1, 1))
+    gw = lres.small_frame_wgrad(xd, dyd, kt, 3, 3, n)
+    assert gw.shape == (co, ci, kt, 3, 3)
+    if ci * co <= 128 * 128:                                          # (the full-size case would take the scalar oracle minutes: float64 matmul instead)
+        want = torch.from_numpy(oracle.conv3d_frames_wgrad(x.double().numpy(), dy.double().numpy(), kt, 3, 3, shift=n))
+    else:
+        col = lres.unroll_taps(x.double().contiguous(memory_format=torch.channels_last), kt, 3, 3, n)
+        want = torch.einsum('fohw,fkhw->ok', dy.double(), col).reshape(co, kt, 3, 3, ci).permute(0, 4, 1, 2, 3)
+    err = float((gw.double().cpu() - want).abs().max() / want.abs().max())
+    assert err < 2e-5, err
