@@ -485,6 +485,16 @@ int lvg_pointwise_wgrad_splits(int64_t pixels, int ci, int co);
 int lvg_pointwise_wgrad(const void* x, const void* dy, float* part, const void* zeros, int64_t pixels, int ci, int co,
                         int64_t x_pixel_stride, int64_t dy_pixel_stride, int splits, int dtype, void* stream);
 
+/*
+ * Operand preparation of the float32 route (csrc/split32.hip): the reference trains the low-resolution networks in float32 with TF32 off
+ * (train_lres.py:267-269); here float32 tensors run on the 16-bit matrix cores as three bfloat16 parts t = t1 + t2 + t3 (t1 = bf16(t),
+ * t2 = bf16(t - t1), t3 = bf16(t - t1 - t2), round to nearest even). One pass over x [pixels, channels] float32 (x_pixel_stride elements
+ * between pixels, 0 = dense) writes out [pixels, blocks * channels] bfloat16 whose channel block k holds part (pattern >> 2 k) & 3:
+ * pattern 0x910 (blocks 6: parts 0 0 1 0 1 2) for a convolution input, 0x24 (blocks 3: parts 0 1 2) for the weight-gradient operands.
+ * channels a multiple of 8; pointers 16-byte aligned.
+ */
+int lvg_split32_stack(const float* x, void* out, int64_t pixels, int channels, int64_t x_pixel_stride, int blocks, int pattern, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,7 @@ _SIGNATURES = {
     'lvg_pointwise_thin_wgrad': [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     'lvg_pointwise_wgrad_splits': [_i64, _i32, _i32],
     'lvg_pointwise_wgrad': [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _i32, _vp],
+    'lvg_split32_stack': [_vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp],
     'lvg_noise_filter_bank': [_vp] * 5 + [_i32] * 7 + [_vp],
     'lvg_tapconv_epilogue_backward': [_vp] * 10 + [_i64, _i32, _i32, _i32, _i64, _i32, _i32, _f32, _f32, _f32, _vp],
 }

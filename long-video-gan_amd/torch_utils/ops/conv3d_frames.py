@@ -13,6 +13,8 @@ kt-stacked output channels and sums the taps in `lvg_tapconv_epilogue`).
 Launch-level interface (used by lvg.models.lres); CPU tensors and unsupported shapes take the explicit PyTorch
 composition below, which is also the definition the GPU tests compare against (next to the C oracle)."""
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -131,6 +133,25 @@ def split_bf16x3(t):
     return b1, b2, b3
 
 
+SPLIT_STACK_HIP = os.environ.get('LVG_SPLIT_STACK_HIP', '1') == '1'
+
+
+def split32_stack(x, parts):
+    """x [(T N), C, H, W] float32 -> [(T N), len(parts) C, H, W] bfloat16 channels-last whose channel block k holds part parts[k] (0 .. 2) of
+    `split_bf16x3(x)`: one pass (csrc/split32.hip) for channels-last GPU tensors with C % 8 == 0, else the tensor expressions. Bit-identical."""
+    xc = x.contiguous(memory_format=torch.channels_last)
+    f, c, h, w = xc.shape
+    if SPLIT_STACK_HIP and xc.is_cuda and xc.dtype == torch.float32 and c % 8 == 0 and _pixel_stride(xc) == c and xc.data_ptr() % 16 == 0 and _init():
+        out = torch.empty((f, len(parts) * c, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        pattern = sum(int(p) << (2 * k) for k, p in enumerate(parts))
+        with torch.cuda.device(x.device):
+            rc = _hip.lib().lvg_split32_stack(xc.data_ptr(), out.data_ptr(), f * h * w, c, c, len(parts), pattern, _hip.stream(x.device))
+        _hip.check(rc, 'lvg_split32_stack')
+        return out
+    xs = split_bf16x3(xc)
+    return torch.cat([xs[i] for i in parts], dim=1).contiguous(memory_format=torch.channels_last)
+
+
 def split32_shape_ok(frames, h, w, ci, co, kt, kh, kw):
     """Is there a float32-output kernel for a convolution with ci input / co output channels (before the six-fold stacking)?"""
     if ci % 64 or co % 64 or not (kt & 1 and kh & 1 and kw & 1):
@@ -155,8 +176,8 @@ def conv3d_frames_split32(x, weight, shift, pre=None, b=None, res=None, post=Non
     f, ci, h, w = x.shape
     co, _, kt, kh, kw = weight.shape
     assert split32_supported(x, weight), 'conv3d_frames_split32: no kernel for this shape'
-    xs, ws = split_bf16x3(x), split_bf16x3(weight)
-    x6 = torch.cat([xs[i] for i in _X6], dim=1).contiguous(memory_format=torch.channels_last)      # [f, 6 ci, h, w] bfloat16
+    ws = split_bf16x3(weight)
+    x6 = split32_stack(x, _X6)                                                                     # [f, 6 ci, h, w] bfloat16
     w6 = pack_weight(torch.cat([ws[i] for i in _W6], dim=1))                                       # [kt, kh, kw, co, 6 ci]
     out = torch.empty((f, co, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     ysum = torch.empty_like(out) if keep_sum else None
@@ -187,8 +208,7 @@ def conv3d_frames_split32_wgrad(x, dy, kt, kh, kw, shift):
     """Weight gradient [Co, Ci, kt, kh, kw] float32 from float32 x [(T N), Ci, H, W], dy [(T N), Co, H, W]: [x1 | x2 | x3] against
     [g1 | g2 | g3] on the 16-bit weight-gradient kernel; of the nine blocks of its [3 Co, 3 Ci] result the six significant ones are added."""
     ci, co = x.shape[1], dy.shape[1]
-    x3 = torch.cat(split_bf16x3(x), dim=1).contiguous(memory_format=torch.channels_last)
-    g3 = torch.cat(split_bf16x3(dy), dim=1).contiguous(memory_format=torch.channels_last)
+    x3, g3 = split32_stack(x, (0, 1, 2)), split32_stack(dy, (0, 1, 2))
     flops0 = stats['flops']
     gw = conv3d_frames_wgrad(x3, g3, kt, kh, kw, shift)                  # [3 co, 3 ci, kt, kh, kw]
     stats['flops'] = flops0 + 2 * x.shape[0] * x.shape[2] * x.shape[3] * co * ci * kt * kh * kw

@@ -498,3 +498,40 @@ def test_second_order_on_hand_kernels_matches_library_route_gpu(dtype, monkeypat
         scale = float(c.abs().max())
         assert float((a - c).abs().max()) <= tol * scale, (name, 'hand route', float((a - c).abs().max()) / scale)
         assert float((b - c).abs().max()) <= tol * scale, (name, 'library route', float((b - c).abs().max()) / scale)
+
+
+def test_split32_stack_definition_cpu():
+    """The stacked operand of the float32 route: three bfloat16 parts whose sum is the tensor to 24 bits, blocks in the requested order (CPU: the tensor expressions)."""
+    from torch_utils.ops import conv3d_frames as cf
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(3, 16, 2, 5, generator=g) * torch.logspace(-6, 6, 16).reshape(1, 16, 1, 1)).contiguous(memory_format=torch.channels_last)
+    out = cf.split32_stack(x, (0, 0, 1, 0, 1, 2))
+    assert out.shape == (3, 96, 2, 5) and out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last)
+    p1, p2, p3 = out[:, 0:16], out[:, 32:48], out[:, 80:96]
+    assert torch.equal(out[:, 16:32], p1) and torch.equal(out[:, 48:64], p1) and torch.equal(out[:, 64:80], p2)
+    err = (p1.double() + p2.double() + p3.double() - x.double()).abs() / x.double().abs().clamp_min(1e-30)
+    assert float(err.max()) < 2.0 ** -22
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('parts', [(0, 0, 1, 0, 1, 2), (0, 1, 2)])
+def test_split32_stack_kernel_is_bit_identical_to_the_tensor_expressions_gpu(parts):
+    from torch_utils.ops import conv3d_frames as cf
+    g = torch.Generator().manual_seed(1)
+    for shape in ((5, 64, 3, 4), (2, 8, 1, 1), (7, 136, 9, 16)):
+        x = torch.randn(*shape, generator=g) * torch.logspace(-20, 20, shape[1]).reshape(1, -1, 1, 1)
+        x.view(-1)[::97] = 0.0
+        x.view(-1)[5] = float('inf')
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        got = cf.split32_stack(xd, parts)
+        cf.SPLIT_STACK_HIP = False
+        try:
+            want = cf.split32_stack(xd, parts)
+        finally:
+            cf.SPLIT_STACK_HIP = True
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        got, want = got.permute(0, 2, 3, 1).contiguous(), want.permute(0, 2, 3, 1).contiguous()      # (1 x 1 frames: channels-last strides are not unique)
+        nan = got.isnan() & want.isnan()                                          # inf - inf: NaN in both (its sign / payload bits are not defined)
+        diff = (got.view(torch.int16) != want.view(torch.int16)) & ~nan
+        assert int(diff.sum()) == 0, (shape, int(diff.sum()), got[diff][:4], want[diff][:4])
+        assert int(nan.sum()) > 0
