@@ -16,7 +16,6 @@
 // Bound: float32 MFMA (157 TFLOP/s): sum_g pairs[g] * 2 rows * 4096 FLOP per tile; 13.2 GFLOP for the shipped bank at 64 rows x 640 frames against 52 GFLOP dense.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <atomic>
 #include "lvg_common.h"
 
 namespace {
@@ -166,16 +165,10 @@ extern "C" int lvg_noise_filter_bank(const float* noise, const float* bankP, con
     const size_t noiseBytes = (size_t)2 * (32 + 2 * (size_t)maxPairs) * sizeof(float);
     const size_t sumBytes = (size_t)(kWaves - 1) * 32 * 64 * sizeof(float);
     const size_t lds = noiseBytes > sumBytes ? noiseBytes : sumBytes;
-    if (lds > 160 * 1024) { lvg_set_error("lvg_noise_filter_bank: filters longer than ~10 000 taps are not supported"); return LVG_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024)
     {
-        static std::atomic<size_t> granted{0};
-        if (granted.load() < lds)
-        {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(noise_bank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            { lvg_set_error("lvg_noise_filter_bank: hipFuncSetAttribute failed"); return LVG_ERR_LAUNCH; }
-            granted.store(lds);
-        }
+        lvg_set_error("lvg_noise_filter_bank: filters longer than ~8000 taps are not supported (two noise rows of a tile must fit 64 KiB of LDS)");
+        return LVG_ERR_UNSUPPORTED;
     }
     const int64_t grid = (int64_t)groups * q.tBlocks * q.rowPairs;
     hipLaunchKernelGGL(noise_bank_kernel, dim3((unsigned)grid), dim3(256), lds, static_cast<hipStream_t>(stream), q);

@@ -88,7 +88,7 @@ class PackedBank:
 
 def supported(noise: torch.Tensor, bank: torch.Tensor) -> bool:
     return (noise.is_cuda and noise.dtype == torch.float32 and bank.dtype == torch.float32 and noise.dim() == 2 and bank.dim() == 2
-            and not noise.requires_grad and not bank.requires_grad and noise.shape[1] >= bank.shape[1] and bank.shape[1] <= 10000)
+            and not noise.requires_grad and not bank.requires_grad and noise.shape[1] >= bank.shape[1] and bank.shape[1] <= 8000)
 
 
 def noise_filter_bank(noise: torch.Tensor, bank: torch.Tensor, packed, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
