@@ -31,7 +31,7 @@
 #include <stdlib.h>
 
 #ifndef LVG_BABL
-#define LVG_BABL 0           // ablation builds only (results are WRONG): 2 no y stores, 4 no activation math, 16 no mask stores, 32 no matrix products, 64 no input DMA
+#define LVG_BABL 0           // ablation builds only (results are WRONG): 2 no y stores, 4 no activation math, 16 no mask stores, 32 no matrix products, 64 no input DMA, 128 no barriers, 256 no wait for the DMA pieces
 #endif
 #define LVG_WABL (LVG_BABL & 32)
 #ifndef LVG_BAND_SCHED_FENCE
@@ -39,6 +39,15 @@
 #endif
 #ifndef LVG_BAND_SLOTS
 #define LVG_BAND_SLOTS 3     // ring slots (K-chunks of 16 input rows): two in use, the rest in flight
+#endif
+#ifndef LVG_BAND_SWP
+#define LVG_BAND_SWP 0       // round 6 experiment: software pipeline over the column blocks with the matrix products spread between the vector instructions -- measured no faster (profiles/r06_band_swp1.log): off
+#endif
+#ifndef LVG_BAND_SWP_GROUPS
+#define LVG_BAND_SWP_GROUPS 6
+#endif
+#ifndef LVG_BAND_SWP_VALU
+#define LVG_BAND_SWP_VALU 8
 #endif
 #ifndef LVG_BAND_PIPE
 #define LVG_BAND_PIPE 1      // stage B of column block b + 1 issued before the activation of block b (16 more registers)
@@ -128,7 +137,11 @@ __device__ __forceinline__ void wait_vm_all_but(int k)
     else if (k < 8)  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier()
+{
+    if (LVG_BABL & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // LDS-DMA of 16 bytes per lane through a raw buffer (offsets outside [0, num_records) deliver zeros): LDS address = ldsPiece
 // (wave-uniform, via M0) + lane * 16. Inline assembly: the compiler would order every later LDS read behind a DMA builtin with
@@ -467,7 +480,8 @@ __global__ __launch_bounds__(512, WPS) void filtered_lrelu_band_kernel(BandArgs 
             // The DMA pieces (and mask dwords) this wave requested during the previous iteration have landed once all but its
             // `young` youngest operations (the stores of that iteration's end) are complete. Zero the next-row pixels in the pieces,
             // meet the other waves: chunks <= gFirst + 1 complete and visible; nobody reads chunk gFirst - 1 any more.
-            if (young >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (LVG_BABL & 256) {}
+            else if (young >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (young >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             patch_slots(patchSlot, patchCount);
@@ -561,6 +575,54 @@ __global__ __launch_bounds__(512, WPS) void filtered_lrelu_band_kernel(BandArgs 
                 #pragma unroll
                 for (int bo = 0; bo < G::OBX; bo++) accW[bo] = zero16();
                 f32x16 accU = stage_b(0);
+#if LVG_BAND_SWP
+                // Software pipeline over the four column blocks: the scheduling region of block bc holds the vector work of
+                // act(bc) next to the matrix products of stage B of block bc + 1 and of stage C of block bc - 1 (neither depends
+                // on it), and the group directives at its end ask for ONE product per run of vector instructions -- a wave
+                // that issues its products in clumps leaves the matrix pipe idle through every activation (the products of a
+                // wave issue in order, 32 cycles apart; tools/probe_issue.hip: product + ~8 vector instructions share 35 cycles).
+                auto stage_c = [&](int bc, const uint32_t (&zq)[8]) __attribute__((always_inline))
+                {
+                    #pragma unroll
+                    for (int h = 0; h < 2; h++)
+                    {
+                        half8 z;
+                        __builtin_memcpy(&z, &zq[4 * h], 16);
+                        const int c = 2 * bc + h;
+                        #pragma unroll
+                        for (int bo = 0; bo < G::OBX; bo++)
+                        {
+                            const int cls = c - 2 * bo * DOWN;
+                            if (cls >= 0 && cls < G::NDC) accW[bo] = mfma(frag_d(cls), z, accW[bo]);
+                        }
+                    }
+                };
+                uint32_t zq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                #pragma unroll
+                for (int bc = 0; bc < 4; bc++)
+                {
+                    f32x16 accUn;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (bc < 3) accUn = stage_b(bc + 1);
+                    if (bc > 0) stage_c(bc - 1, zq);
+                    uint32_t zp[8];
+                    uint32_t mlo = 0, mhi = 0;
+                    if (MODE == LVG_SIGNS_READ) { const uint32_t* r = reinterpret_cast<const uint32_t*>(ML + n * G::SM + 8 * bc); mlo = r[0]; mhi = r[1]; }
+                    if (LVG_BABL & 4) { for (int i = 0; i < 8; i++) { half2v t; t[0] = (_Float16)accU[2 * i]; t[1] = (_Float16)accU[2 * i + 1]; zp[i] = h2_bits(t); } }
+                    else act_block<MODE, SLOPEMAX, CLAMP, G::LUTN>(accU, zp, mdw[bc], mlo, mhi, K);
+                    #pragma unroll
+                    for (int i = 0; i < LVG_BAND_SWP_GROUPS; i++)
+                    {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, LVG_BAND_SWP_VALU, 0);
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < 8; i++) zq[i] = zp[i];
+                    if (bc < 3) accU = accUn;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                stage_c(3, zq);
+#else
                 #pragma unroll
                 for (int bc = 0; bc < 4; bc++)
                 {
@@ -587,6 +649,7 @@ __global__ __launch_bounds__(512, WPS) void filtered_lrelu_band_kernel(BandArgs 
                     }
                     if (bc < 3) accU = LVG_BAND_PIPE ? accUn : stage_b(bc + 1);
                 }
+#endif
                 // ---- W[ox][v] -> WL[row of v in result order][ox] ------------------------------------------------------------
                 #pragma unroll
                 for (int bo = 0; bo < G::OBX; bo++)
