@@ -95,7 +95,7 @@ static double max_err(const std::vector<uint16_t>& got, const std::vector<double
     return m;
 }
 
-static const char* impl_name(int impl) { return impl == 4 ? "BAND" : impl == 3 ? "WAVE" : impl == 2 ? "MFMA" : "VALU"; }
+static const char* impl_name(int impl) { return impl == 5 ? "STRIP" : impl == 4 ? "BAND" : impl == 3 ? "WAVE" : impl == 2 ? "MFMA" : "VALU"; }
 static int g_impl_mask = 0xe;     // bit i: run impl i (FLRELU_IMPLS=3,2,1)
 
 static int run_check(const Case& cs, int dtype)
@@ -134,7 +134,7 @@ static int run_check(const Case& cs, int dtype)
     HIPCHK(hipMemset(dzb.p, 0, c * 2));
     const double tol = dtype == 1 ? 5e-3 : 3e-2;
     int fails = 0;
-    for (int impl = 4; impl >= 1; impl--)
+    for (int impl = 5; impl >= 1; impl--)
     {
         if (!((g_impl_mask >> impl) & 1)) continue;
         HIPCHK(hipMemset(dy.p, 0xff, ny * 2)); HIPCHK(hipMemset(ds.p, 0xee, ns)); HIPCHK(hipMemset(ddx.p, 0xff, nx * 2));
@@ -216,7 +216,7 @@ static void run_time(const Case& cs, int dtype, int mode /*1 = fwd write signs, 
     HIPCHK(hipMemset(dzb.p, 0, c * 2));
     const int pp0 = (nu - 1) + (nd - 1) - cs.px0, pq0 = (nu - 1) + (nd - 1) - cs.py0;
     const double gg = (double)gain * up * up / (down * down);
-    for (int impl = 4; impl >= 1; impl--)
+    for (int impl = 5; impl >= 1; impl--)
     {
         if (g_only_impl && impl != g_only_impl) continue;
         if (!g_only_impl && !((g_impl_mask >> impl) & 1)) continue;
@@ -302,7 +302,7 @@ int main(int argc, char** argv)
     if (!g_flrelu || !g_setimpl || !g_err || !g_orc) { printf("missing symbol\n"); return 2; }
     g_timing = (timing_fn)dlsym(lib, "lvg_flrelu_timing_read");
     g_wtiming = (timing_fn)dlsym(lib, "lvg_flrelu_wave_timing_read");
-    if (const char* im = getenv("FLRELU_IMPLS")) { g_impl_mask = 0; for (const char* c = im; *c; c++) if (*c >= '1' && *c <= '4') g_impl_mask |= 1 << (*c - '0'); }
+    if (const char* im = getenv("FLRELU_IMPLS")) { g_impl_mask = 0; for (const char* c = im; *c; c++) if (*c >= '1' && *c <= '5') g_impl_mask |= 1 << (*c - '0'); }
     int fails = 0;
     if (what == "check" || what == "all")
     {

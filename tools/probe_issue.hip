@@ -133,6 +133,42 @@ __global__ __launch_bounds__(1024) void filler_kernel(int iters, float* out, uin
     if ((threadIdx.x & 63) == 0) { atomicMax((unsigned long long*)&cyc[0], (unsigned long long)(t1 - t0)); atomicMax((unsigned long long*)&cyc[1], (unsigned long long)t1); atomicMin((unsigned long long*)&cyc[2], (unsigned long long)t0); }
 }
 
+// Groups of NM matrix products issued back to back -- all on ONE accumulator (CH = 1: each waits for its predecessor's result),
+// or alternating between two (CH = 0) or four (CH = 2) accumulators -- followed by NV independent packed multiplies.
+template <int NM, int CH, int NV>
+__global__ __launch_bounds__(1024) void chain_kernel(int iters, float* out, uint64_t* cyc, float seed)
+{
+    const int lane = threadIdx.x & 63;
+    half8 a, b;
+    for (int j = 0; j < 8; j++) { a[j] = (_Float16)(seed * (float)(lane + j)); b[j] = (_Float16)(seed * (float)(lane - j)); }
+    f32x16 acc[4];
+    for (int k = 0; k < 4; k++) for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
+    half2v x[8];
+    for (int i = 0; i < 8; i++) { x[i][0] = (_Float16)(1.0f + seed * i); x[i][1] = (_Float16)(1.0f - seed * i); }
+    half2v sc; sc[0] = (_Float16)(1.0f + seed); sc[1] = (_Float16)(1.0f - seed);
+    const uint64_t t0 = __builtin_readcyclecounter();
+    #pragma unroll 1
+    for (int it = 0; it < iters; it++)
+    {
+        #pragma unroll
+        for (int m = 0; m < NM; m++)
+        {
+            const int k = CH == 1 ? 0 : (CH == 0 ? (m & 1) : (m & 3));
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        #pragma unroll
+        for (int i = 0; i < NV; i++) { x[i & 7] = x[i & 7] * sc; asm volatile("" : "+v"(x[i & 7])); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    float r = 0.0f;
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 16; i++) r += acc[k][i];
+    for (int i = 0; i < 8; i++) r += (float)x[i][0] + (float)x[i][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) { atomicMax((unsigned long long*)&cyc[0], (unsigned long long)(t1 - t0)); atomicMax((unsigned long long*)&cyc[1], (unsigned long long)t1); atomicMin((unsigned long long*)&cyc[2], (unsigned long long)t0); }
+}
+
 static float* g_out; static uint64_t* g_cyc; static int g_ncu;
 
 template <class K>
@@ -177,6 +213,14 @@ int main()
     #define DEPC(NV, NS, NL) run("DEP mfma>4cvt + " #NV " valu + " #NS " salu + " #NL " lds", issue_kernel<NV, NS, NL, 1>, 1, NV + 4, NS, NL)
     #define DEP2(NV, NS, NL) run("DEP2 mfma>" #NV " valu>4cvt + " #NS " salu + " #NL " lds", issue_kernel<NV, NS, NL, 2>, 1, NV + 4, NS, NL)
     #define FIL(NV, NS, NL) run("no mfma: " #NV " valu + " #NS " salu + " #NL " lds", filler_kernel<NV, NS, NL>, 0, NV, NS, NL)
+    if (getenv("PROBE_CHAIN"))
+    {
+        #define CHN(NM, CH, NV) run("chain: " #NM " mfma (mode " #CH ": 1 one acc, 0 two, 2 four) + " #NV " valu", chain_kernel<NM, CH, NV>, NM / 2, NV / 2, 0, 0)
+        CHN(2, 1, 0); CHN(2, 0, 0); CHN(4, 1, 0); CHN(4, 0, 0); CHN(4, 2, 0);
+        CHN(2, 1, 16); CHN(2, 0, 16); CHN(4, 1, 32); CHN(4, 0, 32); CHN(4, 2, 32); CHN(4, 1, 16); CHN(4, 0, 16);
+        CHN(2, 1, 32); CHN(2, 0, 32); CHN(1, 1, 8); CHN(1, 1, 16);
+        return 0;
+    }
     IND(0, 0, 0);
     FIL(8, 0, 0); FIL(16, 0, 0); FIL(0, 8, 0); FIL(8, 8, 0); FIL(0, 0, 4); FIL(8, 4, 2);
     IND(2, 0, 0); IND(4, 0, 0); IND(6, 0, 0); IND(8, 0, 0); IND(12, 0, 0); IND(16, 0, 0);
