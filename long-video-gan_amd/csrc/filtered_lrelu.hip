@@ -718,14 +718,16 @@ extern "C" int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t
     // column strips, profiles/r05_band_*.log); LVG_FLRELU_BAND=0 keeps it out of the default route, =2 sends it everything it can take
     // (A/B measurements). impl 4 (lvg_filtered_lrelu_set_impl) = everything it can take.
     static const int env_band = []() { const char* e = getenv("LVG_FLRELU_BAND"); return e ? atoi(e) : 1; }();
-    // The strip kernel (round 6, float16): LVG_FLRELU_STRIP=0 keeps it out of the default route; impl 5 = everything it can take.
-    static const int env_strip = []() { const char* e = getenv("LVG_FLRELU_STRIP"); return e ? atoi(e) : 0; }();
+    // The strip kernel (round 6, float16) takes the planes it measured faster on (its launcher decides: planes of up to four strips,
+    // profiles/r06_sres_ab.log); LVG_FLRELU_STRIP=0 keeps it out of the default route, =2 sends it everything it can take. impl 5 = everything.
+    static const int env_strip = []() { const char* e = getenv("LVG_FLRELU_STRIP"); return e ? atoi(e) : 1; }();
     const bool use_strip = impl == 0 ? (env_strip > 0 && env_wave) : impl == 5;
+    const bool strip_all = impl == 5 || env_strip >= 2;
     const bool use_band = impl == 0 ? (env_band > 0 && env_wave) : impl == 4;
     const bool band_all = impl == 4 || env_band >= 2;
     if (use_mfma && (dtype == LVG_F16 || dtype == LVG_BF16) && (cfg == CFG_U2D2 || cfg == CFG_U4D2 || cfg == CFG_U2D4))
     {
-        int rc = use_strip ? lvg_flrelu_strip_launch(p, cfg, sign_mode, dtype, st) : LVG_ERR_UNSUPPORTED;
+        int rc = use_strip ? lvg_flrelu_strip_launch(p, cfg, sign_mode, dtype, strip_all ? 1 : 0, st) : LVG_ERR_UNSUPPORTED;
         if (rc == LVG_ERR_UNSUPPORTED && use_band) rc = lvg_flrelu_band_launch(p, cfg, sign_mode, dtype, band_all ? 1 : 0, st);
         if (rc == LVG_ERR_UNSUPPORTED && use_wave) rc = lvg_flrelu_wave_launch(p, cfg, sign_mode, dtype, st);
         if (rc == LVG_ERR_UNSUPPORTED) rc = lvg_flrelu_mfma_launch(p, cfg, sign_mode, dtype, st);      // (slope > 1: the round-2 kernel)

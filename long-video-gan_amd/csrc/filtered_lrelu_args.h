@@ -36,5 +36,5 @@ int lvg_flrelu_wave_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStrea
 // `all` = 0: only the shapes it measured faster on than the wave kernel (else LVG_ERR_UNSUPPORTED); 1: everything it can take.
 int lvg_flrelu_band_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all, hipStream_t stream);
 // filtered_lrelu_strip.hip (round 6: one wave per 24-column strip, wave-private LDS ring, no barrier; float16 only).
-// LVG_ERR_UNSUPPORTED for what it does not take. Same arguments.
-int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream);
+// LVG_ERR_UNSUPPORTED for what it does not take. `all` = 0: only the shapes it measured faster on; 1: everything it can take.
+int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all, hipStream_t stream);

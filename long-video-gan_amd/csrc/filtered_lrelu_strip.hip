@@ -745,9 +745,20 @@ int launch_strip(FlreluArgs& a, int mode, hipStream_t stream)
 
 } // namespace
 
-int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, hipStream_t stream)
+int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all, hipStream_t stream)
 {
     if (dtype != LVG_F16) return LVG_ERR_UNSUPPORTED;
+    if (!all)
+    {
+        // Measured against the band / wave kernels on the launches of the sres step (16 frames, cold operands; profiles/r06_sres_ab.log):
+        // faster on planes of up to four strips -- up 2 / down 4 backward at output widths 38, 54 and 86 (120 -> 108, 249 -> 175, 330 -> 308 us),
+        // the forward modes at width 84 (up 4 / down 2: 134 -> 111 us, up 2 / down 2: 158 -> 136 us) -- and slower on the wide planes, where its
+        // 96-byte row pieces and 8-byte stores cost more than the row-band kernel's barrier.
+        bool take = false;
+        if (cfg == LVG_FLRELU_CFG_U2D4) take = p.yw <= 96;
+        else take = mode != LVG_SIGNS_READ && p.yw > 52 && p.yw <= 96;
+        if (!take) return LVG_ERR_UNSUPPORTED;
+    }
     switch (cfg)
     {
         case LVG_FLRELU_CFG_U2D2: return launch_strip<2, 2, 12, 12, 2, 16>(p, mode, stream);

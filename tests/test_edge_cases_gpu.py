@@ -121,7 +121,7 @@ def _taps(n, rate):
 
 @pytest.fixture
 def flrelu_impl():
-    """lvg_filtered_lrelu_set_impl for the duration of a test: 1 fp32-VALU, 2 round-2 MFMA, 3 wave, 4 band."""
+    """lvg_filtered_lrelu_set_impl for the duration of a test: 1 fp32-VALU, 2 round-2 MFMA, 3 wave, 4 band, 5 strip."""
     from torch_utils.ops import _hip
     prev = []
 
@@ -150,7 +150,7 @@ def test_filtered_lrelu_float32_nonfinite_follows_the_reference(oracle):
     assert (~fin).sum() > 0 and fin.sum() > 0
 
 
-@pytest.mark.parametrize('impl', [2, 3, 4], ids=['mfma', 'wave', 'band'])
+@pytest.mark.parametrize('impl', [2, 3, 4, 5], ids=['mfma', 'wave', 'band', 'strip'])
 @pytest.mark.parametrize('bad', BAD, ids=['nan', 'inf', '-inf'])
 def test_filtered_lrelu_16bit_nonfinite_stays_local(impl, bad, oracle, flrelu_impl):
     """One bad pixel in a 94 x 150 plane: outputs more than a block (128 up-sampled = 64 output pixels, + the filters' reach) away from it
@@ -187,7 +187,7 @@ def test_filtered_lrelu_16bit_nonfinite_stays_local(impl, bad, oracle, flrelu_im
     np.testing.assert_array_equal(sd[0, 1][rows], sc[0, 1][rows])
 
 
-@pytest.mark.parametrize('impl', [0, 2, 3, 4], ids=['default', 'mfma', 'wave', 'band'])
+@pytest.mark.parametrize('impl', [0, 2, 3, 4, 5], ids=['default', 'mfma', 'wave', 'band', 'strip'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_filtered_lrelu_zero_clamp_and_large_slope(impl, dtype, oracle, flrelu_impl):
     flrelu_impl(impl)

@@ -239,10 +239,46 @@ BAND = [
 ]
 
 
+@pytest.fixture
+def strip_kernel_everywhere():
+    """Route every float16 call the strip kernel (round 6, csrc/filtered_lrelu_strip.hip) can take to it (lvg_filtered_lrelu_set_impl(5)),
+    instead of only the plane widths it is the default for. LVG_FLRELU_STRIP_MAXGRID is read once per process by the launcher, so the
+    several-items-per-wave case is covered by shapes with more (plane, strip) items than resident waves ('many_planes')."""
+    from torch_utils.ops import _hip
+    prev = _hip.lib().lvg_filtered_lrelu_set_impl(5)
+    assert prev >= 0
+    yield
+    _hip.lib().lvg_filtered_lrelu_set_impl(prev)
+
+
+# Extra geometry for the strip kernel: a plane's first strip starting left of the image at every residue of the padding (DMA origin a
+# multiple of 8, transpose-read base 0 / 4, fragment shift 0..3), strips whose ring row reaches past the end of the image row (the
+# zeroed straddling piece) while not being the last strip, widths of 24 k + {2, 4} columns (narrow last strip), up 2 / down 4 forward.
+STRIP = BAND + [
+    ('pad_residues_a', [2, 3, 40, 54], 2, 2, 12, 12, [10, 7, 8, 9]),
+    ('pad_residues_b', [2, 3, 40, 54], 2, 2, 12, 12, [7, 10, 11, 6]),
+    ('pad_residues_c', [1, 3, 40, 54], 2, 2, 12, 12, [6, 11, 5, 12]),
+    ('narrow_last_strip', [1, 3, 30, 45], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('width_50', [1, 2, 20, 52], 2, 2, 12, 12, [9, 8, 9, 8]),
+    ('d4_forward', [1, 3, 60, 100], 2, 4, 12, 24, [9, 8, 9, 8]),
+]
+
+
+@pytest.mark.parametrize('clamp', [2.5, 256.0], ids=['clamp2.5', 'clamp256'])
+@pytest.mark.parametrize('case', STRIP, ids=[s[0] for s in STRIP])
+def test_strip_kernel_forward_backward_vs_oracle(case, clamp, oracle, strip_kernel_everywhere):
+    """The strip kernel on everything it can take, float16: the same checks as for the row-band kernel below."""
+    _kernel_forward_backward_vs_oracle(case, clamp, oracle)
+
+
 @pytest.mark.parametrize('clamp', [2.5, 256.0], ids=['clamp2.5', 'clamp256'])
 @pytest.mark.parametrize('case', BAND, ids=[s[0] for s in BAND])
 def test_band_kernel_forward_backward_vs_oracle(case, clamp, oracle, band_kernel_everywhere):
-    """The row-band kernel on everything it can take, float16: forward with the mask against the float64 oracle, the mask against the
+    _kernel_forward_backward_vs_oracle(case, clamp, oracle)
+
+
+def _kernel_forward_backward_vs_oracle(case, clamp, oracle):
+    """One fused kernel on everything it can take, float16: forward with the mask against the float64 oracle, the mask against the
     oracle's, the backward pass (sign-READ mode, filter roles swapped: for up 4 / down 2 layers that is the up 2 / down 4 instance)
     against the oracle run on the mask the GPU wrote. clamp 2.5 exercises the clamp and its mask bit, clamp 256 the proof that skips them."""
     import scipy.signal

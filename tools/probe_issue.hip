@@ -169,6 +169,34 @@ __global__ __launch_bounds__(1024) void chain_kernel(int iters, float* out, uint
     if ((threadIdx.x & 63) == 0) { atomicMax((unsigned long long*)&cyc[0], (unsigned long long)(t1 - t0)); atomicMax((unsigned long long*)&cyc[1], (unsigned long long)t1); atomicMin((unsigned long long*)&cyc[2], (unsigned long long)t0); }
 }
 
+// NV independent packed multiplies and NN "s_nop 7" (8 wait states each) per group: does a wave's s_nop take issue time from the OTHER waves of its SIMD?
+template <int NV, int NN>
+__global__ __launch_bounds__(1024) void nop_kernel(int iters, float* out, uint64_t* cyc, float seed)
+{
+    half2v x[8];
+    for (int i = 0; i < 8; i++) { x[i][0] = (_Float16)(1.0f + seed * i); x[i][1] = (_Float16)(1.0f - seed * i); }
+    half2v sc; sc[0] = (_Float16)(1.0f + seed); sc[1] = (_Float16)(1.0f - seed);
+    const uint64_t t0 = __builtin_readcyclecounter();
+    #pragma unroll 1
+    for (int it = 0; it < iters; it++)
+    {
+        #pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            #pragma unroll
+            for (int i = 0; i < NV; i++) { x[i & 7] = x[i & 7] * sc; asm volatile("" : "+v"(x[i & 7])); }
+            #pragma unroll
+            for (int i = 0; i < NN; i++) asm volatile("s_nop 7");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    float r = 0.0f;
+    for (int i = 0; i < 8; i++) r += (float)x[i][0] + (float)x[i][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) { atomicMax((unsigned long long*)&cyc[0], (unsigned long long)(t1 - t0)); atomicMax((unsigned long long*)&cyc[1], (unsigned long long)t1); atomicMin((unsigned long long*)&cyc[2], (unsigned long long)t0); }
+}
+
 static float* g_out; static uint64_t* g_cyc; static int g_ncu;
 
 template <class K>
@@ -219,6 +247,8 @@ int main()
         CHN(2, 1, 0); CHN(2, 0, 0); CHN(4, 1, 0); CHN(4, 0, 0); CHN(4, 2, 0);
         CHN(2, 1, 16); CHN(2, 0, 16); CHN(4, 1, 32); CHN(4, 0, 32); CHN(4, 2, 32); CHN(4, 1, 16); CHN(4, 0, 16);
         CHN(2, 1, 32); CHN(2, 0, 32); CHN(1, 1, 8); CHN(1, 1, 16);
+        #define NOPK(NV, NN) run("no mfma: " #NV " valu + " #NN " x s_nop 7", nop_kernel<NV, NN>, 0, NV, NN, 0)
+        NOPK(8, 0); NOPK(8, 1); NOPK(8, 2); NOPK(8, 4); NOPK(0, 4); NOPK(16, 2);
         return 0;
     }
     IND(0, 0, 0);
