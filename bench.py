@@ -295,7 +295,8 @@ def main():
             video = G(B, T, magnitude_ema_beta=ema_beta, dtype=dtype)
         logits = D(video, dtype=dtype)
         F.softplus(-logits).mean().backward()
-        pending_emas[:] = [pending, lres.stack_pending(pending) if pending else None]
+        pending_emas[:] = [pending, lres.stack_pending(pending) if pending else None,
+                           ddp.stat_sync_plan(pending) if pending and world > 1 else None]      # (built when the step is captured, reused by every replay)
 
     sync_events = []               # (start, end) HIP events around the gradient exchange of the timed steps
 
@@ -334,7 +335,8 @@ def main():
                 step()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (more than one rank: the process group's watchdog thread must not invalidate this thread's capture)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local' if world > 1 else 'global'):
                 compute()
             graph.replay()
             update()

@@ -126,15 +126,7 @@ int lvg_filtered_lrelu(const void* x, void* y, const void* b, uint8_t* s,
                        float gain, float slope, float clamp, int flip, int sign_mode,
                        int dtype, void* stream);
 
-/*
- * Which fused kernel serves float16 / bfloat16 tensors: 0 = default (float16 planes of two / three column strips: the row-band MFMA
- * kernel, csrc/filtered_lrelu_band.hip, LVG_FLRELU_BAND=0 switches it off; everything else: the wave-per-tile MFMA kernel,
- * csrc/filtered_lrelu_wave.hip; LVG_FLRELU_WAVE=0: the round-2 MFMA kernel, csrc/filtered_lrelu_mfma.hip; LVG_FLRELU_MFMA=0: the VALU
- * kernel), 1 = the fp32-VALU kernel (csrc/filtered_lrelu.hip, the only one for float32), 2 = the round-2 MFMA kernel, 3 = the
- * wave-per-tile kernel, 4 = the row-band kernel for everything it can take (falls back to 3).
- * Process-wide; returns the previous setting. No reference counterpart: a measurement / bisecting hook for tests and bench.py.
- */
-int lvg_filtered_lrelu_set_impl(int impl);
+/* (Which fused kernel serves a call is the library's choice; the test / measurement override lives in lvg_test_hooks.h.) */
 
 /* 1 if lvg_filtered_lrelu has a fused kernel for these parameters, else 0 (no launch). */
 int lvg_filtered_lrelu_supported(int fu_n, int fd_n, int up, int down, int dtype);
@@ -260,13 +252,6 @@ int lvg_conv3d_frames_wgrad_splits(int64_t frames, int h, int w, int ci, int co,
  * 0 = unsupported shape. */
 int64_t lvg_conv3d_frames_workgroups(int64_t frames, int h, int wd, int ci, int co, int kt, int kh, int kw);
 
-/* Measurement / test control (no counterpart in the reference): force the tile of lvg_conv3d_frames -- bm pixels (128 | 256) x bn output
- * channels (64 | 128), weight ring depth nb (2 | 3); 0 = the kernel's own choice -- and switch the persistent-workgroup form of the
- * 64-channel tiles on / off. Every form computes the same bits (tests/test_conv3d_frames.py). Initial values: LVG_CONV_BM / _BN / _NB /
- * _PERSIST from the environment. NOT thread-safe against concurrent lvg_conv3d_frames / lvg_conv3d_frames_workgroups calls: the plan is
- * process-wide state read by both (a caller sizes msq_partial with one and launches with the other); change it only while no other
- * thread is inside the library. */
-int lvg_conv3d_frames_set_plan(int bm, int bn, int nb, int persist);
 
 /*
  * Backward of lvg_tapconv_epilogue from dout and the saved ysum; the gradient is written already scattered

@@ -85,6 +85,8 @@ int env_int(const char* name, int dflt)
 struct Overrides { int bm, bn, nb, persist; };
 Overrides& overrides()
 {
+    // process-wide on purpose: a backward pass runs on autograd's own thread and has to see what the test's thread set (a
+    // thread-local override would silently test the default tile there). Test / measurement hook: include/lvg_test_hooks.h.
     static Overrides o = {env_int("LVG_CONV_BM", 0), env_int("LVG_CONV_BN", 0), env_int("LVG_CONV_NB", 0), env_int("LVG_CONV_PERSIST", 0)};
     return o;
 }

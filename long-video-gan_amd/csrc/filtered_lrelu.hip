@@ -635,7 +635,7 @@ extern "C" int lvg_filtered_lrelu_act(void* x, uint8_t* s, const int64_t xshape[
     }
 }
 
-static std::atomic<int> g_flrelu_impl{0};
+static std::atomic<int> g_flrelu_impl{0};      // process-wide on purpose (include/lvg_test_hooks.h): the backward launch comes from autograd's thread, not the test's
 
 extern "C" int lvg_filtered_lrelu_set_impl(int impl)
 {

@@ -75,9 +75,26 @@ def stack_pending(pending):
     return (torch.cat([l.reshape(-1).float() for _, l, _, _, _ in pending]), torch.cat([p.reshape(-1).float() for _, _, _, p, _ in pending]))
 
 
-def finish_stat_sync(pending, stacked=None) -> None:
+def stat_sync_plan(pending, device=None):
+    """What `finish_stat_sync` needs besides the statistics themselves, built ONCE per recorded scope (a captured phase keeps it next
+    to its static tensors: rebuilding the weight vectors from Python lists after every replay cost two host-to-device copies per phase):
+    (element counts, weights 1 - beta, weights beta). Every buffer may be recorded at most once per scope -- a second record would be
+    redone from a 'previous' value that already holds the first local update."""
+    seen = set()
+    for buf, _, _, _, _ in pending:
+        assert id(buf) not in seen, 'a running statistic was recorded twice in one deferred_stat_sync scope'
+        seen.add(id(buf))
+    sizes = [b.numel() for b, _, _, _, _ in pending]
+    device = pending[0][1].device if device is None else device
+    # (weights formed in Python floats and rounded once, like the scalar arguments of the eager calls)
+    w_to = torch.tensor([1.0 - bt for (_, _, bt, _, _), n in zip(pending, sizes) for _ in range(n)], dtype=torch.float32, device=device)
+    w_from = torch.tensor([bt for (_, _, bt, _, _), n in zip(pending, sizes) for _ in range(n)], dtype=torch.float32, device=device)
+    return sizes, w_to, w_from
+
+
+def finish_stat_sync(pending, stacked=None, plan=None) -> None:
     """One all-reduce for every statistic recorded in a deferred scope, then each buffer is REDONE from its previous value and the
-    mean over ranks, in the form of its call site."""
+    mean over ranks, in the form of its call site. `plan`: `stat_sync_plan(pending)` kept by the caller (replayed phases)."""
     world = _world()
     if not pending or world <= 1:
         return
@@ -85,10 +102,7 @@ def finish_stat_sync(pending, stacked=None) -> None:
     glob = local.clone()
     dist.all_reduce(glob)
     glob = glob / world
-    sizes = [b.numel() for b, _, _, _, _ in pending]
-    # (weights formed in Python floats and rounded once, like the scalar arguments of the eager calls)
-    w_to = torch.tensor([1.0 - bt for (_, _, bt, _, _), n in zip(pending, sizes) for _ in range(n)], dtype=glob.dtype, device=glob.device)
-    w_from = torch.tensor([bt for (_, _, bt, _, _), n in zip(pending, sizes) for _ in range(n)], dtype=glob.dtype, device=glob.device)
+    sizes, w_to, w_from = stat_sync_plan(pending, glob.device) if plan is None else plan
     towards = torch.lerp(prev, glob, w_to)                # prev.lerp(stat, 1 - beta)
     frm = torch.lerp(glob, prev, w_from)                  # stat.lerp(prev, beta)
     o = 0

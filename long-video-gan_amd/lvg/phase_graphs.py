@@ -56,16 +56,32 @@ class PhaseGraphs:
                 t.copy_(v)
             for s, f in zip(self.syncs, fired_before):
                 s._fired = list(f)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                pending, stacked = self._run(fn)
+            # More than one rank: the process group's watchdog thread issues event queries of its own; 'thread_local' keeps them from
+            # invalidating this thread's capture. A capture that is refused anyway (never observed at one rank; an RCCL multi-GPU run has
+            # not been available to this repository) turns the phase graphs off for good: the same protocol, launched eagerly.
+            mode = 'thread_local' if ddp._world() > 1 else 'global'
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    pending, stacked = self._run(fn)
+            except Exception as err:  # pylint: disable=broad-except
+                import sys
+                print(f'[phase_graphs] hipGraph capture of phase {key!r} refused ({type(err).__name__}: {err}); eager launches from here on', file=sys.stderr)
+                torch.cuda.synchronize()
+                for s, f in zip(self.syncs, fired_before):
+                    s._fired = list(f)
+                self.capture = False
+                self.graphs.clear()
+                ddp.finish_stat_sync(*self._run(fn))
+                return
             # which gradients this phase produces (their hooks ran during the capture and will not run again)
             fired = [[i for i, (now, was) in enumerate(zip(s._fired, f)) if now and not was] for s, f in zip(self.syncs, fired_before)]
-            entry = self.graphs[key] = (g, pending, stacked, fired)
-        g, pending, stacked, fired = entry
+            plan = ddp.stat_sync_plan(pending) if pending and ddp._world() > 1 else None
+            entry = self.graphs[key] = (g, pending, stacked, fired, plan)
+        g, pending, stacked, fired, plan = entry
         g.replay()
         for s, idx in zip(self.syncs, fired):
             for i in idx:
                 s._fired[i] = True
         if pending:
-            ddp.finish_stat_sync(pending, stacked)
+            ddp.finish_stat_sync(pending, stacked, plan)

@@ -40,8 +40,9 @@ def _apply(x: torch.Tensor, w_tw: torch.Tensor, wide_in: bool, co: int) -> torch
     y = torch.empty_strided((f, co, h, w), (h * w * co, 1, w * co, co), dtype=x.dtype, device=x.device)
     thin, wide = w_tw.shape
     fn = _hip.lib().lvg_pointwise_thin_out if wide_in else _hip.lib().lvg_pointwise_thin_in
-    _hip.check(fn(x.data_ptr(), w_tw.data_ptr(), y.data_ptr(), _pixels(x), wide, thin, _hip.dtype_code(x.dtype), _hip.stream(x.device)),
-               'lvg_pointwise_thin_out' if wide_in else 'lvg_pointwise_thin_in')
+    with torch.cuda.device(x.device):                                        # (the launch goes to the CURRENT HIP device: make it the tensor's)
+        _hip.check(fn(x.data_ptr(), w_tw.data_ptr(), y.data_ptr(), _pixels(x), wide, thin, _hip.dtype_code(x.dtype), _hip.stream(x.device)),
+                   'lvg_pointwise_thin_out' if wide_in else 'lvg_pointwise_thin_in')
     return y
 
 
@@ -51,8 +52,9 @@ def _wgrad(wide_t: torch.Tensor, thin_t: torch.Tensor) -> torch.Tensor:
     pixels = _pixels(wide_t)
     blocks = int(_hip.lib().lvg_pointwise_thin_wgrad_blocks(pixels, wide))
     part = torch.empty((blocks, thin, wide), dtype=torch.float32, device=wide_t.device)
-    _hip.check(_hip.lib().lvg_pointwise_thin_wgrad(wide_t.data_ptr(), thin_t.data_ptr(), part.data_ptr(), pixels, wide, thin, _hip.dtype_code(wide_t.dtype),
-                                                   blocks, _hip.stream(wide_t.device)), 'lvg_pointwise_thin_wgrad')
+    with torch.cuda.device(wide_t.device):
+        _hip.check(_hip.lib().lvg_pointwise_thin_wgrad(wide_t.data_ptr(), thin_t.data_ptr(), part.data_ptr(), pixels, wide, thin, _hip.dtype_code(wide_t.dtype),
+                                                       blocks, _hip.stream(wide_t.device)), 'lvg_pointwise_thin_wgrad')
     return part.sum(dim=0)
 
 

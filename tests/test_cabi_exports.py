@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/lvg_ops.h declares (no compute)."""
+"""The C-ABI library loads and exports every symbol the headers under include/ declare (no compute): lvg_ops.h = the drop-in operator
+ABI, lvg_test_hooks.h = the test / measurement controls kept OUT of it."""
 
 import ctypes
 import os
@@ -8,17 +9,29 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'lvg_ops.h')
+HEADERS = sorted(os.path.join(ROOT, 'include', f) for f in os.listdir(os.path.join(ROOT, 'include')) if f.endswith('.h'))
 LIB = os.path.join(ROOT, 'long-video-gan_amd', 'lib', 'liblvg_hip.so')
 
 
-def declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(lvg_[a-z0-9_]+)\s*\(', text)))
+def declared_symbols(headers=None):
+    syms = set()
+    for h in (HEADERS if headers is None else headers):
+        text = open(h).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        syms.update(re.findall(r'\b(lvg_[a-z0-9_]+)\s*\(', text))
+    return sorted(syms)
+
+
+def test_operator_header_holds_no_test_hooks():
+    """Routing overrides are process-wide test controls: they are declared in lvg_test_hooks.h, not in the operator ABI."""
+    ops = declared_symbols([HEADER])
+    assert 'lvg_filtered_lrelu_set_impl' not in ops and 'lvg_conv3d_frames_set_plan' not in ops
+    hooks = declared_symbols([os.path.join(ROOT, 'include', 'lvg_test_hooks.h')])
+    assert hooks == ['lvg_conv3d_frames_set_plan', 'lvg_filtered_lrelu_set_impl']
 
 
 def test_header_declares_the_hot_path():
-    syms = declared_symbols()
+    syms = declared_symbols([HEADER])
     for must in ('lvg_bias_act', 'lvg_upfirdn2d', 'lvg_filtered_lrelu', 'lvg_filtered_lrelu_act', 'lvg_last_error', 'lvg_abi_version'):
         assert must in syms
 
@@ -30,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     import torch  # noqa: F401  (maps libamdhip64 first, as the product loader does)
     lib = ctypes.CDLL(LIB)
     for name in declared_symbols():
-        assert hasattr(lib, name), f'{name} declared in include/lvg_ops.h but not exported by liblvg_hip.so'
+        assert hasattr(lib, name), f'{name} declared under include/ but not exported by liblvg_hip.so'
     lib.lvg_abi_version.restype = ctypes.c_int
     assert lib.lvg_abi_version() == 1
 
