@@ -6,6 +6,7 @@ roles of the filters swapped, reading that mask (:239-268), so gradients of any 
 Parameter combinations without a fused kernel take the generic path: upfirdn2d ->
 `lvg_filtered_lrelu_act` (in place, same mask format) -> upfirdn2d (:223-229)."""
 
+import collections
 import os
 import warnings
 
@@ -17,6 +18,8 @@ from .. import misc
 from . import upfirdn2d
 from . import bias_act
 from . import _hip
+
+_Adjoint = collections.namedtuple('_Adjoint', 'padding gain mask_x mask_y')     # parameters of the backward launch (see _adjoint_call)
 
 #----------------------------------------------------------------------------
 
@@ -267,38 +270,47 @@ def _filtered_lrelu_cuda(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cl
 
         @staticmethod
         def backward(ctx, dy): # pylint: disable=arguments-differ
-            fu, fd = ctx.fu, ctx.fd
-            si, = ctx.saved_tensors
-            _, _, xh, xw = ctx.x_shape
-            _, _, yh, yw = ctx.y_shape
-            sx, sy = ctx.s_ofs
-            fu_w, fu_h = _get_filter_size(fu)
-            fd_w, fd_h = _get_filter_size(fd)
-            if fu is not None and fu.ndim == 1:
-                fu_h = fu_w
-            if fd is not None and fd.ndim == 1:
-                fd_h = fd_w
-            dx = db = None
-            for i in (1, 2, 4, 5, 6):
-                assert not ctx.needs_input_grad[i]
-
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
-                pp = [
-                    (fu_w - 1) + (fd_w - 1) - px0,
-                    xw * up - yw * down + px0 - (up - 1),
-                    (fu_h - 1) + (fd_h - 1) - py0,
-                    xh * up - yh * down + py0 - (up - 1),
-                ]
-                gg = gain * (up ** 2) / (down ** 2)
-                ff = (not flip_filter)
-                sx = sx - (fu_w - 1) + px0
-                sy = sy - (fu_h - 1) + py0
-                dx = _filtered_lrelu_cuda(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None, flip_filter=ff).apply(dy, fd, fu, None, si, sx, sy)
-
-            if ctx.needs_input_grad[3]:
-                db = _bias_grad(dx)
-
+            # Only x and b are differentiable; filters, the mask and its offsets are constants of the call.
+            want_dx, want_db = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
+            assert not any(ctx.needs_input_grad[i] for i in (1, 2, 4, 5, 6))
+            if not (want_dx or want_db):
+                return (None,) * 7
+            mask, = ctx.saved_tensors
+            adj = _adjoint_call(ctx.x_shape, ctx.y_shape, ctx.fu, ctx.fd, ctx.s_ofs)
+            # The adjoint of (pad, up-FIR, pointwise, down-FIR) is the same chain with the FIRs' roles exchanged and their taps mirrored;
+            # the pointwise stage is replaced by its derivative, which the 2-bit mask encodes (clamp=None: nothing left to clamp).
+            grad_op = _filtered_lrelu_cuda(up=down, down=up, padding=adj.padding, gain=adj.gain, slope=slope, clamp=None,
+                                           flip_filter=not flip_filter)
+            dx = grad_op.apply(dy, ctx.fd, ctx.fu, None, mask, adj.mask_x, adj.mask_y)
+            db = _bias_grad(dx) if want_db else None        # (the bias enters before the up-FIR: its gradient is dx summed per channel)
             return dx, None, None, db, None, None, None
+
+    def _adjoint_call(x_shape, y_shape, fu, fd, mask_ofs):
+        """Geometry of the backward launch. Forward: U = upfirdn(x, fu, up, pad) has  in * up + pad0 + pad1 - (taps_u - 1)  samples per
+        axis and y = U[::down] after the down-FIR. The adjoint feeds dy (out samples) through an up-by-`down` FIR of taps_d taps and a
+        down-by-`up` FIR of taps_u taps and must return exactly `in` samples: solving  (out * down + q0 + q1 - (taps_d - 1) - (taps_u - 1)
+        + (up - 1)) // up == in  with the leading pad fixed by causality (q0 = taps_u - 1 + taps_d - 1 - pad0) gives q1 below. The mask
+        was written in U's coordinates; the adjoint's up-sampled plane starts (taps_u - 1 - pad0) samples earlier, hence the offsets."""
+        taps_ux, taps_uy = _get_filter_size(fu)
+        taps_dx, taps_dy = _get_filter_size(fd)
+        if fu is not None and fu.ndim == 1:
+            taps_uy = taps_ux                               # separable filter given as one vector
+        if fd is not None and fd.ndim == 1:
+            taps_dy = taps_dx
+        in_h, in_w = x_shape[2], x_shape[3]
+        out_h, out_w = y_shape[2], y_shape[3]
+
+        def axis(n_in, n_out, taps_u, taps_d, lead):
+            q0 = (taps_u - 1) + (taps_d - 1) - lead
+            q1 = n_in * up - n_out * down + lead - (up - 1)
+            return q0, q1
+
+        qx0, qx1 = axis(in_w, out_w, taps_ux, taps_dx, px0)
+        qy0, qy1 = axis(in_h, out_h, taps_uy, taps_dy, py0)
+        return _Adjoint(padding=[qx0, qx1, qy0, qy1],
+                        gain=gain * (up * up) / (down * down),   # d/dU of (gain * U) folded with the two FIR gains: up**2 forward, down**2 here
+                        mask_x=mask_ofs[0] - (taps_ux - 1) + px0,
+                        mask_y=mask_ofs[1] - (taps_uy - 1) + py0)
 
     _filtered_lrelu_cuda_cache[key] = FilteredLReluCuda
     return FilteredLReluCuda
