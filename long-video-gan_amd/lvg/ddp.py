@@ -31,7 +31,8 @@ def _world() -> int:
 # the middle of the pass in the reference. Inside a `deferred_stat_sync()` scope a layer instead folds in its LOCAL statistic and
 # records (buffer, local statistic, beta, previous buffer value); ONE all-reduce afterwards (`finish_stat_sync`) redoes every
 # buffer with the mean over ranks -- the reference's arithmetic, bit-identical on every rank. The only difference is that the gain
-# used in THIS pass saw the local statistic: a relative change of (1 - beta) * (local / global - 1) ~ 1e-5, nothing at world size 1.
+# used in THIS pass saw the local statistic: a relative change of (1 - beta) * (local / global - 1) per layer -- measured on the full lres
+# generator at two ranks of ONE clip each: 2.3e-4 of the emitted video's range (tests/test_ddp_gloo.py, gate 5e-4) -- nothing at world size 1.
 # It is what lets a pass be captured into a hipGraph (an RCCL collective inside a capture aborts on this stack): the recorded
 # tensors are static outputs of the graph, the all-reduce runs after the replay (lvg.phase_graphs).
 

@@ -29,8 +29,8 @@ def record_measured(name, **values):
     """Append measured parity errors to gpurun_out/parity_measured.json (best effort; merged back by gpurun) and print them,
     so that every gate in the suite can be read next to the number it gates."""
     import json
-    vals = {k: float(v) for k, v in values.items()}
-    print(f'[measured] {name}: ' + ', '.join(f'{k}={v:.4g}' for k, v in vals.items()))
+    vals = {k: (v if isinstance(v, (list, dict, str)) else float(v)) for k, v in values.items()}
+    print(f'[measured] {name}: ' + ', '.join(f'{k}={v:.4g}' if isinstance(v, float) else f'{k}={v}' for k, v in vals.items()))
     try:
         d = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(d, exist_ok=True)

@@ -24,7 +24,7 @@ def _build(device):
     return G.to(device).requires_grad_(True), D.to(device).requires_grad_(True)
 
 
-def _pre_activation_spy(records, pin_to=None, pinned=None):
+def _pre_activation_spy(records, pin_to=None, pinned=None, where=None):
     """Patch of lres._TapConvEpilogue._backward that also records z = ysum * pre + b (+ res) of every activated call (the argument of the
     leaky ReLU whose derivative the backward pass takes): returns the original to restore.
 
@@ -56,6 +56,9 @@ def _pre_activation_spy(records, pin_to=None, pinned=None):
                 differs = zo.sign() != z.sign()
                 if bool(differs.any()):
                     pinned.extend(float(v) for v in (zo[differs].abs() / zo.abs().max()))
+                    if where is not None:       # which layer (activation shape [frames, channels, h, w]), how many elements, terms per bias-gradient sum
+                        where.append(dict(x=list(key[0]), w=list(key[1]), flipped=int(differs.sum()), of=int(z.numel()),
+                                          terms_per_channel_sum=int(z.numel() // z.shape[1])))
                     target = zo.sign() * 1e-4 * zo.abs().max()
                     want_sum = (target - shift) / (1.0 if scale is None else scale)
                     ysum = torch.where(differs, want_sum.to(ysum.dtype), ysum)
@@ -64,11 +67,11 @@ def _pre_activation_spy(records, pin_to=None, pinned=None):
     return orig
 
 
-def _forward_backward(device, g, records=None, pin_to=None, pinned=None):
+def _forward_backward(device, g, records=None, pin_to=None, pinned=None, where=None):
     """One generator + discriminator pass on the golden inputs -> (features' rms, video, logits, loss, the seven parameter gradients)."""
     from lvg.models import lres
     G, D = _build(device)
-    orig = _pre_activation_spy(records, pin_to, pinned) if records is not None else None
+    orig = _pre_activation_spy(records, pin_to, pinned, where) if records is not None else None
     try:
         noise = torch.tensor(g['noise'], device=device)
         emb = G.temporal_emb.blur(noise)
@@ -138,8 +141,9 @@ def _run(device, rtol_grad):
         lres.SPLIT_F32 = True
     lib32, lib64 = _gradient_errors(lib_grads, g), _gradient_errors(lib_grads, g64)
     assert max(lib32.values()) <= rtol_grad and max(lib64.values()) < 1e-3, ('library route', lib32, lib64)
-    pinned, pin_records = [], []
-    _, _, pin_video, pin_logits, _, pin_grads = _forward_backward(device, g, pin_records, pin_to=lib_records, pinned=pinned)
+    pinned, pin_records, where = [], [], []
+    _, _, pin_video, pin_logits, _, pin_grads = _forward_backward(device, g, pin_records, pin_to=lib_records, pinned=pinned, where=where)
+    record_measured(f'lres_T16_f32_kink_layers_{device}', layers=where)
     pin32, pin64 = _gradient_errors(pin_grads, g), _gradient_errors(pin_grads, g64)
     record_measured(f'lres_T16_f32_kink_pinned_{device}', pinned_elements=len(pinned), largest_relative_distance_from_zero=max(pinned, default=0.0),
                     hand_route_unpinned_vs_f64=max(vs64.values()), hand_route_pinned_vs_f64=max(pin64.values()), hand_route_pinned_vs_f32=max(pin32.values()),
@@ -180,8 +184,9 @@ def test_generator_discriminator_match_reference_gpu():
 @pytest.mark.gpu
 def test_bf16_forward_close_to_fp32_gpu():
     """bfloat16 activations / contraction vs the float32 golden of the reference. SURVEY.md 7 measured the deviation of the
-    reference's OWN bf16 run from its float32 run at 1.1e-2 max / 1.5e-3 mean (outputs in [-0.43, 0.26]); the gate is twice
-    that band, 2.2e-2 / 3e-3. The measured errors are printed and recorded (conftest.record_measured)."""
+    reference's OWN bf16 run from its float32 run at 1.1e-2 max / 1.5e-3 mean (outputs in [-0.43, 0.26]). Gate: 1.5 x this repository's
+    measured deviation (1.39e-2 max / 2.20e-3 mean, profiles/r05_parity_measured.json; the kernels are bit-reproducible, so the margin only
+    has to cover other boxes' library builds): 2.1e-2 / 3.3e-3. Measured values are printed and recorded."""
     g = load_golden('lres_models')
     G, _ = _build('cuda')
     with torch.no_grad():
@@ -189,7 +194,7 @@ def test_bf16_forward_close_to_fp32_gpu():
         video = G.synthesize_video(G._temporal_input(ws), ws, T, dtype=torch.bfloat16)
     err = np.abs(video.cpu().numpy() - g['video'])
     record_measured('lres_T16_bf16_video_vs_reference_f32', max_abs=err.max(), mean_abs=err.mean(), ref_range=np.abs(g['video']).max())
-    assert err.max() < 2.2e-2 and err.mean() < 3e-3, (float(err.max()), float(err.mean()))
+    assert err.max() < 2.1e-2 and err.mean() < 3.3e-3, (float(err.max()), float(err.mean()))
 
 
 def _run_t128(device, dtype=None):
@@ -217,27 +222,29 @@ def _run_t128(device, dtype=None):
 def test_t128_generator_matches_reference_cpu():
     torch.set_num_threads(8)
     err, logits, g = _run_t128('cpu')
-    assert err.max() <= 1e-3 + 2.5e-4, float(err.max())
+    record_measured('lres_T128_f32_video_vs_reference_cpu', max_abs=err.max(), mean_abs=err.mean())
+    assert err.max() <= 1e-3, float(err.max())      # north star: 1e-3, the golden's float16 storage error (2.5e-4) included; measured 2.5e-4
     np.testing.assert_allclose(logits, g['t128_logits'], rtol=1e-3, atol=1e-3)
 
 
 @pytest.mark.gpu
 def test_t128_generator_matches_reference_gpu():
     err, logits, g = _run_t128('cuda')
-    assert err.max() <= 1e-3 + 2.5e-4, float(err.max())
+    record_measured('lres_T128_f32_video_vs_reference_cuda', max_abs=err.max(), mean_abs=err.mean())
+    assert err.max() <= 1e-3, float(err.max())      # north star: 1e-3, the golden's float16 storage error (2.5e-4) included
     np.testing.assert_allclose(logits, g['t128_logits'], rtol=1e-3, atol=1e-3)
 
 
 @pytest.mark.gpu
 def test_t128_bf16_generator_gate_gpu():
-    """configs[1] runs bf16 activations: the 128-frame bf16 video against the float32 reference video. Its range is +-0.84,
-    1.95 x the 16-frame golden's, so twice the SURVEY.md 7 band (1.1e-2 max / 1.5e-3 mean on a range of 0.43) scales to
-    4.3e-2 max / 5.9e-3 mean; the logit is gated at 0.1. Measured values are printed and recorded."""
+    """configs[1] runs bf16 activations: the 128-frame bf16 video against the float32 reference video (range +-0.84). Gates: 1.5 x the
+    measured deviation (1.56e-2 max / 2.08e-3 mean, logit 3.2e-3; profiles/r05_parity_measured.json): 2.4e-2 / 3.2e-3 / 5e-3
+    (before: 4.3e-2 / 5.9e-3 / 0.1). Measured values are printed and recorded."""
     err, logits, g = _run_t128('cuda', dtype=torch.bfloat16)
     record_measured('lres_T128_bf16_video_vs_reference_f32', max_abs=err.max(), mean_abs=err.mean(), ref_range=np.abs(g['t128_video'].astype(np.float32)).max(),
                     logit_abs=abs(float(logits.reshape(-1)[0]) - float(g['t128_logits'].reshape(-1)[0])))
-    assert err.max() < 4.3e-2 and err.mean() < 5.9e-3, (float(err.max()), float(err.mean()))
-    assert abs(float(logits.reshape(-1)[0]) - float(g['t128_logits'].reshape(-1)[0])) < 0.1
+    assert err.max() < 2.4e-2 and err.mean() < 3.2e-3, (float(err.max()), float(err.mean()))
+    assert abs(float(logits.reshape(-1)[0]) - float(g['t128_logits'].reshape(-1)[0])) < 5e-3
 
 
 def _run_r1(device):
