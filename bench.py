@@ -431,7 +431,7 @@ def main():
             # dense-contraction (MFMA) figure of the step, and BASELINE.json configs[3] (super-resolution pair)
             # with the filtered_lrelu roofline. Failures here never take the main line down.
             del graph
-            legs = [('forward_only', lambda: _forward_only_leg(G, B, T, dtype)),
+            legs = [('forward_only', lambda: _forward_only_leg(G, B, T, dtype, timer=timer)),
                     ('mfma', lambda: _mfma_leg(step, elapsed / args.steps)),
                     ('batch_sweep', lambda: _batch_sweep_leg(G, D, dtype, T)),
                     ('fp32', lambda: _fp32_leg(G, D, T)),
@@ -676,9 +676,10 @@ def _batch_sweep_leg(G, D, dtype, T, batches=(1, 2, 4), steps=6):
 
 
 
-def _forward_only_leg(G, B, T, dtype, steps=6):
+def _forward_only_leg(G, B, T, dtype, steps=6, timer=None):
     """BASELINE.json's headline metric: frames/sec of the low-resolution generator FORWARD at 128 x 36 x 64
-    (inference: no gradient, no mask), replayed from a hipGraph like the main step."""
+    (inference: no gradient, no mask), replayed from a hipGraph like the main step. With `timer` (the main line's OpTimer) the
+    leg carries its own `roofline`: the launches of one more forward pass, re-timed per kernel family like the main step's."""
     with torch.no_grad():
         for _ in range(2):
             G(B, T, dtype=dtype)
@@ -694,8 +695,32 @@ def _forward_only_leg(G, B, T, dtype, steps=6):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
     del g
-    return {'metric': 'frames/sec/GPU lres-G forward 128x36x64', 'value': round(B * T / dt, 1), 'unit': 'frames/s',
-            'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'hipgraph'}
+    out = {'metric': 'frames/sec/GPU lres-G forward 128x36x64', 'value': round(B * T / dt, 1), 'unit': 'frames/s',
+           'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'batch': B, 'launch_mode': 'hipgraph'}
+    if timer is not None and not os.environ.get('LVG_BENCH_NO_ROOFLINE'):
+        timer.calls.clear()
+        timer.enabled = True
+        with torch.no_grad():
+            G(B, T, dtype=dtype)
+        timer.enabled = False
+        ops = timer.measure()
+        flop_ops = getattr(timer, 'flop_ops', set())
+        if ops:
+            name = max(ops, key=lambda k: ops[k]['total_ms'])
+            d = ops[name]
+            common = dict(kernel=name, launches=d['launches'], avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2), traffic=None,
+                          measured_on='all launches of this kernel from one forward pass, captured once each (pass order) into a hipGraph replayed 3x between HIP events on the launch stream')
+            if name in flop_ops:
+                tf = d['bytes'] / (d['total_ms'] * 1e-3) / 1e12
+                out['roofline'] = dict(bound='mfma', achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / MFMA_PEAK_TFLOPS, 4),
+                                       algorithmic_flops_per_launch=int(d['bytes'] / d['launches']), **common)
+            else:
+                out['roofline'] = dict(bound='hbm', achieved=round(d['gbps'], 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(d['gbps'] / HBM_PEAK_GBPS, 4),
+                                       algorithmic_bytes_per_launch=int(d['bytes'] / d['launches']), **common)
+            out['ms_in_custom_ops'] = round(sum(v['total_ms'] for v in ops.values()), 3)
+            out['ops'] = {k: (dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), tflops=round(v['gbps'] / 1e3, 1)) if k in flop_ops else
+                              dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1))) for k, v in ops.items()}
+    return out
 
 
 def _fp32_leg(G, D, T, B=8, steps=3):
