@@ -26,7 +26,7 @@
 // c ^ ((r >> 1) & 7): conflict-free `ds_read_b128` for any tap shift, since the 16-lane read groups cover 16
 // rows that are distinct modulo 16 -- SQ_LDS_BANK_CONFLICT = 0 measured) is applied to the per-lane SOURCE address.
 //
-// Measured facts the schedule is built on (profiles/r02_conv3d_igemm_*.csv, tools/gpu_conv_abl.sh):
+// Measured facts the schedule is built on (profiles/r02_conv3d_igemm_*.csv; the round-2 script is in the git history):
 //  * the K loop is bound by INSTRUCTION ISSUE, not by the matrix pipe or by bytes: the first version spent 160
 //    scalar + 90 vector instructions per K-step and wave next to its 16 MFMAs (31 % MFMA busy). Everything per-step
 //    is therefore strength-reduced: running 64-bit tile pointers in SGPRs with the SGPR-base form of the LDS-DMA

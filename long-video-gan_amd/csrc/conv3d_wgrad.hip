@@ -260,7 +260,7 @@ int compute_units()
 }
 
 // Split K so that the launch is ONE full round of workgroups, rounded DOWN: 184 registers allow two workgroups per CU, the LDS band
-// of 64-pixel-wide frames only one. Measured (tools/gpu_wgrad_splits.sh, profiles/r02_wgrad_splits.log): a launch of 520 workgroups on
+// of 64-pixel-wide frames only one. Measured (profiles/r02_wgrad_splits.log): a launch of 520 workgroups on
 // 512 slots takes 1.3x the time of one of 510 (the 8 stragglers run alone), and more splits than slots only add partial-sum traffic
 // (1024 splits of the 64-channel layer wrote and re-read 151 MB). LVG_WGRAD_SPLITS / LVG_WGRAD_TARGET override (measurements).
 int wgrad_splits(const WPlan& pl, int ci, int co, int kt)

@@ -117,7 +117,7 @@ def test_graph_mode_trains_like_eager_mode_gpu():
       generator gradients  eager vs graph <= 2e-5 of the largest,  running statistics <= 1e-6,
       discriminator weights <= 1e-3; its BIAS gradients <= 6e-2: at this small size they are sums of cancelling terms accumulated with
       atomics -- b32.conv1.bias takes one of a few values from run to run, up to 2.4e-2 of the largest gradient apart, in eager mode as
-      well (tools/diag_sres_small.py) --, so the tight gates sit on the weights and on the generator side, which sees the
+      well (round-5 diagnostic, removed from tools/ in round 6) --, so the tight gates sit on the weights and on the generator side, which sees the
       discriminator's whole backward pass,
     the sign statistics of the real logits counted once; then the float16 configuration: finite after three steps, one graph per phase."""
     kw = dict(SMALL, augment_p_init=0.0, augment_real_sign_target=None, in_augment_strength=0.0, lr_cond_prob=1.0,

@@ -62,7 +62,7 @@ def test_graph_mode_trains_like_eager_mode():
     """use_graphs=True replays the compute of update_G / update_D from hipGraphs, with the host-side draws (crop offsets, temporal stretch)
     handed over through static buffers. With the device-side randomness taken out (fixed temporal noise per shape, no DiffAugment -- captured
     and eager execution number the device generator differently) both modes compute the same step, and in FLOAT32 the step is
-    deterministic enough to be the yardstick (measured, tools/diag_graph_determinism.py, profiles/r05_graph_determinism.log: two eager
+    deterministic enough to be the yardstick (measured, profiles/r05_graph_determinism.log: two eager
     runs agree to 1e-6 of the largest generator gradient; the discriminator's bias gradients are sums with atomics and differ by 1e-4 ..
     2.5e-4 of the largest gradient between two EAGER runs; the running magnitudes agree exactly):
       generator gradients   eager vs graph  <= 2e-5 of the largest gradient   (measured 2e-7 .. 1e-6)
