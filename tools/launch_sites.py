@@ -1,0 +1,93 @@
+"""Which source lines launch the step's kernels: one eager generator update (G forward, D forward, backward) under torch.profiler with Python
+stacks; every device kernel launch is attributed to the innermost frame inside this repository. Prints launches per (file:line, kernel family),
+small kernels (< 12 us) first -- the map behind the per-step fixed cost.
+usage: python tools/launch_sites.py [--batch 1] [--frames 128] [--top 80]"""
+import argparse
+import collections
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'long-video-gan_amd'))
+_DB = os.path.join(ROOT, 'long-video-gan_amd', 'miopen_db')
+os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(_DB, 'db'))
+os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(_DB, 'cache'))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from torch.profiler import profile, ProfilerActivity  # noqa: E402
+
+from lvg import ddp  # noqa: E402
+from lvg.models import lres  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=1)
+ap.add_argument('--frames', type=int, default=128)
+ap.add_argument('--top', type=int, default=80)
+args = ap.parse_args()
+
+torch.manual_seed(0)
+dev = torch.device('cuda')
+G = lres.VideoGenerator().to(dev).requires_grad_(True).train()
+D = lres.VideoDiscriminator(seq_length=args.frames, max_edge=64).to(dev).requires_grad_(False).train()
+sync = ddp.FlatGradSync(G.parameters(), overlap=False)
+dtype = torch.bfloat16
+
+
+def step():
+    sync.zero()
+    with lres.deferred_magnitude_sync():
+        video = G(args.batch, args.frames, magnitude_ema_beta=0.999, dtype=dtype)
+    F.softplus(-D(video, dtype=dtype)).mean().backward()
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step()
+    torch.cuda.synchronize()
+
+events = prof.events()
+# device kernels carry no stack; their launching CPU op does. Walk: kernel -> correlated launch -> enclosing cpu op with a stack.
+by_site = collections.Counter()
+dur_site = collections.Counter()
+small_site = collections.Counter()
+pat = re.compile(r'(long-video-gan_amd/[^\s(]+\.py)\((\d+)\): (\S+)')
+# every CPU op event lists the device kernels it launched; count them at the innermost op and attribute them to the first frame inside this repository
+for ev in events:
+    if ev.device_type == torch.autograd.DeviceType.CUDA or not ev.kernels:
+        continue
+    if ev.cpu_children:            # count kernels at the innermost op only
+        inner = [c for c in ev.cpu_children if c.kernels]
+        if inner:
+            continue
+    site = 'autograd / unknown'
+    for frame in (ev.stack or []):
+        m = pat.search(frame)
+        if m:
+            site = f'{m.group(1).replace("long-video-gan_amd/", "")}:{m.group(2)} {m.group(3)}'
+            break
+    for k in ev.kernels:
+        name = re.sub(r'\(anonymous namespace\)::|void |at::native::', '', k.name)[:60]
+        key = (site, ev.name[:40], name)
+        by_site[key] += 1
+        dur_site[key] += k.duration
+        if k.duration < 12:
+            small_site[key] += 1
+total = sum(by_site.values())
+print(f'kernels in one eager step: {total}; under 12 us: {sum(small_site.values())}')
+agg = collections.Counter()
+agg_small = collections.Counter()
+agg_us = collections.Counter()
+for (site, op, name), c in by_site.items():
+    agg[site] += c
+    agg_small[site] += small_site[(site, op, name)]
+    agg_us[site] += dur_site[(site, op, name)]
+print('--- by source line (launches, of them small, total us)')
+for site, c in agg.most_common(args.top):
+    print(f'{c:5d} {agg_small[site]:5d} {agg_us[site]:9.0f}  {site}')
+print('--- by (source line, op, kernel), small kernels')
+for key, c in small_site.most_common(args.top):
+    print(f'{c:5d} {dur_site[key] / max(by_site[key], 1):7.1f} us  {key[0]} | {key[1]} | {key[2]}')
