@@ -45,7 +45,8 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
     torch.cuda.synchronize()
 
@@ -64,11 +65,16 @@ for ev in events:
         if inner:
             continue
     site = 'autograd / unknown'
-    for frame in (ev.stack or []):
-        m = pat.search(frame)
-        if m:
-            site = f'{m.group(1).replace("long-video-gan_amd/", "")}:{m.group(2)} {m.group(3)}'
-            break
+    cur = ev
+    while cur is not None and site == 'autograd / unknown':
+        for frame in (cur.stack or []):
+            m = pat.search(frame)
+            if m:
+                site = f'{m.group(1).replace("long-video-gan_amd/", "")}:{m.group(2)} {m.group(3)}'
+                break
+        if site == 'autograd / unknown' and cur.name and ('Backward' in cur.name or 'AccumulateGrad' in cur.name):
+            site = 'autograd node ' + cur.name[:60]
+        cur = cur.cpu_parent
     for k in ev.kernels:
         name = re.sub(r'\(anonymous namespace\)::|void |at::native::', '', k.name)[:60]
         key = (site, ev.name[:40], name)
