@@ -226,12 +226,22 @@ class FlatGradSync:
                         cur.wait_stream(st)
             self._work.append(dist.all_reduce(self.flat[s:e], async_op=True))
 
-    def zero(self) -> None:
-        """Zero the flat buffer and (re)attach the views as .grad of every parameter."""
+    def zero(self, assign: bool = False) -> None:
+        """Zero the flat buffer and (re)attach the views as .grad of every parameter.
+
+        `assign=True` (steps of ONE backward pass, not armed): the parameters' .grad are set to None instead, so autograd ASSIGNS each
+        incoming gradient (no launch) where it would otherwise add it into the zeroed view (one launch per parameter, ~100 per generator
+        update); `gather()` after the backward pass copies them into the flat buffer with a few multi-tensor launches and re-attaches the
+        views. Inside a captured phase `gather()` belongs to the phase (the replay then refills the flat buffer)."""
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
-            p.grad = v
+            p.grad = None if assign else v
         self._fired = [False] * len(self.params)
+
+    def gather(self) -> None:
+        """After a backward pass that followed `zero(assign=True)`: gradients -> flat buffer, views re-attached."""
+        assert not self._armed, 'FlatGradSync.gather: not with the overlapped exchange (its buckets read the flat buffer from the hooks)'
+        self._adopt_replaced_grads()
 
     def arm(self) -> None:
         """Call before the last backward of the step: buckets reduce as they fill."""
@@ -248,6 +258,7 @@ class FlatGradSync:
         view was otherwise not usable: `p.grad` is then a new tensor holding the full sum and the flat buffer
         is stale. Copy it in before anything is reduced; if that bucket has already been sent (overlap), the
         exchanged values are wrong and there is no way to repair them, so fail loudly."""
+        dst, src = [], []
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             g = p.grad
             if g is None or g is v or (g.data_ptr() == v.data_ptr() and g.shape == v.shape):
@@ -255,9 +266,12 @@ class FlatGradSync:
             if self._armed and self.bucket_of[i] in self._launched:
                 raise RuntimeError('FlatGradSync: autograd replaced the .grad view of a parameter whose bucket was already '
                                    'all-reduced (backward with create_graph=True under overlap=True); arm() only before a plain backward')
-            v.copy_(g.detach())
+            dst.append(v)
+            src.append(g.detach() if g.dtype == v.dtype else g.detach().to(v.dtype))
             self._fired[i] = True
             p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)                  # a few multi-tensor launches instead of one copy per parameter
 
     def finish(self, gain: Optional[float] = None, drop_unused: bool = True) -> None:
         """Complete the exchange: mean over ranks, * gain, nan_to_num. In place on the flat buffer.

@@ -1073,7 +1073,7 @@ class Synthesis3dResBlock(nn.Module):
         w0, mod_0, demod_0 = modulation_terms(self.weight_0, self.affine_0(lat).reshape(t, n, -1), True, dtype)
         w1, mod_1, demod_1 = modulation_terms(self.weight_1, self.affine_1(lat).reshape(t, n, -1), True, dtype)
         # parameter casts / constant scales: small launches that do not depend on the activations -- they belong here (second stream)
-        w_skip = self.weight_skip[:, :, 0] * (self.weight_skip_gain * SQRT_HALF)
+        w_skip = self.weight_skip.squeeze(2) * (self.weight_skip_gain * SQRT_HALF)
         return w0, mod_0, demod_0, w1, mod_1, demod_1, self.bias_0.to(dtype), self.bias_1.to(dtype), w_skip
 
     def forward_frames(self, x, latent: torch.Tensor, magnitude_ema_beta: float = 1.0,

@@ -417,6 +417,30 @@ def test_segmented_trainers_match_eager_world2():
     _spawn(_worker_segmented_lres)
 
 
+def test_flat_sync_assign_mode_equals_accumulate_mode():
+    """zero(assign=True) + gather(): the same flat buffer, the same .grad views and the same "unused parameter ends with grad None" as the
+    accumulate mode (single process; the exchange itself is world-size independent)."""
+    from lvg import ddp
+    results = []
+    for assign in (False, True):
+        net = _make_net(5)
+        unused = torch.nn.Parameter(torch.ones(3))
+        sync = ddp.FlatGradSync(list(net.parameters()) + [unused], overlap=False)
+        x = torch.randn(6, 37, generator=torch.Generator().manual_seed(9))
+        for _ in range(2):                                              # two steps: the views must be re-attached after the first
+            sync.zero(assign=assign)
+            net(x).square().sum().backward()
+            if assign:
+                assert all(p.grad is not v for p, v in zip(net.parameters(), sync.views))      # autograd assigned fresh tensors
+                sync.gather()
+            for p, v in zip(net.parameters(), sync.views):
+                assert p.grad is v
+            sync.finish(gain=0.5)
+        assert unused.grad is None
+        results.append(sync.flat.clone())
+    assert torch.equal(results[0], results[1])
+
+
 def test_flat_sync_adopts_replaced_grads_and_drops_unused():
     """Single process. (1) backward(create_graph=True) makes autograd REPLACE the .grad views: finish() must
     carry those values into the flat buffer (round-1 advisor finding: they were silently zeroed). (2) A

@@ -184,3 +184,41 @@ def test_graph_trainers_two_ranks_on_one_device():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+def test_flat_sync_assign_mode_inside_a_captured_step():
+    """FlatGradSync.zero(assign=True) ... backward ... gather() captured into a hipGraph (bench.py's main step): every replay refills the flat
+    buffer with that replay's gradients, equal to the eager accumulate-mode buffer bit for bit."""
+    from lvg import ddp
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Tanh(), torch.nn.Linear(96, 32)).cuda()
+    ref = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Tanh(), torch.nn.Linear(96, 32)).cuda()
+    ref.load_state_dict(net.state_dict())
+    sync, sync_ref = ddp.FlatGradSync(net.parameters(), overlap=False), ddp.FlatGradSync(ref.parameters(), overlap=False)
+    x = torch.zeros(16, 64, device='cuda')
+
+    def compute():
+        sync.zero(assign=True)
+        net(x).square().sum().backward()
+        sync.gather()
+
+    x.normal_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        compute()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        compute()
+    for _ in range(3):
+        x.normal_()
+        graph.replay()
+        sync.finish()
+        sync_ref.zero()
+        ref(x).square().sum().backward()
+        sync_ref.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(sync.flat, sync_ref.flat)
+        for p, v in zip(net.parameters(), sync.views):
+            assert p.grad is v
