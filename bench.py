@@ -286,18 +286,21 @@ def main():
     ema_beta = 0.999
     pending_emas = []
 
+    ASSIGN_GRADS = os.environ.get('LVG_BENCH_ASSIGN_GRADS', '1') != '0'      # (A/B: 0 = gradients added into the zeroed flat views)
+
     def compute():
         if args.forward_only:
             with torch.no_grad():
                 return G(B, T, dtype=dtype)
         # one backward pass per step: autograd assigns the gradients (no add into zeroed views, ~100 launches), gather() copies them into
         # the flat buffer with a few multi-tensor launches -- inside the captured region, so every replay refills the flat buffer
-        sync.zero(assign=True)
+        sync.zero(assign=ASSIGN_GRADS)
         with lres.deferred_magnitude_sync() as pending:
             video = G(B, T, magnitude_ema_beta=ema_beta, dtype=dtype)
         logits = D(video, dtype=dtype)
         F.softplus(-logits).mean().backward()
-        sync.gather()
+        if ASSIGN_GRADS:
+            sync.gather()
         pending_emas[:] = [pending, lres.stack_pending(pending) if pending else None,
                            ddp.stat_sync_plan(pending) if pending and world > 1 else None]      # (built when the step is captured, reused by every replay)
 
