@@ -892,7 +892,7 @@ def _sres_leg(dev, timer, segments=2, steps=6, warmup=2):
            'roofline': {'bound': 'hbm', 'kernel': 'filtered_lrelu', 'achieved': round(gb, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gb / HBM_PEAK_GBPS, 4),
                         'launches': n, 'avg_launch_us': round(tot_ms * 1e3 / max(n, 1), 2), 'algorithmic_bytes_per_launch': int(tot_b / max(n, 1)),
                         'traffic': _pmc_traffic('filtered_lrelu_fused16', 'sres') or _pmc_traffic('filtered_lrelu_wave', 'sres'), 'traffic_source': _TRAFFIC_SOURCE.format(scope='sres'),
-                        'traffic_scope': 'per launch of the 16-bit fused kernels (row-band + wave-per-tile), launch-weighted',
+                        'traffic_scope': 'per launch of the 16-bit fused kernels (strip + row-band + wave-per-tile), launch-weighted',
                         'algorithmic_bytes_per_launch_mfma_family': int(mf_bytes / max(mf_launches, 1)), 'launches_mfma_family': mf_launches,
                         'measured_on': 'all fused filtered_lrelu launches of one step (forward with mask write, backward with mask read), captured once each into a hipGraph per family, replayed 3x between HIP events',
                         'families': {k: dict(launches=v['launches'], total_ms=round(v['total_ms'], 3), gbps=round(v['gbps'], 1)) for k, v in ops.items()},

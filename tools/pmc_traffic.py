@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {'conv2d_wgrad': 'conv2d_wgrad', 'conv2d_igemm': ', 2, 2, true, ', 'conv3d_igemm': 'conv3d_igemm', 'conv3d_wgrad': 'conv3d_wgrad', 'bias_act': 'bias_act', 'upfirdn2d': 'upfirdn2d', 'filtered_lrelu_band': 'filtered_lrelu_band', 'filtered_lrelu_wave': 'filtered_lrelu_wave', 'filtered_lrelu_mfma': 'filtered_lrelu_mfma', 'filtered_lrelu': 'filtered_lrelu',
+FAMILIES = {'conv2d_wgrad': 'conv2d_wgrad', 'conv2d_igemm': ', 2, 2, true, ', 'conv3d_igemm': 'conv3d_igemm', 'conv3d_wgrad': 'conv3d_wgrad', 'bias_act': 'bias_act', 'upfirdn2d': 'upfirdn2d', 'filtered_lrelu_strip': 'filtered_lrelu_strip', 'filtered_lrelu_band': 'filtered_lrelu_band', 'filtered_lrelu_wave': 'filtered_lrelu_wave', 'filtered_lrelu_mfma': 'filtered_lrelu_mfma', 'filtered_lrelu': 'filtered_lrelu',
             'tapconv_epilogue': 'tapconv_', 'modconv_epilogue': 'epilogue_', 'modconv2d_layout': 'LayoutArgs'}     # first match wins
 
 
@@ -43,7 +43,7 @@ def main():
         out[fam + '_detail'] = dict(read_bytes=int(rd), write_bytes=int(wr), launches_profiled=nf[fam],
                                     note='FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported, KiB -> bytes')
     # the 16-bit fused filtered_lrelu launches of a step are shared between the row-band, wave-per-tile and four-wave kernels: one launch-weighted figure
-    fused = [f for f in ('filtered_lrelu_band', 'filtered_lrelu_wave', 'filtered_lrelu_mfma') if nf[f] or nw[f]]
+    fused = [f for f in ('filtered_lrelu_strip', 'filtered_lrelu_band', 'filtered_lrelu_wave', 'filtered_lrelu_mfma') if nf[f] or nw[f]]
     if fused:
         n = sum(max(nf[f], nw[f]) for f in fused)
         rd = 2.0 * 1024.0 * sum(fetch[f] for f in fused) / n
