@@ -6,7 +6,7 @@
 // of its workgroup) and three waves per SIMD do not cover it; going from two to three waves gave 1.33x. So here
 //   * a WAVE owns a column strip of 24 outputs of one plane (64 up-sampled columns for up 2 / down 2 and up 4 / down 2, 128 for
 //     up 2 / down 4: one block of output columns, half the accumulators of the row-band kernel) -- <= 128 registers, 12 to 16 waves
-//     per CU -- and walks down it in steps of 32 up-sampled rows; work items (plane, strip) are dealt out in contiguous runs;
+//     per CU -- and walks down it in steps of 32 up-sampled rows; work items (plane, strip) are dealt out round robin over the waves;
 //   * its input rows enter a wave-PRIVATE LDS ring (three K-chunks of 16 rows) through LDS-DMA; no barrier after the set-up, the
 //     chunk stream runs across item boundaries (the next strip's first rows are requested while the current strip finishes);
 //   * DMA origins are even columns (dword-aligned addresses); the odd residue, and the padding left of the image in a plane's first
@@ -60,7 +60,11 @@ struct StripArgs
     int phX, phY;
     int org0, base0, ef0;  // first strip of a plane: DMA origin column (multiple of 8, <= 0 when the padding reaches left of the image), ring column of its first column (0 or 4), fragment shift
     int ef1;               // other strips: DMA origin = first column rounded down to even, fragment shift = its parity
-    int waves;             // waves of the launch (items are dealt out in contiguous runs)
+    int waves;             // waves of the launch: wave g takes items g, g + waves, g + 2 waves, ... (neighbouring strips of a plane run side by side on
+                           // neighbouring waves: their overlapping input columns and adjacent output pieces meet in the L2 -- dealt out in contiguous runs the
+                           // strips of a plane followed each other on ONE wave, 8 us apart, and the counters showed twice the input bytes fetched from HBM)
+    int stepP, stepS;      // waves / ns, waves % ns: what one step of `waves` items adds to (plane, strip); (0, 1) when items are dealt out in contiguous runs
+    int rr;                // 1 = round robin
 };
 
 template <int UP, int DOWN, int FU, int FD, int NBC, int MODE>
@@ -247,10 +251,11 @@ __global__ __launch_bounds__(64 * WPB) void filtered_lrelu_strip_kernel(StripArg
         if (!(p.slope <= 1.0f) || !(tLimit > 0.0f)) tLimit = 0.0f;
     }
 
-    // ---- this wave's items: a contiguous run of (plane, strip) ------------------------------------------------------------------
+    // ---- this wave's items: (plane, strip) pairs gw, gw + waves, gw + 2 waves, ... ---------------------------------------------------
     const int gw = (int)blockIdx.x * WPB + w;
-    const int itemBeg = (int)((int64_t)q.items * gw / q.waves), itemEnd = (int)((int64_t)q.items * (gw + 1) / q.waves);
-    const int nItems = itemEnd - itemBeg;
+    // round robin (stepP / stepS = one step of `waves` items), or -- up 2 / down 4, measured faster that way -- contiguous runs (step = one strip)
+    const int itemBeg = q.rr ? gw : (int)((int64_t)q.items * gw / q.waves);
+    const int nItems = q.rr ? (gw < q.items ? (q.items - gw + q.waves - 1) / q.waves : 0) : (int)((int64_t)q.items * (gw + 1) / q.waves) - itemBeg;
     if (nItems <= 0) return;
     const int totalChunks = nItems * q.nch;
     const uint32_t rowBytes = (uint32_t)p.xw * 2u, planeBytes = (uint32_t)p.xh * rowBytes;
@@ -297,7 +302,9 @@ __global__ __launch_bounds__(64 * WPB) void filtered_lrelu_strip_kernel(StripArg
         if (++issChunk == q.nch)
         {
             issChunk = 0; issRowBase = (uint32_t)(q.inY0 * (int)rowBytes);
-            if (++issStrip == q.ns) { issStrip = 0; issPlanePtr += planeBytes; }
+            issStrip += q.stepS;
+            issPlanePtr += (uint64_t)q.stepP * planeBytes;
+            if (issStrip >= q.ns) { issStrip -= q.ns; issPlanePtr += planeBytes; }
             set_issue_lanes();                                               // (the origin moves with the strip)
         }
     };
@@ -626,7 +633,8 @@ __global__ __launch_bounds__(64 * WPB) void filtered_lrelu_strip_kernel(StripArg
             young = storesNow;
         }
         itemChunk0 += q.nch;
-        if (++strip == q.ns) { strip = 0; ++plane; }
+        strip += q.stepS; plane += q.stepP;
+        if (strip >= q.ns) { strip -= q.ns; ++plane; }
     }
     if (LVG_SDUMMY_V || LVG_SDUMMY_M)
     {
@@ -732,7 +740,9 @@ int launch_strip(FlreluArgs& a, int mode, hipStream_t stream)
         if (gridEnv > 0 && gridEnv < maxGrid) maxGrid = gridEnv; \
         int64_t wantWg = ((int64_t)q.items + WPB - 1) / WPB; \
         const unsigned grid = (unsigned)(wantWg < maxGrid ? wantWg : maxGrid); \
-        q.waves = (int)grid * WPB; \
+        q.waves = (int)grid * WPB; q.rr = DOWN == 4 ? 0 : 1; \
+        { static const char* ev_ = getenv("LVG_FLRELU_STRIP_RR"); if (ev_) q.rr = atoi(ev_) ? 1 : 0; }      /* (A/B measurements) */ \
+        q.stepP = q.rr ? q.waves / q.ns : 0; q.stepS = q.rr ? q.waves % q.ns : 1; \
         if (getenv("LVG_FLRELU_DEBUG")) fprintf(stderr, "filtered_lrelu_strip: up %d down %d mode %d: planes %d, strips %d, v-blocks %d, chunks %d, org0 %d base0 %d ef %d/%d, lds %zu, %d workgroups/CU, grid %u x %d waves\n", \
             UP, DOWN, M, q.planes, q.ns, q.nvb, q.nch, q.org0, q.base0, q.ef0, q.ef1, lds, perCu, grid, WPB); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, q); } while (0)
@@ -750,13 +760,14 @@ int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all
     if (dtype != LVG_F16) return LVG_ERR_UNSUPPORTED;
     if (!all)
     {
-        // Measured against the band / wave kernels on the launches of the sres step (16 frames, cold operands; profiles/r06_sres_ab.log):
-        // faster on planes of up to four strips -- up 2 / down 4 backward at output widths 38, 54 and 86 (120 -> 108, 249 -> 175, 330 -> 308 us),
-        // the forward modes at width 84 (up 4 / down 2: 134 -> 111 us, up 2 / down 2: 158 -> 136 us) -- and slower on the wide planes, where its
-        // 96-byte row pieces and 8-byte stores cost more than the row-band kernel's barrier.
+        // Measured against the band / wave kernels on the launches of the sres step (16 frames, cold operands; profiles/r06_sres_ab_routed.log,
+        // r06_sres_ab_all.log): faster on planes of up to four strips -- up 2 / down 4 backward at output widths 38 and 54 (120 -> 113, 249 -> 174 us;
+        // at width 86 it ties with the row-band kernel, 308-356 against 330 us, and is left there), up 4 / down 2 forward at width 84 (134 -> 96 us),
+        // up 2 / down 2 at widths 84 / 86 forward (158 -> 102 us) and backward (138 -> 118 us) -- and slower on the wide planes, where its 96-byte
+        // row pieces and 8-byte stores cost more than the row-band kernel's barrier.
         bool take = false;
-        if (cfg == LVG_FLRELU_CFG_U2D4) take = p.yw <= 96;
-        else take = mode != LVG_SIGNS_READ && p.yw > 52 && p.yw <= 96;
+        if (cfg == LVG_FLRELU_CFG_U2D4) take = p.yw <= 64;
+        else take = p.yw > 52 && p.yw <= 96;
         if (!take) return LVG_ERR_UNSUPPORTED;
     }
     switch (cfg)
