@@ -767,7 +767,7 @@ int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all
         // row pieces and 8-byte stores cost more than the row-band kernel's barrier.
         bool take = false;
         if (cfg == LVG_FLRELU_CFG_U2D4) take = p.yw <= 64;
-        else take = p.yw > 52 && p.yw <= 96;
+        else take = p.yw > 72 && p.yw <= 96;          // (width 54 = 24 + 24 + 6: slower, 67 against 56 us)
         if (!take) return LVG_ERR_UNSUPPORTED;
     }
     switch (cfg)
