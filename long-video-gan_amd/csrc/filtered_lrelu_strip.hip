@@ -554,6 +554,7 @@ __global__ __launch_bounds__(64 * WPB) void filtered_lrelu_strip_kernel(StripArg
                 const int nOwn = lastStrip ? p.sWBytes - signByte0 : (kTW * DOWN) / 4;
                 const int sy = 32 * b + n;
                 uint8_t* srow = sPlane + (uint32_t)(sy * p.sWBytes) + signByte0;
+                uint32_t mv[NBC], pv[NBC];                                  // this lane's dword of every column block, its partner lane's (other half wave, same row)
                 #pragma unroll
                 for (int bc = 0; bc < NBC; bc++)
                 {
@@ -562,12 +563,37 @@ __global__ __launch_bounds__(64 * WPB) void filtered_lrelu_strip_kernel(StripArg
                     const int o = 8 * bc + 4 * g;
                     const int nv = p.swLimit - (signByte0 + o);               // bytes at and beyond swLimit carry no pixels: zeros
                     if (nv < 4) v = nv <= 0 ? 0u : (v & ((1u << (8 * nv)) - 1u));
-                    if (8 * bc < nOwn)
+                    mv[bc] = v;
+                    const uint2v ex = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                    pv[bc] = g ? ex[0] : ex[1];
+                }
+                // One store per lane: the lanes of half wave g own bytes 16 g .. 16 g + 15 of their row (NBC = 2: the lower half wave stores the whole
+                // 12- / 16-byte piece of the row, the upper one nothing) -- 12 or 16 contiguous bytes per row instead of three 4-byte pieces.
+                if (sy < p.sH && !(LVG_SABL & 16))
+                {
+                    if (NBC == 2)
                     {
-                        if (o + 4 <= nOwn && sy < p.sH && !(LVG_SABL & 16)) *reinterpret_cast<uint32_t*>(srow + o) = v;
-                        if (32 * b < p.sH && !(LVG_SABL & 16)) storesNow += 1;
+                        const int k = nOwn >> 2;                              // dwords of the row this strip owns (3; the last strip: up to 4)
+                        if (g == 0)
+                        {
+                            if (k >= 4)      *reinterpret_cast<uint4*>(srow) = make_uint4(mv[0], pv[0], mv[1], pv[1]);
+                            else if (k == 3) { *reinterpret_cast<uint2*>(srow) = make_uint2(mv[0], pv[0]); *reinterpret_cast<uint32_t*>(srow + 8) = mv[1]; }
+                            else if (k == 2) *reinterpret_cast<uint2*>(srow) = make_uint2(mv[0], pv[0]);
+                            else if (k == 1) *reinterpret_cast<uint32_t*>(srow) = mv[0];
+                        }
+                    }
+                    else
+                    {
+                        const int k = min(4, max(0, (nOwn >> 2) - 4 * g));
+                        const uint32_t d0 = g ? pv[2] : mv[0], d1 = g ? mv[2] : pv[0], d2 = g ? pv[NBC - 1] : mv[1], d3 = g ? mv[NBC - 1] : pv[1];
+                        uint8_t* dst = srow + 16 * g;
+                        if (k >= 4)      *reinterpret_cast<uint4*>(dst) = make_uint4(d0, d1, d2, d3);
+                        else if (k == 3) { *reinterpret_cast<uint2*>(dst) = make_uint2(d0, d1); *reinterpret_cast<uint32_t*>(dst + 8) = d2; }
+                        else if (k == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(d0, d1);
+                        else if (k == 1) *reinterpret_cast<uint32_t*>(dst) = d0;
                     }
                 }
+                if (32 * b < p.sH && nOwn >= 4 && !(LVG_SABL & 16)) storesNow += 1;      // (lower bound of the store instructions issued)
             }
 
             // ---- stage D, streaming (see filtered_lrelu_band.hip): the two K-chunks of this v-block feed output block
@@ -582,15 +608,29 @@ __global__ __launch_bounds__(64 * WPB) void filtered_lrelu_strip_kernel(StripArg
                 };
                 auto store_block = [&](const uint32_t (&ypk)[8], int oy0) __attribute__((always_inline)) -> int
                 {
-                    // lane (n, g): output row oy0 + n, columns 8 qd + 4 g .. + 3 as one 8-byte store
+                    // lane (n, g): output row oy0 + n. Full strips: the two half waves exchange their first / second quad so that lane (n, g) holds
+                    // columns 8 g .. 8 g + 7 (one 16-byte store) and its own four of columns 16 .. 23 (8 bytes); ragged strips: 8- / 4-byte pieces.
                     const int oy = oy0 + n;
+                    if (LVG_SABL & 2) return 0;
+                    char* rowp = yPlane + (uint32_t)oy * yRowB;
+                    if (colsHere == kTW)
+                    {
+                        const uint2v e0 = __builtin_amdgcn_permlane32_swap(ypk[0], ypk[2], false, false);
+                        const uint2v e1 = __builtin_amdgcn_permlane32_swap(ypk[1], ypk[3], false, false);
+                        if (oy < p.yh)
+                        {
+                            *reinterpret_cast<uint4*>(rowp + 16 * g) = make_uint4(e0[0], e1[0], e0[1], e1[1]);
+                            *reinterpret_cast<uint2*>(rowp + 32 + 8 * g) = make_uint2(ypk[4], ypk[5]);
+                        }
+                        return 2;
+                    }
                     int issued = 0;
                     #pragma unroll
                     for (int qd = 0; qd < kTW / 8; qd++)
                     {
                         const int c = 8 * qd + 4 * g;
-                        char* dst = yPlane + (uint32_t)oy * yRowB + (uint32_t)c * 2u;
-                        if (8 * qd < colsHere && !(LVG_SABL & 2))
+                        char* dst = rowp + (uint32_t)c * 2u;
+                        if (8 * qd < colsHere)
                         {
                             if (oy < p.yh)
                             {
@@ -761,12 +801,12 @@ int lvg_flrelu_strip_launch(FlreluArgs& p, int cfg, int mode, int dtype, int all
     if (!all)
     {
         // Measured against the band / wave kernels on the launches of the sres step (16 frames, cold operands; profiles/r06_sres_ab_routed.log,
-        // r06_sres_ab_all.log): faster on planes of up to four strips -- up 2 / down 4 backward at output widths 38 and 54 (120 -> 113, 249 -> 174 us;
-        // at width 86 it ties with the row-band kernel, 308-356 against 330 us, and is left there), up 4 / down 2 forward at width 84 (134 -> 96 us),
+        // r06_sres_ab_all.log): faster on planes of up to four strips -- up 2 / down 4 backward at output widths 38, 54 and 86 (120 -> 109, 249 -> 176,
+        // 330 -> 309 us; items in contiguous runs there, round robin measured 356), up 4 / down 2 forward at width 84 (134 -> 96 us),
         // up 2 / down 2 at widths 84 / 86 forward (158 -> 102 us) and backward (138 -> 118 us) -- and slower on the wide planes, where its 96-byte
         // row pieces and 8-byte stores cost more than the row-band kernel's barrier.
         bool take = false;
-        if (cfg == LVG_FLRELU_CFG_U2D4) take = p.yw <= 64;
+        if (cfg == LVG_FLRELU_CFG_U2D4) take = p.yw <= 96;
         else take = p.yw > 72 && p.yw <= 96;          // (width 54 = 24 + 24 + 6: slower, 67 against 56 us)
         if (!take) return LVG_ERR_UNSUPPORTED;
     }
