@@ -520,23 +520,31 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x,
     constexpr int V = Elem<T>::kVec;
     if (vec)
     {
-        const int nv = hw / V;
+        // 16-byte loads over the aligned interior of the plane, element loads for the (< V) elements in front of it and behind it: planes
+        // of 94 x 150 or 166 x 278 half-precision pixels are not multiples of 16 bytes, so every second plane starts 8 bytes off -- the
+        // all-or-nothing test of the first version sent exactly the large sres planes down the 2-byte path (1.4-1.7 TB/s)
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
+        int head = (int)(((16 - (addr & 15)) & 15) / sizeof(T));
+        if (head > hw) head = hw;
+        const T* body = row + head;
+        const int nv = (hw - head) / V;
         float s2 = 0.f;
         int i = threadIdx.x;
         for (; i + 256 < nv; i += 512)                                // two independent 16-byte loads in flight per trip
         {
-            const Vec16<T> a = load_vec16<T>(row + (int64_t)i * V), b = load_vec16<T>(row + (int64_t)(i + 256) * V);
+            const Vec16<T> a = load_vec16<T>(body + (int64_t)i * V), b = load_vec16<T>(body + (int64_t)(i + 256) * V);
             #pragma unroll
             for (int e = 0; e < V; e++) { s += (float)to_acc(a.v[e]); s2 += (float)to_acc(b.v[e]); }
         }
         if (i < nv)
         {
-            const Vec16<T> a = load_vec16<T>(row + (int64_t)i * V);
+            const Vec16<T> a = load_vec16<T>(body + (int64_t)i * V);
             #pragma unroll
             for (int e = 0; e < V; e++) s += (float)to_acc(a.v[e]);
         }
         s += s2;
-        for (int j = nv * V + threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
+        if ((int)threadIdx.x < head) s += (float)to_acc(row[threadIdx.x]);
+        for (int j = head + nv * V + threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
     }
     else
         for (int j = threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
@@ -553,7 +561,7 @@ extern "C" int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t 
     LVG_REQUIRE(x && out && planes >= 1 && planes <= 0x7fffffffLL && hw >= 1 && hw <= 0x7fffffffLL, "plane_sum: bad sizes");
     LVG_REQUIRE(dtype == LVG_F32 || dtype == LVG_F16 || dtype == LVG_BF16, "plane_sum: float32 / float16 / bfloat16 only (dtype %d)", dtype);
     const int esz = dtype == LVG_F32 ? 4 : 2;
-    const int vec = lvg_aligned16(x) && (hw * esz) % 16 == 0;
+    const int vec = (((uintptr_t)x) % esz) == 0 && hw >= 64;          // (element-aligned base: every plane then has a 16-byte-aligned interior)
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LVG_F32)       hipLaunchKernelGGL(plane_sum_kernel<float>, dim3((unsigned)planes), dim3(256), 0, s, (const float*)x, out, (int)hw, vec);
     else if (dtype == LVG_F16)  hipLaunchKernelGGL(plane_sum_kernel<f16_t>, dim3((unsigned)planes), dim3(256), 0, s, (const f16_t*)x, out, (int)hw, vec);
