@@ -359,6 +359,11 @@ int lvg_weight_dgrad_pack(const void* wp, void* wt, int taps, int co, int ci, vo
  * (reference torch_utils/ops/filtered_lrelu.py:254); the caller adds the samples of a channel. */
 int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream);
 
+/* out[plane] = sum of the SQUARES of the hw elements of plane `plane` (float32 accumulation, fixed order): one pass over a 16-bit or
+ * float32 activation for the mean-square statistic of the generators' input-magnitude EMAs, x.float().square().mean() in the reference
+ * (model/generator_sres.py:278-286, model/generator_lres.py:298-312): the caller adds the planes and divides by the element count. */
+int lvg_plane_sum_sq(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream);
+
 /*
  * Fused stages of the ADA augmentation pipeline (csrc/ada_augment.hip; reference model/ada_augment.py).
  *   lvg_ada_warp: the geometric stage (:271-304: reflect padding by `margins`, x2 up-sampling with the 12-tap low-pass, bilinear

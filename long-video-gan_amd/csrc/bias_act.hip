@@ -511,9 +511,11 @@ extern "C" int lvg_bias_act_grad_bias(const void* dy, const void* xref, const vo
 // N sums of a channel.
 namespace {
 
-template <class T>
+template <class T, bool SQ>
 __global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int hw, int vec)
 {
+    // SQ: sum of squares (the mean-square statistic of the generators' input-magnitude EMAs)
+    auto term = [](float v) __attribute__((always_inline)) -> float { return SQ ? v * v : v; };
     __shared__ float red[4];
     const T* row = x + (int64_t)blockIdx.x * hw;
     float s = 0.f;
@@ -534,20 +536,20 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x,
         {
             const Vec16<T> a = load_vec16<T>(body + (int64_t)i * V), b = load_vec16<T>(body + (int64_t)(i + 256) * V);
             #pragma unroll
-            for (int e = 0; e < V; e++) { s += (float)to_acc(a.v[e]); s2 += (float)to_acc(b.v[e]); }
+            for (int e = 0; e < V; e++) { s += term((float)to_acc(a.v[e])); s2 += term((float)to_acc(b.v[e])); }
         }
         if (i < nv)
         {
             const Vec16<T> a = load_vec16<T>(body + (int64_t)i * V);
             #pragma unroll
-            for (int e = 0; e < V; e++) s += (float)to_acc(a.v[e]);
+            for (int e = 0; e < V; e++) s += term((float)to_acc(a.v[e]));
         }
         s += s2;
-        if ((int)threadIdx.x < head) s += (float)to_acc(row[threadIdx.x]);
-        for (int j = head + nv * V + threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
+        if ((int)threadIdx.x < head) s += term((float)to_acc(row[threadIdx.x]));
+        for (int j = head + nv * V + threadIdx.x; j < hw; j += 256) s += term((float)to_acc(row[j]));
     }
     else
-        for (int j = threadIdx.x; j < hw; j += 256) s += (float)to_acc(row[j]);
+        for (int j = threadIdx.x; j < hw; j += 256) s += term((float)to_acc(row[j]));
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -556,15 +558,26 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x,
 
 } // namespace
 
-extern "C" int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
+template <bool SQ>
+static int plane_sum_launch(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream, const char* what)
 {
-    LVG_REQUIRE(x && out && planes >= 1 && planes <= 0x7fffffffLL && hw >= 1 && hw <= 0x7fffffffLL, "plane_sum: bad sizes");
-    LVG_REQUIRE(dtype == LVG_F32 || dtype == LVG_F16 || dtype == LVG_BF16, "plane_sum: float32 / float16 / bfloat16 only (dtype %d)", dtype);
+    LVG_REQUIRE(x && out && planes >= 1 && planes <= 0x7fffffffLL && hw >= 1 && hw <= 0x7fffffffLL, "%s: bad sizes", what);
+    LVG_REQUIRE(dtype == LVG_F32 || dtype == LVG_F16 || dtype == LVG_BF16, "%s: float32 / float16 / bfloat16 only (dtype %d)", what, dtype);
     const int esz = dtype == LVG_F32 ? 4 : 2;
     const int vec = (((uintptr_t)x) % esz) == 0 && hw >= 64;          // (element-aligned base: every plane then has a 16-byte-aligned interior)
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == LVG_F32)       hipLaunchKernelGGL(plane_sum_kernel<float>, dim3((unsigned)planes), dim3(256), 0, s, (const float*)x, out, (int)hw, vec);
-    else if (dtype == LVG_F16)  hipLaunchKernelGGL(plane_sum_kernel<f16_t>, dim3((unsigned)planes), dim3(256), 0, s, (const f16_t*)x, out, (int)hw, vec);
-    else                        hipLaunchKernelGGL(plane_sum_kernel<bf16_t>, dim3((unsigned)planes), dim3(256), 0, s, (const bf16_t*)x, out, (int)hw, vec);
-    return lvg_check_launch("plane_sum");
+    if (dtype == LVG_F32)       hipLaunchKernelGGL((plane_sum_kernel<float, SQ>), dim3((unsigned)planes), dim3(256), 0, s, (const float*)x, out, (int)hw, vec);
+    else if (dtype == LVG_F16)  hipLaunchKernelGGL((plane_sum_kernel<f16_t, SQ>), dim3((unsigned)planes), dim3(256), 0, s, (const f16_t*)x, out, (int)hw, vec);
+    else                        hipLaunchKernelGGL((plane_sum_kernel<bf16_t, SQ>), dim3((unsigned)planes), dim3(256), 0, s, (const bf16_t*)x, out, (int)hw, vec);
+    return lvg_check_launch(what);
+}
+
+extern "C" int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
+{
+    return plane_sum_launch<false>(x, out, planes, hw, dtype, stream, "plane_sum");
+}
+
+extern "C" int lvg_plane_sum_sq(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
+{
+    return plane_sum_launch<true>(x, out, planes, hw, dtype, stream, "plane_sum_sq");
 }

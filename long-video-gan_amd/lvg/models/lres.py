@@ -30,7 +30,7 @@ import contextlib
 
 from .. import ddp
 
-from torch_utils.ops import bias_act, conv3d_frames, noise_bank, pointwise_thin, style_prep, upfirdn2d, weight_prep
+from torch_utils.ops import bias_act, conv3d_frames, noise_bank, pointwise_thin, stats, style_prep, upfirdn2d, weight_prep
 from torch_utils.ops.modconv_epilogue import dual_supported, modconv_epilogue, modconv_epilogue_dual, tap_gather_backward, tap_gather_forward
 
 SQRT_HALF = math.sqrt(0.5)
@@ -153,7 +153,7 @@ class MagnitudeEMA(nn.Module):
 
     def forward(self, x: torch.Tensor, beta: float = 1.0) -> torch.Tensor:
         if beta != 1:
-            return self.update(x.detach().float().square().mean(), beta)
+            return self.update(stats.mean_square(x), beta)
         return self.magnitude_ema.rsqrt()
 
 

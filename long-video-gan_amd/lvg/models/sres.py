@@ -34,7 +34,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import torch_utils.distributed as dist_utils
-from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, modconv2d_layout, upfirdn2d, weight_prep
+from torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, filtered_lrelu, modconv2d_layout, stats, upfirdn2d, weight_prep
 
 from .. import ddp
 from .lres import FullyConnectedLayer, _linear_filter
@@ -263,10 +263,12 @@ class SynthesisLayer(nn.Module):
             assert x.shape[1:] == (self.in_channels, int(self.in_size[1]), int(self.in_size[0])), x.shape
         if update_emas:
             if fused:       # mean square over the concatenated input
-                parts = [t.detach().float().square().sum() for t in (x, cond) if t is not None]
-                mag = sum(parts) / float(sum(t.numel() for t in (x, cond) if t is not None))
+                # (stats.mean_square: one pass over the 16-bit activation instead of cast + square + reduce)
+                counts = [float(t.numel()) for t in (x, cond) if t is not None]
+                parts = [stats.mean_square(t) * c for t, c in zip([t for t in (x, cond) if t is not None], counts)]
+                mag = sum(parts) / sum(counts)
             else:
-                mag = x.detach().float().square().mean()
+                mag = stats.mean_square(x)
             ddp.ema_of_rank_mean(self.magnitude_ema, mag.detach(), self.magnitude_ema_beta, ddp.LERP_FROM)
         input_gain = self.magnitude_ema.rsqrt()
 

@@ -303,3 +303,20 @@ def _kernel_forward_backward_vs_oracle(case, clamp, oracle):
             y2 = filtered_lrelu.filtered_lrelu(x, torch.tensor(fu, device=DEV), torch.tensor(fd, device=DEV), b,
                                                up=up, down=down, padding=pad, gain=np.sqrt(2), slope=0.2, clamp=clamp)
         assert torch.equal(y2, y.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape,cl', [((2, 155, 148, 276), False), ((16, 362, 94, 150), True), ((3, 7, 33, 57), False), ((1, 5, 128, 36, 64), False)])
+def test_mean_square_statistic(shape, cl, dtype):
+    """torch_utils.ops.stats.mean_square (lvg_plane_sum_sq: one pass, float32 accumulation) == x.float().square().mean() of the reference's
+    input-magnitude statistic (generator_sres.py:278-286), on contiguous and channels-last tensors, with a tail that is not a whole chunk."""
+    from torch_utils.ops import stats
+    torch.manual_seed(5)
+    x = torch.randn(shape, device='cuda').to(dtype) * 3
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    got = stats.mean_square(x)
+    want = x.double().square().mean()
+    assert got.dtype == torch.float32 and got.shape == ()
+    assert abs(float(got) - float(want)) <= 2e-6 * float(want)
