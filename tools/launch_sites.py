@@ -25,7 +25,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--frames', type=int, default=128)
 ap.add_argument('--top', type=int, default=80)
-ap.add_argument('--net', default='lres', choices=['lres', 'sres'])
+ap.add_argument('--net', default='lres', choices=['lres', 'sres', 'train_sres', 'train_lres'])
+ap.add_argument('--big', type=float, default=15.0, help='also list aten kernels of at least this many us (passes over activations written as tensor expressions)')
 args = ap.parse_args()
 
 torch.manual_seed(0)
@@ -41,6 +42,26 @@ if args.net == 'lres':
         with lres.deferred_magnitude_sync():
             video = G(args.batch, args.frames, magnitude_ema_beta=0.999, dtype=dtype)
         F.softplus(-D(video, dtype=dtype)).mean().backward()
+elif args.net == 'train_sres':
+    # one full iteration of SuperResTrainer (update_G + update_D with fake generation, ADA on), eager, micro-batches of 2 segments
+    from lvg.train_sres import SuperResTrainer
+    tr = SuperResTrainer(device='cuda', compute_dtype=torch.float16, G_grad_accum=2, D_grad_accum=2, augment_p_init=0.2, overlap_grad_sync=False, with_ema=True)
+    lr_clip = torch.rand(4, 3, tr.context_seq_length, 36, 64, device='cuda') * 2 - 1
+    hr_clip = torch.rand(4, 3, tr.seq_length, 144, 256, device='cuda') * 2 - 1
+    state = dict(n=1)
+
+    def step():
+        tr.train_step(state['n'], lr_clip, hr_clip)
+        state['n'] += 1
+elif args.net == 'train_lres':
+    from lvg.train_lres import LowResTrainer
+    tr = LowResTrainer(seq_length=args.frames, device=dev, compute_dtype=torch.bfloat16, G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=False, with_ema=True)
+    real = torch.rand(2, 3, args.frames, 36, 64, device=dev) * 2 - 1
+    state = dict(n=1)
+
+    def step():
+        tr.train_step(state['n'], real)
+        state['n'] += 1
 else:
     # the sres leg of bench.py: generator update of SuperResTrainer on two segments
     from lvg.train_sres import SuperResTrainer
@@ -108,6 +129,14 @@ for (site, op, name), c in by_site.items():
 print('--- by source line (launches, of them small, total us)')
 for site, c in agg.most_common(args.top):
     print(f'{c:5d} {agg_small[site]:5d} {agg_us[site]:9.0f}  {site}')
+print(f'--- aten / library kernels of at least {args.big} us: launches, avg us, total us')
+big = collections.Counter(); big_us = collections.Counter()
+for (site, op, name), c in by_site.items():
+    avg = dur_site[(site, op, name)] / c
+    if avg >= args.big and (op.startswith('aten::') or 'Backward' in site) and not any(k in name for k in ('igemm', 'wgrad', 'filtered_lrelu', 'upfirdn', 'bias_act', 'epilogue', 'nhwc', 'nchw', 'Cijk', 'ada_', 'style_', 'weight_prep')):
+        big[(site, op, name)] += c; big_us[(site, op, name)] += dur_site[(site, op, name)]
+for key, us in big_us.most_common(args.top):
+    print(f'{big[key]:5d} {us / big[key]:8.1f} {us:9.0f}  {key[0]} | {key[1]} | {key[2]}')
 print('--- by (source line, op, kernel), small kernels')
 for key, c in small_site.most_common(args.top):
     print(f'{c:5d} {dur_site[key] / max(by_site[key], 1):7.1f} us  {key[0]} | {key[1]} | {key[2]}')
