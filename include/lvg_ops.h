@@ -363,6 +363,20 @@ int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dty
  * float32 activation for the mean-square statistic of the generators' input-magnitude EMAs, x.float().square().mean() in the reference
  * (model/generator_sres.py:278-286, model/generator_lres.py:298-312): the caller adds the planes and divides by the element count. */
 int lvg_plane_sum_sq(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream);
+/* out[plane] = max |x| over the plane (NaN-ignoring fmax): the tensor maximum behind the power-of-two scale of a split-precision operand
+ * (torch_utils/ops/conv2d_frames.py::pow2_scale) without an abs() copy of the tensor. */
+int lvg_plane_absmax(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream);
+
+/*
+ * Operand of the split-precision contraction of the sres generator's float32 layers in one pass (no reference counterpart: the reference
+ * runs these layers as float32 convolutions, model/generator_sres.py:24-67): float32 NCHW planes src [n, c, src_h, src_w], times mul[n, c]
+ * (or NULL), times the device scalar scale[0] (or NULL; a power of two), split into float16 parts (part 0 = rounding of the value,
+ * part 1 = rounding of the remainder) and written channels-last into the interior (off_y, off_x) of a frame dst [n, dst_h, dst_w,
+ * n_blocks * c_pad] as n_blocks stacked channel blocks; bit blk of `pattern` selects the part of block blk. Border and padding channels are
+ * left untouched (zero-fill the frame once).
+ */
+int lvg_split16_frames(const float* src, const float* mul, const float* scale, void* dst, int64_t n, int c, int src_h, int src_w,
+                       int dst_h, int dst_w, int off_y, int off_x, int c_pad, int n_blocks, int pattern, void* stream);
 
 /*
  * Fused stages of the ADA augmentation pipeline (csrc/ada_augment.hip; reference model/ada_augment.py).

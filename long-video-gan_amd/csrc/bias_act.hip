@@ -511,11 +511,12 @@ extern "C" int lvg_bias_act_grad_bias(const void* dy, const void* xref, const vo
 // N sums of a channel.
 namespace {
 
-template <class T, bool SQ>
+template <class T, int SQ>
 __global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int hw, int vec)
 {
-    // SQ: sum of squares (the mean-square statistic of the generators' input-magnitude EMAs)
-    auto term = [](float v) __attribute__((always_inline)) -> float { return SQ ? v * v : v; };
+    // SQ = 1: sum of squares (the mean-square statistic of the generators' input-magnitude EMAs); SQ = 2: max |x| (the scale of a split-precision operand)
+    auto term = [](float v) __attribute__((always_inline)) -> float { return SQ == 1 ? v * v : (SQ == 2 ? fabsf(v) : v); };
+    auto acc = [](float a_, float b_) __attribute__((always_inline)) -> float { return SQ == 2 ? fmaxf(a_, b_) : a_ + b_; };
     __shared__ float red[4];
     const T* row = x + (int64_t)blockIdx.x * hw;
     float s = 0.f;
@@ -536,29 +537,29 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const T* __restrict__ x,
         {
             const Vec16<T> a = load_vec16<T>(body + (int64_t)i * V), b = load_vec16<T>(body + (int64_t)(i + 256) * V);
             #pragma unroll
-            for (int e = 0; e < V; e++) { s += term((float)to_acc(a.v[e])); s2 += term((float)to_acc(b.v[e])); }
+            for (int e = 0; e < V; e++) { s = acc(s, term((float)to_acc(a.v[e]))); s2 = acc(s2, term((float)to_acc(b.v[e]))); }
         }
         if (i < nv)
         {
             const Vec16<T> a = load_vec16<T>(body + (int64_t)i * V);
             #pragma unroll
-            for (int e = 0; e < V; e++) s += term((float)to_acc(a.v[e]));
+            for (int e = 0; e < V; e++) s = acc(s, term((float)to_acc(a.v[e])));
         }
-        s += s2;
-        if ((int)threadIdx.x < head) s += term((float)to_acc(row[threadIdx.x]));
-        for (int j = head + nv * V + threadIdx.x; j < hw; j += 256) s += term((float)to_acc(row[j]));
+        s = acc(s, s2);
+        if ((int)threadIdx.x < head) s = acc(s, term((float)to_acc(row[threadIdx.x])));
+        for (int j = head + nv * V + threadIdx.x; j < hw; j += 256) s = acc(s, term((float)to_acc(row[j])));
     }
     else
-        for (int j = threadIdx.x; j < hw; j += 256) s += term((float)to_acc(row[j]));
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int j = threadIdx.x; j < hw; j += 256) s = acc(s, term((float)to_acc(row[j])));
+    for (int o = 32; o > 0; o >>= 1) s = acc(s, __shfl_xor(s, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc(acc(red[0], red[1]), acc(red[2], red[3]));
 }
 
 } // namespace
 
-template <bool SQ>
+template <int SQ>
 static int plane_sum_launch(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream, const char* what)
 {
     LVG_REQUIRE(x && out && planes >= 1 && planes <= 0x7fffffffLL && hw >= 1 && hw <= 0x7fffffffLL, "%s: bad sizes", what);
@@ -574,10 +575,15 @@ static int plane_sum_launch(const void* x, float* out, int64_t planes, int64_t h
 
 extern "C" int lvg_plane_sum(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
 {
-    return plane_sum_launch<false>(x, out, planes, hw, dtype, stream, "plane_sum");
+    return plane_sum_launch<0>(x, out, planes, hw, dtype, stream, "plane_sum");
 }
 
 extern "C" int lvg_plane_sum_sq(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
 {
-    return plane_sum_launch<true>(x, out, planes, hw, dtype, stream, "plane_sum_sq");
+    return plane_sum_launch<1>(x, out, planes, hw, dtype, stream, "plane_sum_sq");
+}
+
+extern "C" int lvg_plane_absmax(const void* x, float* out, int64_t planes, int64_t hw, int dtype, void* stream)
+{
+    return plane_sum_launch<2>(x, out, planes, hw, dtype, stream, "plane_absmax");
 }

@@ -297,6 +297,73 @@ int check_common(const char* what, int64_t n, int64_t hw, int dtype)
     return LVG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// float32 layers of the super-resolution generator (the three lowest resolutions): the operand of their split-precision
+// contraction in ONE pass. dst[n, y + offY, x + offX, blk * cPad + c] = part_blk(src[n, c, y, x] * mul[n, c] * scale) for the
+// stacked blocks blk = 0 .. nBlk - 1, part 0 = the float16 rounding of the scaled value, part 1 = the float16 rounding of what
+// that left (torch_utils/ops/conv2d_frames.py::split16; `pattern` bit blk selects the part). Replaces cat / float / mul / permute /
+// half / sub / half / zeros / three strided copies (~15 passes over a 38 MB tensor per call). The frame's border and its padding
+// channels are NOT written (the caller zero-fills the frame once).
+struct SplitArgs
+{
+    const float* src; const float* mul; const float* scale;
+    uint16_t* dst;
+    int n, c, hw, srcW, dstW, dstHW, offY, offX, cPad, cTot, nBlk, pattern;
+    float invW;
+};
+
+__global__ __launch_bounds__(256) void split16_frames_kernel(SplitArgs a)
+{
+    __shared__ float tile[kTile][kTile + 1];                               // [c][p], already multiplied by mul and scale
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * kTile, c0 = blockIdx.y * kTile;
+    const int64_t n = blockIdx.z;
+    const float sc = a.scale ? a.scale[0] : 1.0f;
+    #pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        const int idx = tid + 256 * i, c = idx >> 6, pl = idx & 63;
+        float v = 0.0f;
+        if (c0 + c < a.c && p0 + pl < a.hw)
+        {
+            v = a.src[(n * a.c + c0 + c) * (int64_t)a.hw + p0 + pl];
+            if (a.mul) v *= a.mul[n * a.c + c0 + c];
+            v *= sc;                                                        // (a power of two: exact)
+        }
+        tile[c][pl] = v;
+    }
+    __syncthreads();
+    const int pl = tid & 63, cg0 = tid >> 6, p = p0 + pl;
+    if (p >= a.hw) return;
+    int y, x;
+    split_pixel(p, a.srcW, a.invW, y, x);
+    uint16_t* row = a.dst + (n * a.dstHW + (int64_t)(y + a.offY) * a.dstW + (x + a.offX)) * a.cTot;
+    #pragma unroll
+    for (int it = 0; it < 2; it++)
+    {
+        const int cl = 8 * (cg0 + 4 * it), cc = c0 + cl;
+        if (cc >= a.c) continue;
+        uint16_t hi[8], lo[8];
+        #pragma unroll
+        for (int e = 0; e < 8; e++)
+        {
+            const float t = tile[cl + e][pl];
+            const _Float16 h = (_Float16)t;
+            const _Float16 l = (_Float16)(t - (float)h);
+            __builtin_memcpy(&hi[e], &h, 2); __builtin_memcpy(&lo[e], &l, 2);
+        }
+        const int nValid = min(8, a.c - cc);
+        for (int blk = 0; blk < a.nBlk; blk++)
+        {
+            const uint16_t* part = ((a.pattern >> blk) & 1) ? lo : hi;
+            uint16_t* d = row + (int64_t)blk * a.cPad + cc;
+            if (nValid == 8) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(part);
+            else for (int e = 0; e < nValid; e++) d[e] = part[e];
+        }
+    }
+}
+
 } // namespace
 
 static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
@@ -376,4 +443,22 @@ extern "C" int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, c
     if (dtype == LVG_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else                  hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return lvg_check_launch("modconv2d_nhwc_to_nchw");
+}
+
+extern "C" int lvg_split16_frames(const float* src, const float* mul, const float* scale, void* dst, int64_t n, int c, int src_h, int src_w,
+                                  int dst_h, int dst_w, int off_y, int off_x, int c_pad, int n_blocks, int pattern, void* stream)
+{
+    LVG_REQUIRE(src && dst && n >= 1 && c >= 1 && src_h >= 1 && src_w >= 1, "split16_frames: bad sizes");
+    LVG_REQUIRE(off_y >= 0 && off_x >= 0 && dst_h >= src_h + off_y && dst_w >= src_w + off_x, "split16_frames: the source plane must fit inside the destination frame");
+    LVG_REQUIRE(c_pad >= c && c_pad % 8 == 0 && n_blocks >= 1 && n_blocks <= 8, "split16_frames: c_pad must be a multiple of 8 that holds the channels; 1..8 blocks");
+    LVG_REQUIRE((int64_t)dst_h * dst_w <= 0x3fffffffLL && (int64_t)src_h * src_w <= 0x3fffffffLL && n <= 65535, "split16_frames: frame too large");
+    LVG_REQUIRE((((uintptr_t)dst) & 15) == 0, "split16_frames: dst must be 16-byte aligned");
+    SplitArgs a;
+    a.src = src; a.mul = mul; a.scale = scale; a.dst = (uint16_t*)dst;
+    a.n = (int)n; a.c = c; a.hw = src_h * src_w; a.srcW = src_w; a.dstW = dst_w; a.dstHW = dst_h * dst_w; a.offY = off_y; a.offX = off_x;
+    a.cPad = c_pad; a.cTot = c_pad * n_blocks; a.nBlk = n_blocks; a.pattern = pattern;
+    a.invW = a.hw < (1 << 22) ? 1.0f / (float)src_w : 0.0f;
+    const dim3 grid((unsigned)((a.hw + kTile - 1) / kTile), (unsigned)((c + kTile - 1) / kTile), (unsigned)n);
+    hipLaunchKernelGGL(split16_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return lvg_check_launch("split16_frames");
 }

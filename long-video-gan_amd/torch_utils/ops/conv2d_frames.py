@@ -118,6 +118,27 @@ def pow2_scale(t, target=1024.0):
     return torch.exp2(torch.floor(torch.log2(target / amax)))
 
 
+def split16_into_frame(src, mul, frame, off_y, off_x, c_pad, pattern=(0, 1, 0), target=1024.0):
+    """The float16x2 operand of a float32 tensor in one pass (csrc/modconv2d_layout.hip::split16_frames_kernel): src float32 NCHW [n, c, h, w]
+    (contiguous, GPU), mul [n, c] float32 or None; frame [n, H, W, len(pattern) * c_pad] float16, zero-filled by the caller. Writes
+    part pattern[blk] of (src * mul * s) into channel block blk of the frame's interior at (off_y, off_x) and returns the power-of-two scale s
+    (0-d float32 tensor) -- bit for bit what  pow2_scale(src * mul), split16(src * mul * s)  and the strided copies produce."""
+    n, c, h, w = src.shape
+    assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and frame.dtype == torch.float16 and frame.is_contiguous()
+    assert frame.shape[0] == n and frame.shape[3] == len(pattern) * c_pad and all(p_ in (0, 1) for p_ in pattern)
+    planes = torch.empty([n, c], dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _hip.check(_hip.lib().lvg_plane_absmax(src.data_ptr(), planes.data_ptr(), n * c, h * w, _hip.dtype_code(src.dtype), _hip.stream(src.device)), 'plane_absmax')
+        # max |src * mul| = max over (n, c) of |mul| * max over the plane of |src| (the float32 rounding of a product is monotonic)
+        amax = (planes if mul is None else planes * mul.abs()).amax().clamp_min(1e-30)
+        s = torch.exp2(torch.floor(torch.log2(target / amax)))
+        bits = sum(int(p_) << i for i, p_ in enumerate(pattern))
+        rc = _hip.lib().lvg_split16_frames(src.data_ptr(), _hip.ptr(mul), s.data_ptr(), frame.data_ptr(), n, c, h, w, frame.shape[1], frame.shape[2],
+                                           off_y, off_x, c_pad, len(pattern), bits, _hip.stream(src.device))
+    _hip.check(rc, 'split16_frames')
+    return s
+
+
 def wgrad_splits(n, hx, wx, hd, wd, ci, co):
     return int(_hip.lib().lvg_conv2d_frames_wgrad_splits(n, hx, wx, hd, wd, ci, co, 3, 3))
 

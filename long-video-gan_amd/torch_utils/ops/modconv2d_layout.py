@@ -273,14 +273,21 @@ class _ModConv2dSplit(torch.autograd.Function):
         co, ci = weight.shape[:2]
         geo = c2.Geometry(h, w, padding)
         cip, cop = c2.round_up(ci, c2.CH), c2.round_up(co, c2.CH)
-        xin = (first if second is None else torch.cat((first, second), dim=1)).float() * mod.float()[:, :, None, None]
-        xs, sx = _split_parts(xin.permute(0, 2, 3, 1), SPLIT_MODE)
         ws, sw = _split_parts(weight, SPLIT_MODE)
         k = len(xpat)
         xp = torch.zeros([n, geo.hx, geo.wx, k * cip], dtype=dt, device=first.device)      # the stacked parts per pixel
-        inner = xp[:, 2:2 + h, 2:2 + w]
-        for j, pi in enumerate(xpat):
-            inner[..., j * cip:j * cip + ci] = xs[pi]
+        fast = FUSED_SPLIT and SPLIT_MODE == 'f16x2' and second is None and first.is_cuda and first.dtype == torch.float32
+        if fast:
+            # scale, split and placement of (first * mod) in ONE pass over the float32 planes (lvg_split16_frames); the tensor expressions
+            # below made ~15 passes over the 38 MB tensor of these layers
+            sx = c2.split16_into_frame(first.contiguous(), mod.float().contiguous(), xp, 2, 2, cip, xpat)
+            xs = None
+        else:
+            xin = (first if second is None else torch.cat((first, second), dim=1)).float() * mod.float()[:, :, None, None]
+            xs, sx = _split_parts(xin.permute(0, 2, 3, 1), SPLIT_MODE)
+            inner = xp[:, 2:2 + h, 2:2 + w]
+            for j, pi in enumerate(xpat):
+                inner[..., j * cip:j * cip + ci] = xs[pi]
         wp = torch.cat([c2.pack_weight(ws[pi], dt, cip, cop) for pi in wpat], dim=3)        # [3, 3, cop, k cip]
         alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work (the partial products are this implementation's cost, not the operation's)
         y = c2.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), out_dtype=torch.float32, alg_flops=alg)     # [n, ho, wo, cop] float32, scaled by sx sw
@@ -314,13 +321,18 @@ class _ModConv2dSplit(torch.autograd.Function):
         d_demod = None
         if demod is not None and ctx.needs_input_grad[4]:
             d_demod = (d_out * y[..., :co].permute(0, 3, 1, 2)).sum(dim=(2, 3))
-        g = d_out if demod is None else d_out * demod.float()[:, :, None, None]
-        gs, s = _split_parts(g.permute(0, 2, 3, 1), mode)
         k = len(xpat)
         dyp = torch.zeros([n, geo.hd, geo.wd, k * cop], dtype=dt, device=first.device)       # stacked parts of the gradient per pixel at (q, q)
-        inner = dyp[:, geo.q:geo.q + geo.ho, geo.q:geo.q + geo.wo]
-        for j, pi in enumerate(xpat):
-            inner[..., j * cop:j * cop + co] = gs[pi]
+        fast = FUSED_SPLIT and mode == 'f16x2' and d_out.is_cuda
+        if fast:
+            s = c2.split16_into_frame(d_out.contiguous(), None if demod is None else demod.float().contiguous(), dyp, geo.q, geo.q, cop, xpat)
+            gs = None
+        else:
+            g = d_out if demod is None else d_out * demod.float()[:, :, None, None]
+            gs, s = _split_parts(g.permute(0, 2, 3, 1), mode)
+            inner = dyp[:, geo.q:geo.q + geo.ho, geo.q:geo.q + geo.wo]
+            for j, pi in enumerate(xpat):
+                inner[..., j * cop:j * cop + co] = gs[pi]
         d_weight = None
         if ctx.needs_input_grad[2]:
             # each part of x against each part of the gradient: the blocks (i, j) of the [nparts cop, nparts cip] result with i + j < nparts
@@ -354,6 +366,7 @@ class _ModConv2dSplit(torch.autograd.Function):
         return d_first, None, d_weight, d_mod, d_demod, None
 
 
+FUSED_SPLIT = os.environ.get('LVG_SRES_FUSED_SPLIT', '1') != '0'     # operands of the float32 layers split in one pass (lvg_split16_frames; 0: tensor expressions)
 SPLIT_F32 = os.environ.get('LVG_SRES_SPLIT_F32', '1') != '0'      # float32 3 x 3 layers on the hand-written kernels through split operands (0: the library convolution)
 
 

@@ -325,3 +325,26 @@ def test_split_node_vs_library_float32_layer_gpu(monkeypatch):
         errs[k_ + '_hand'], errs[k_ + '_lib'] = rel(h_, t_), rel(l_, t_)
         assert errs[k_ + '_hand'] < 2e-5 and errs[k_ + '_hand'] <= 4 * errs[k_ + '_lib'] + 2e-6, (k_, errs)
     record_measured('sres_L1_split_f32_vs_f64_rel_max', **errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 512, 512, 31, 38), (1, 37, 21, 9, 13), (3, 70, 130, 17, 5)])
+def test_fused_operand_split_equals_tensor_expressions_gpu(shape, monkeypatch):
+    """lvg_split16_frames / lvg_plane_absmax (one pass: scale, float16 x 2 split, placement in the padded frame) against the tensor
+    expressions they replace (pow2_scale, split16, strided copies), through the whole float32 node: outputs and gradients bit for bit."""
+    n, ci, co, h, w = shape
+    torch.manual_seed(11)
+    first = torch.randn(n, ci, h, w, device='cuda') * 3
+    weight = torch.randn(co, ci, 3, 3, device='cuda') * 0.05
+    mod = 1 + 0.3 * torch.randn(n, ci, device='cuda')
+    demod = 0.02 * (0.5 + torch.rand(n, co, device='cuda'))
+    dy = torch.randn(n, co, h + 2, w + 2, device='cuda') * 1e-3
+
+    def run(flag):
+        monkeypatch.setattr(ml, 'FUSED_SPLIT', flag)
+        args = [t.detach().clone().requires_grad_(True) for t in (first, weight, mod, demod)]
+        y = ml._ModConv2dSplit.apply(args[0], None, args[1], args[2], args[3], 2)
+        return [y.detach()] + list(torch.autograd.grad(y, args, dy))
+    fused, plain = run(True), run(False)
+    for name, a, b in zip(('y', 'd_x', 'd_weight', 'd_mod', 'd_demod'), fused, plain):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))

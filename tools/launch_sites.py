@@ -80,7 +80,7 @@ else:
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
     torch.cuda.synchronize()
@@ -112,7 +112,7 @@ for ev in events:
         cur = cur.cpu_parent
     for k in ev.kernels:
         name = re.sub(r'\(anonymous namespace\)::|void |at::native::', '', k.name)[:60]
-        key = (site, ev.name[:40], name)
+        key = (site, ev.name[:40] + (' ' + str(ev.input_shapes)[:90] if getattr(ev, 'input_shapes', None) and k.duration >= args.big else ''), name)
         by_site[key] += 1
         dur_site[key] += k.duration
         if k.duration < 30:
