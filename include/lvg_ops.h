@@ -377,6 +377,9 @@ int lvg_plane_absmax(const void* x, float* out, int64_t planes, int64_t hw, int 
  */
 int lvg_split16_frames(const float* src, const float* mul, const float* scale, void* dst, int64_t n, int c, int src_h, int src_w,
                        int dst_h, int dst_w, int off_y, int off_x, int c_pad, int n_blocks, int pattern, void* stream);
+/* The float32 result of that contraction back to NCHW planes: dst[n, c, p] = src[n, p, c] * scale[n, c] * factor[0] for c < c_dst (src has
+ * c_src >= c_dst channels per pixel; scale / factor may be NULL). */
+int lvg_nhwc_f32_to_nchw(const float* src, const float* scale, const float* factor, float* dst, int64_t n, int64_t hw, int c_src, int c_dst, void* stream);
 
 /*
  * Fused stages of the ADA augmentation pipeline (csrc/ada_augment.hip; reference model/ada_augment.py).

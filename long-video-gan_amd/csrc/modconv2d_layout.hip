@@ -364,6 +364,45 @@ __global__ __launch_bounds__(256) void split16_frames_kernel(SplitArgs a)
     }
 }
 
+
+// float32 epilogue of the same layers: dst[n, c, p] = src[n, p, c] * scale[n, c] * factor[0] for c < cDst; src = the float32 NHWC result of
+// the split-precision contraction (pixel stride cSrc >= cDst). Replaces mul / permute / mul / contiguous.
+struct UnsplitArgs
+{
+    const float* src; const float* scale; const float* factor;
+    float* dst;
+    int n, hw, cSrc, cDst;
+};
+
+__global__ __launch_bounds__(256) void nhwc_f32_to_nchw_kernel(UnsplitArgs a)
+{
+    __shared__ float tile[kTile][kTile + 1];                               // [p][c]
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * kTile, c0 = blockIdx.y * kTile;
+    const int64_t n = blockIdx.z;
+    #pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        const int idx = tid + 256 * i, pl = idx >> 6, c = idx & 63;         // consecutive threads: consecutive channels of one pixel
+        float v = 0.0f;
+        if (p0 + pl < a.hw && c0 + c < a.cDst) v = a.src[(n * a.hw + p0 + pl) * (int64_t)a.cSrc + c0 + c];
+        tile[pl][c] = v;
+    }
+    __syncthreads();
+    const float f = a.factor ? a.factor[0] : 1.0f;
+    #pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        const int idx = tid + 256 * i, c = idx >> 6, pl = idx & 63;         // consecutive threads: consecutive pixels of one channel
+        if (c0 + c < a.cDst && p0 + pl < a.hw)
+        {
+            float v = tile[pl][c] * f;
+            if (a.scale) v *= a.scale[n * a.cDst + c0 + c];
+            a.dst[(n * a.cDst + c0 + c) * (int64_t)a.hw + p0 + pl] = v;
+        }
+    }
+}
+
 } // namespace
 
 static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
@@ -461,4 +500,14 @@ extern "C" int lvg_split16_frames(const float* src, const float* mul, const floa
     const dim3 grid((unsigned)((a.hw + kTile - 1) / kTile), (unsigned)((c + kTile - 1) / kTile), (unsigned)n);
     hipLaunchKernelGGL(split16_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return lvg_check_launch("split16_frames");
+}
+
+extern "C" int lvg_nhwc_f32_to_nchw(const float* src, const float* scale, const float* factor, float* dst, int64_t n, int64_t hw, int c_src, int c_dst, void* stream)
+{
+    LVG_REQUIRE(src && dst && n >= 1 && n <= 65535 && hw >= 1 && hw <= 0x3fffffffLL && c_dst >= 1 && c_src >= c_dst, "nhwc_f32_to_nchw: bad sizes");
+    UnsplitArgs a;
+    a.src = src; a.scale = scale; a.factor = factor; a.dst = dst; a.n = (int)n; a.hw = (int)hw; a.cSrc = c_src; a.cDst = c_dst;
+    const dim3 grid((unsigned)((hw + kTile - 1) / kTile), (unsigned)((c_dst + kTile - 1) / kTile), (unsigned)n);
+    hipLaunchKernelGGL(nhwc_f32_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return lvg_check_launch("nhwc_f32_to_nchw");
 }

@@ -64,6 +64,7 @@ _SIGNATURES = {
     'lvg_plane_sum_sq': [_vp, _vp, _i64, _i64, _i32, _vp],
     'lvg_plane_absmax': [_vp, _vp, _i64, _i64, _i32, _vp],
     'lvg_split16_frames': [_vp, _vp, _vp, _vp, _i64] + [_i32] * 10 + [_vp],
+    'lvg_nhwc_f32_to_nchw': [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     'lvg_weight_prep2d': [_vp] * 5 + [_i32] * 5 + [_f32, _i32, _vp],
     'lvg_weight_prep2d_backward': [_vp] * 5 + [_i32] * 5 + [_f32, _vp],
     'lvg_adam_step': [_vp] * 5 + [_i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],

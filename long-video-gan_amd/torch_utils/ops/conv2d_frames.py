@@ -139,6 +139,17 @@ def split16_into_frame(src, mul, frame, off_y, off_x, c_pad, pattern=(0, 1, 0), 
     return s
 
 
+def nhwc_f32_to_nchw(y, c_dst, scale=None, factor=None):
+    """y float32 [n, h, w, c_src] (contiguous, GPU) -> float32 NCHW [n, c_dst, h, w] = y[..., :c_dst] * scale[n, c] * factor (0-d tensor), one pass."""
+    n, h, w, c_src = y.shape
+    assert y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and c_dst <= c_src
+    out = torch.empty([n, c_dst, h, w], dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = _hip.lib().lvg_nhwc_f32_to_nchw(y.data_ptr(), _hip.ptr(scale), _hip.ptr(factor), out.data_ptr(), n, h * w, c_src, c_dst, _hip.stream(y.device))
+    _hip.check(rc, 'nhwc_f32_to_nchw')
+    return out
+
+
 def wgrad_splits(n, hx, wx, hd, wd, ci, co):
     return int(_hip.lib().lvg_conv2d_frames_wgrad_splits(n, hx, wx, hd, wd, ci, co, 3, 3))
 

@@ -291,9 +291,16 @@ class _ModConv2dSplit(torch.autograd.Function):
         wp = torch.cat([c2.pack_weight(ws[pi], dt, cip, cop) for pi in wpat], dim=3)        # [3, 3, cop, k cip]
         alg = 2 * n * geo.ho * geo.wo * co * ci * 9                  # algorithmic work (the partial products are this implementation's cost, not the operation's)
         y = c2.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), out_dtype=torch.float32, alg_flops=alg)     # [n, ho, wo, cop] float32, scaled by sx sw
-        y = y * (1.0 / (sx * sw))
-        yv = y[..., :co].permute(0, 3, 1, 2)
-        out = (yv if demod is None else yv * demod.float()[:, :, None, None]).contiguous()
+        if fast:
+            # (the saved y stays UNSCALED on this path: the backward pass folds 1 / (sx sw) into d_demod)
+            inv = (1.0 / (sx * sw)).reshape(1)
+            out = c2.nhwc_f32_to_nchw(y, co, None if demod is None else demod.float().contiguous(), inv)
+            y_scale = inv
+        else:
+            y = y * (1.0 / (sx * sw))
+            yv = y[..., :co].permute(0, 3, 1, 2)
+            out = (yv if demod is None else yv * demod.float()[:, :, None, None]).contiguous()
+            y_scale = None
         # the weight gradient needs each part of x ONCE: they are the first occurrences in the stacked frame when the pattern starts 0, .. (f16x2:
         # blocks 0, 1; bf16x3: blocks 0, 2, 5 -- kept as a separate compact frame there)
         xw = xp if SPLIT_MODE == 'f16x2' else None
@@ -304,6 +311,7 @@ class _ModConv2dSplit(torch.autograd.Function):
                 innerw[..., pi * cip:pi * cip + ci] = xs[pi]
         ctx.save_for_backward(first, second, mod, demod, xw, y, weight, sx, sw)
         ctx.geo, ctx.alg, ctx.mode, ctx.cip = geo, alg, SPLIT_MODE, cip
+        ctx.y_scale = y_scale
         return out
 
     @staticmethod
@@ -321,6 +329,8 @@ class _ModConv2dSplit(torch.autograd.Function):
         d_demod = None
         if demod is not None and ctx.needs_input_grad[4]:
             d_demod = (d_out * y[..., :co].permute(0, 3, 1, 2)).sum(dim=(2, 3))
+            if ctx.y_scale is not None:
+                d_demod = d_demod * ctx.y_scale
         k = len(xpat)
         dyp = torch.zeros([n, geo.hd, geo.wd, k * cop], dtype=dt, device=first.device)       # stacked parts of the gradient per pixel at (q, q)
         fast = FUSED_SPLIT and mode == 'f16x2' and d_out.is_cuda
@@ -357,7 +367,11 @@ class _ModConv2dSplit(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
             ws, _ = _split_parts(weight, mode)
             wd = torch.cat([c2.pack_weight_dgrad(ws[pi], dt, cip, cop) for pi in wpat], dim=3)       # [3, 3, cip, k cop]
-            dx = c2.conv2d_valid(dyp, wd, geo.h, geo.w, out_dtype=torch.float32, alg_flops=ctx.alg)[..., :ci].permute(0, 3, 1, 2) * (1.0 / (s * sw))   # d (x * mod), NCHW view
+            dxf = c2.conv2d_valid(dyp, wd, geo.h, geo.w, out_dtype=torch.float32, alg_flops=ctx.alg)
+            if fast:
+                dx = c2.nhwc_f32_to_nchw(dxf, ci, None, (1.0 / (s * sw)).reshape(1))            # d (x * mod), contiguous NCHW planes in one pass
+            else:
+                dx = dxf[..., :ci].permute(0, 3, 1, 2) * (1.0 / (s * sw))                          # the same as a view
             if ctx.needs_input_grad[3]:
                 xcat = (first if second is None else torch.cat((first, second), dim=1)).float()
                 d_mod = (dx * xcat).sum(dim=(2, 3))

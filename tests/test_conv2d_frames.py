@@ -331,7 +331,8 @@ def test_split_node_vs_library_float32_layer_gpu(monkeypatch):
 @pytest.mark.parametrize('shape', [(2, 512, 512, 31, 38), (1, 37, 21, 9, 13), (3, 70, 130, 17, 5)])
 def test_fused_operand_split_equals_tensor_expressions_gpu(shape, monkeypatch):
     """lvg_split16_frames / lvg_plane_absmax (one pass: scale, float16 x 2 split, placement in the padded frame) against the tensor
-    expressions they replace (pow2_scale, split16, strided copies), through the whole float32 node: outputs and gradients bit for bit."""
+    expressions they replace (pow2_scale, split16, strided copies), and lvg_nhwc_f32_to_nchw (scaled float32 result back to NCHW planes) against mul / permute / contiguous, through the whole float32
+    node: outputs and gradients bit for bit (d_mod: to the reduction order of a float32 sum)."""
     n, ci, co, h, w = shape
     torch.manual_seed(11)
     first = torch.randn(n, ci, h, w, device='cuda') * 3
@@ -347,4 +348,8 @@ def test_fused_operand_split_equals_tensor_expressions_gpu(shape, monkeypatch):
         return [y.detach()] + list(torch.autograd.grad(y, args, dy))
     fused, plain = run(True), run(False)
     for name, a, b in zip(('y', 'd_x', 'd_weight', 'd_mod', 'd_demod'), fused, plain):
+        if name == 'd_mod':
+            # the same products summed over a contiguous tensor instead of a permuted view: the library's reduction order differs
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name
+            continue
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
