@@ -1009,8 +1009,10 @@ next_tile:                                                            // PERSIST
                         g = g * gainv;
                         if constexpr (CLAMP)
                         {
-                            g.x = g.x > cl ? cl : (g.x < -cl ? -cl : g.x);
-                            g.y = g.y > cl ? cl : (g.y < -cl ? -cl : g.y);
+                            // one v_med3_f32 per value instead of two compares and two selects; a NaN comes out as -clamp, as in the reference's
+                            // kernel (bias_act.cu:139: `(y > -clamp & y < clamp) ? y : (y >= 0) ? clamp : -clamp`)
+                            g.x = __builtin_amdgcn_fmed3f(g.x, -cl, cl);
+                            g.y = __builtin_amdgcn_fmed3f(g.y, -cl, cl);
                         }
                         sq2 = g * g + sq2;
                         const f32x2 o = SCALE ? g * post2[h2] : g;

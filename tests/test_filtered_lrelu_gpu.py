@@ -320,3 +320,54 @@ def test_mean_square_statistic(shape, cl, dtype):
     want = x.double().square().mean()
     assert got.dtype == torch.float32 and got.shape == ()
     assert abs(float(got) - float(want)) <= 2e-6 * float(want)
+
+
+def _random_case(seed):
+    """A seeded random geometry inside what the sres layers span and a little beyond: plane sizes 6..130 x 6..180 (one to eight column
+    strips, one to five row blocks), the three (up, down) pairs of the forward and backward passes, every residue of the four paddings
+    (positive = margin, negative = crop) that leaves at least one output pixel, slope / gain / clamp drawn separately."""
+    rs = np.random.RandomState(1000 + seed)
+    up, down, nu, nd = [(2, 2, 12, 12), (4, 2, 24, 12), (2, 4, 12, 24)][seed % 3]
+    n, c = int(rs.randint(1, 3)), int(rs.randint(1, 5))
+    h, w = int(rs.randint(6, 131)), int(rs.randint(6, 181))
+    while True:
+        pad = [int(v) for v in rs.randint(-7, 15, size=4)]
+        ow = (w * up + pad[0] + pad[1] - (nu - 1) - (nd - 1) + (down - 1)) // down
+        oh = (h * up + pad[2] + pad[3] - (nu - 1) - (nd - 1) + (down - 1)) // down
+        if ow >= 1 and oh >= 1:
+            break
+    slope = [0.2, 0.1, 0.5][int(rs.randint(3))]
+    gain = [float(np.sqrt(2)), 1.0][int(rs.randint(2))]
+    clamp = [2.5, 256.0, None][int(rs.randint(3))]
+    return (f'seed{seed}_u{up}d{down}_{h}x{w}', [n, c, h, w], up, down, nu, nd, pad), slope, gain, clamp
+
+
+@pytest.mark.parametrize('impl', [0, 5, 4, 3], ids=['routed', 'strip', 'band', 'wave'])
+@pytest.mark.parametrize('seed', range(18))
+def test_random_geometry_vs_oracle(seed, impl, oracle):
+    """Seeded random plane sizes / paddings / activation constants, float16, on the default route and with each fused MFMA kernel forced
+    (what a kernel cannot take falls back, so every case runs): forward and mask against the float64 oracle, backward against the oracle
+    on the GPU's mask. The hand-picked lists above name the code paths; this sweep is for the combinations nobody picked."""
+    import scipy.signal
+    from torch_utils.ops import _hip
+    case, slope, gain, clamp = _random_case(seed)
+    name, shape, up, down, nu, nd, pad = case
+    dtype = torch.float16
+    fu = scipy.signal.firwin(numtaps=nu, cutoff=0.9 / up, width=0.6 / up, fs=2.0).astype(np.float32)
+    fd = scipy.signal.firwin(numtaps=nd, cutoff=0.9 / down, width=0.6 / down, fs=2.0).astype(np.float32)
+    rs = np.random.RandomState(seed)
+    x = dev(rs.randn(*shape), dtype, True)
+    b = dev(rs.randn(shape[1]) * 0.3, dtype, True)
+    prev = _hip.lib().lvg_filtered_lrelu_set_impl(impl)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            y = filtered_lrelu.filtered_lrelu(x, torch.tensor(fu, device=DEV), torch.tensor(fd, device=DEV), b,
+                                              up=up, down=down, padding=pad, gain=gain, slope=slope, clamp=clamp)
+            ref, so = oracle.filtered_lrelu(host(x), fu, fd, host(b), up=up, down=down, padding=pad, gain=gain, slope=slope,
+                                            clamp=clamp, write_signs=True)
+            assert tuple(y.shape) == ref.shape and y.dtype == dtype, name
+            np.testing.assert_allclose(host(y), ref, err_msg=name, **TOL[dtype])
+            _check_backward(oracle, x, b, y, fu, fd, up, down, pad, gain, slope, dtype, name, mask_ref=so)
+    finally:
+        _hip.lib().lvg_filtered_lrelu_set_impl(prev)
