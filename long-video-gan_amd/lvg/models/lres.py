@@ -362,7 +362,11 @@ class _HandWgrad(torch.autograd.Function):
         ctx.save_for_backward(x, g)
         ctx.n = n
         kt, kh, kw = taps
-        return conv3d_frames.conv3d_frames_wgrad(_cl(x), _cl(g), kt, kh, kw, n).to(x.dtype)
+        xc, gc = _cl(x), _cl(g)
+        if taps == (1, 1, 1) and x.is_cuda:
+            # no taps: the pixel index is the whole K dimension (csrc/pointwise_wgrad.hip; conv3d_wgrad is built for 3 x 3 spatial taps)
+            return conv3d_frames.pointwise_wgrad(xc, gc).to(x.dtype).reshape(g.shape[1], x.shape[1], 1, 1, 1)
+        return conv3d_frames.conv3d_frames_wgrad(xc, gc, kt, kh, kw, n).to(x.dtype)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -384,8 +388,56 @@ def _hand_second_order_takes(x: torch.Tensor, weight: torch.Tensor, padding_hw) 
     if x.dtype not in (torch.float16, torch.bfloat16) or ci % 64 or co % 64 or weight.dtype != x.dtype:
         return False
     xc = _cl(x)
+    if tuple(weight.shape[2:]) == (1, 1, 1):
+        f, _, h, w = x.shape
+        wgrad_ok = POINTWISE_WGRAD_HAND and (f * h * w) % 8 == 0 and conv3d_frames.pointwise_wgrad_splits(f * h * w, ci, co) > 0
+    else:
+        wgrad_ok = _hand_wgrad_shape_ok(xc, co, weight, padding_hw)
     return (_hand_conv_takes(xc, weight, padding_hw) and _hand_conv_shape_ok(xc, co, ci, weight, padding_hw)
-            and _hand_wgrad_shape_ok(xc, co, weight, padding_hw) and conv3d_frames.supported(xc, weight))
+            and wgrad_ok and conv3d_frames.supported(xc, weight))
+
+
+class _PairView(torch.autograd.Function):
+    """Pixels -> pixel pairs (see _pairable) as a node: a re-labelling of the same memory, so its gradient is the inverse re-labelling of the
+    incoming gradient (and that one's gradient is this node again): no copy in either direction, any order of differentiation."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return _pair_view(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _UnpairView.apply(g)
+
+
+class _UnpairView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return _unpair_view(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PairView.apply(g)
+
+
+def _second_order_conv(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw) -> Optional[torch.Tensor]:
+    """The contraction of an R1 pass on the hand-written kernels, as nodes that can be differentiated again -- or None (library route).
+    Round 6: also the layers round 5 moved to their own kernels for the first-order passes -- 3-channel side (pointwise_thin), 32-channel
+    layers as pixel pairs, 1 x 1 convolutions (weight gradient on pointwise_wgrad). Measured on the 8-clip R1 update before: 46 of 67 ms of
+    device time in the library's double-backward of exactly these layers (profiles/r06_launch_sites_r1_before.log)."""
+    if not HAND_SECOND_ORDER:
+        return None
+    taps = tuple(weight.shape[2:])
+    if taps == (1, 1, 1) and THIN_POINTWISE and pointwise_thin.supported(x, weight[:, :, 0, 0, 0]):
+        return pointwise_thin.pointwise_thin(x, weight[:, :, 0, 0, 0], twice=True)
+    if _pairable(x, weight) and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last):
+        xp, wp = _PairView.apply(x), pair_weight(weight)                 # (pair_weight: tensor expressions, differentiable as they are)
+        if _hand_second_order_takes(xp, wp, padding_hw):
+            return _UnpairView.apply(_HandConv.apply(xp, wp, n))
+        return None
+    if _hand_second_order_takes(x, weight, padding_hw):
+        return _HandConv.apply(x, weight, n)
+    return None
 
 
 def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_hw) -> torch.Tensor:
@@ -401,8 +453,10 @@ def temporal_conv_frames(x: torch.Tensor, weight: torch.Tensor, n: int, padding_
     if THIN_POINTWISE and not SECOND_ORDER and tuple(weight.shape[2:]) == (1, 1, 1) and pointwise_thin.supported(x, weight[:, :, 0, 0, 0]):
         # 3-channel side (ToRGB, the discriminator's first layer): streaming kernels for all three passes (csrc/pointwise_thin.hip)
         return pointwise_thin.pointwise_thin(x, weight[:, :, 0, 0, 0])
-    if SECOND_ORDER and _hand_second_order_takes(x, weight, padding_hw):
-        return _HandConv.apply(x, weight, n)
+    if SECOND_ORDER:
+        y = _second_order_conv(x, weight, n, padding_hw)
+        if y is not None:
+            return y
     return _TemporalConvFrames.apply(x, weight, n, tuple(padding_hw))
 
 

@@ -271,6 +271,13 @@ def pointwise_wgrad_supported(x, dy):
     return int(_hip.lib().lvg_pointwise_wgrad_splits(pixels, x.shape[1], dy.shape[1])) > 0
 
 
+def pointwise_wgrad_splits(pixels, ci, co):
+    """> 0: lvg_pointwise_wgrad takes a [pixels, ci] x [pixels, co] pair of dense 16-bit pixel matrices (decided on shapes)."""
+    if not _init() or ci % 64 or co % 64:
+        return 0
+    return int(_hip.lib().lvg_pointwise_wgrad_splits(pixels, ci, co))
+
+
 def pointwise_wgrad(x, dy):
     """Weight gradient [Co, Ci] (float32) of a 1 x 1 convolution: sum over pixels dy[m][co] x[m][ci] (csrc/pointwise_wgrad.hip)."""
     assert pointwise_wgrad_supported(x, dy), 'pointwise_wgrad: no hand-written kernel for this shape / dtype / layout'

@@ -535,3 +535,93 @@ def test_split32_stack_kernel_is_bit_identical_to_the_tensor_expressions_gpu(par
         diff = (got.view(torch.int16) != want.view(torch.int16)) & ~nan
         assert int(diff.sum()) == 0, (shape, int(diff.sum()), got[diff][:4], want[diff][:4])
         assert int(nan.sum()) > 0
+
+
+def _r1_pattern(fn, x, wt):
+    """value, input gradient, and the gradients of an R1-style penalty on that input gradient"""
+    y = fn(x, wt)
+    (g,) = torch.autograd.grad(y.float().tanh().sum(), [x], create_graph=True)
+    gw, gx = torch.autograd.grad(g.float().square().sum(), [wt, x])
+    return [t.detach().float() for t in (y, g, gw, gx)]
+
+
+@pytest.mark.parametrize('co,ci', [(16, 3), (3, 16)])
+def test_thin_pointwise_nodes_are_closed_under_differentiation_cpu(co, ci):
+    """pointwise_thin._ThinConv / _ThinWgrad (round 6: the 3-channel layers of an R1 pass on their own kernels; on CPU tensors the nodes run
+    the plain definitions): the R1 pattern against autograd of F.conv2d."""
+    import torch.nn.functional as F
+    from torch_utils.ops import pointwise_thin
+    torch.manual_seed(2)
+    x = torch.randn(5, ci, 4, 6).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn(co, ci) * 0.4).requires_grad_(True)
+    got = _r1_pattern(lambda x, wt: pointwise_thin._ThinConv.apply(x, wt), x, wt)
+    want = _r1_pattern(lambda x, wt: F.conv2d(x, wt[:, :, None, None]), x, wt)
+    for a, b, name in zip(got, want, ['y', 'dx', 'd penalty / dw', 'd penalty / dx']):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, name
+
+
+@pytest.mark.parametrize('taps', [(3, 3, 3), (1, 3, 3), (1, 1, 1)])
+def test_pixel_pair_nodes_are_closed_under_differentiation_cpu(taps):
+    """lres._PairView / _UnpairView around lres._HandConv with lres.pair_weight (the 32-channel layers of an R1 pass as pixel pairs): the R1
+    pattern against autograd of F.conv3d on the unpaired tensors."""
+    import torch.nn.functional as F
+    from lvg.models import lres
+    torch.manual_seed(3)
+    T, N, ci, co, h, w = 4, 2, 3, 5, 4, 6
+    kt, kh, kw = taps
+    x = torch.randn(T * N, ci, h, w).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn(co, ci, kt, kh, kw) * 0.3).requires_grad_(True)
+
+    def ref(x, wt):
+        v = x.reshape(T, N, ci, h, w).permute(1, 2, 0, 3, 4)
+        return F.conv3d(v, wt, padding=(kt // 2, kh // 2, kw // 2)).permute(2, 0, 1, 3, 4).reshape(T * N, co, h, w)
+
+    def paired(x, wt):
+        return lres._UnpairView.apply(lres._HandConv.apply(lres._PairView.apply(x), lres.pair_weight(wt), N))
+
+    for a, b, name in zip(_r1_pattern(paired, x, wt), _r1_pattern(ref, x, wt), ['y', 'dx', 'd penalty / dw', 'd penalty / dx']):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [('thin_3_to_32', 3, 32, (1, 1, 1), 64), ('pair_32_to_32', 32, 32, (1, 3, 3), 64), ('pair_32_to_64', 32, 64, (1, 3, 3), 64),
+                                  ('pair_skip_32_to_64', 32, 64, (1, 1, 1), 64), ('skip_64_to_128', 64, 128, (1, 1, 1), 32)], ids=lambda c: c[0])
+def test_second_order_routes_of_the_first_discriminator_block_gpu(case, monkeypatch):
+    """The layers of the low-resolution discriminator that round 5 left on the library inside an R1 pass (3-channel input layer, 32-channel
+    layers, 1 x 1 skip convolutions): the R1 pattern on the hand-written kernels against the library's kt-convolution form, float32 as the
+    yardstick (both 16-bit routes within 16-bit rounding of it) -- and no library convolution may have run on the hand route."""
+    from lvg.models import lres
+    from torch_utils.ops import conv3d_frames
+    name, ci, co, taps, size = case
+    torch.manual_seed(4)
+    T, N = 8, 2
+    x32 = torch.randn(T * N, ci, size, size, device='cuda').contiguous(memory_format=torch.channels_last)
+    fan = ci * taps[0] * taps[1] * taps[2]
+    w32 = torch.randn(co, ci, *taps, device='cuda') / fan ** 0.5
+    pad = (taps[1] // 2, taps[2] // 2)
+    dt = torch.bfloat16
+
+    def r1(dtype, hand):
+        monkeypatch.setattr(lres, 'HAND_SECOND_ORDER', hand)
+        x = x32.to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wt = w32.to(dtype).requires_grad_(True)
+        with lres.second_order():
+            return _r1_pattern(lambda x, wt: lres.temporal_conv_frames(x, wt, N, pad), x, wt)
+
+    ref = r1(torch.float32, False)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        hand = r1(dt, True)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    library = ('igemm_fwd', 'igemm_bwd', 'igemm_wrw', 'miopen', 'Cijk', 'ck::', 'xdlops', 'SubTensorOp', 'batched_transpose')
+    assert not [k for k in names if any(tag in k for tag in library)], names
+    lib = r1(dt, False)
+    measured = {}
+    for a, b, c, what in zip(hand, lib, ref, ['y', 'dx', 'd penalty / dw', 'd penalty / dx']):
+        scale = float(c.abs().max())
+        e_hand, e_lib = float((a - c).abs().max()) / scale, float((b - c).abs().max()) / scale
+        measured[what] = [e_hand, e_lib]
+        # bfloat16 rounding of y under tanh'' (|y| up to ~5 with 3 .. 288 unit-variance terms) costs up to a few per cent of the largest
+        # element on EITHER 16-bit route: the gate is 2e-2, or twice what the library's route shows on the same tensors
+        assert e_hand <= max(2e-2, 2 * e_lib), (name, what, 'hand route', e_hand, 'library route', e_lib)
+    record_measured(f'lres_second_order_{name}', **{k.replace(' ', '_').replace('/', 'by'): v for k, v in measured.items()})

@@ -25,7 +25,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--frames', type=int, default=128)
 ap.add_argument('--top', type=int, default=80)
-ap.add_argument('--net', default='lres', choices=['lres', 'sres', 'train_sres', 'train_lres'])
+ap.add_argument('--net', default='lres', choices=['lres', 'sres', 'train_sres', 'train_lres', 'r1_lres'])
+ap.add_argument('--first-iter', type=int, default=1, help='iteration number of the first profiled-run warm-up (train_lres: R1 runs when it divides by the R1 interval)')
 ap.add_argument('--big', type=float, default=15.0, help='also list aten kernels of at least this many us (passes over activations written as tensor expressions)')
 args = ap.parse_args()
 
@@ -53,11 +54,19 @@ elif args.net == 'train_sres':
     def step():
         tr.train_step(state['n'], lr_clip, hr_clip)
         state['n'] += 1
+elif args.net == 'r1_lres':
+    # the R1 update alone (second-order pass through the discriminator, reference video_gan_lres.py:180-204)
+    from lvg.train_lres import LowResTrainer
+    tr = LowResTrainer(seq_length=args.frames, device=dev, compute_dtype=torch.bfloat16, G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=False, with_ema=True)
+    real = torch.rand(max(2, args.batch), 3, args.frames, 36, 64, device=dev) * 2 - 1
+
+    def step():
+        tr.update_r1(real, gain=16)
 elif args.net == 'train_lres':
     from lvg.train_lres import LowResTrainer
     tr = LowResTrainer(seq_length=args.frames, device=dev, compute_dtype=torch.bfloat16, G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=False, with_ema=True)
     real = torch.rand(2, 3, args.frames, 36, 64, device=dev) * 2 - 1
-    state = dict(n=1)
+    state = dict(n=args.first_iter)
 
     def step():
         tr.train_step(state['n'], real)
