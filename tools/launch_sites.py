@@ -65,7 +65,7 @@ elif args.net == 'r1_lres':
 elif args.net == 'train_lres':
     from lvg.train_lres import LowResTrainer
     tr = LowResTrainer(seq_length=args.frames, device=dev, compute_dtype=torch.bfloat16, G_grad_accum=1, D_grad_accum=1, overlap_grad_sync=False, with_ema=True)
-    real = torch.rand(2, 3, args.frames, 36, 64, device=dev) * 2 - 1
+    real = torch.rand(max(2, args.batch), 3, args.frames, 36, 64, device=dev) * 2 - 1
     state = dict(n=args.first_iter)
 
     def step():
