@@ -591,12 +591,12 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
         'value': round(total_batch * frames_per_clip * steps / elapsed, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'ms_per_step': round(elapsed / steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': dtype_name, 'data': 'synthetic',
-        'launch_mode': 'hipgraph per phase (update_G, fake generation, update_D micro-batch); optimizer, exchange, R1 eager' if graphs else 'eager',
+        'launch_mode': 'hipgraph per phase (update_G, fake generation, update_D micro-batch, R1 micro-batch); optimizer and exchange eager' if graphs else 'eager',
         'config': {'workload': f'train_lres.py step body, total batch {total_batch} ({B}/GPU, {accum} micro-batches), G at {frames_per_clip + 32} frames cropped to {frames_per_clip}, '
                                f'DiffAugment + temporal-scale augment, R1 steps in the timed region: {r1_steps}', 'global_batch': total_batch,
                    'frames_per_clip': frames_per_clip, 'parallelism': f'dp{world}',
                    'grad_sync': 'FlatGradSync, one rank: no exchange' if world == 1 else
-                                ('FlatGradSync, 128 MB buckets, exchange after the replayed phases (R1: overlapped with its backward pass)' if graphs else 'FlatGradSync(overlap=True), 128 MB buckets')},
+                                ('FlatGradSync, 128 MB buckets, exchange after the replayed phases' if graphs else 'FlatGradSync(overlap=True), 128 MB buckets')},
         'grad_sync': {'exposed_ms_per_step': round(exposed_ms, 3), 'note': 'device time of the all-reduces / waits of FlatGradSync.finish() per iteration (update_G + update_D [+ R1]); 0 at one rank'}}
 
 
@@ -638,7 +638,7 @@ def _train_sres_leg(dev, steps=16, warmup=1, total_batch=16):
     del tr
     return {**extra, 'metric': 'frames/sec train_sres iteration (update_G + update_D + R1/16 + ADA/4 + EMA), 8-frame 144x256 segments', 'value': round(total_batch * 8 / dt, 2),
             'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'warmup': warmup, 'dtype': 'f16',
-            'launch_mode': 'hipgraph per phase (update_G micro-batch, fake generation, update_D micro-batch); optimizer, R1, ADA update eager' if graphs else 'eager', 'n_gpus': 1,
+            'launch_mode': 'hipgraph per phase (update_G micro-batch, fake generation, update_D micro-batch, R1 micro-batch); optimizer, ADA update eager' if graphs else 'eager', 'n_gpus': 1,
             'config': {'workload': f'train_sres.py step body, total batch {total_batch} ({accum} micro-batches of 2 segments), ADA p = 0.2 + conditioning augmentation, '
                                    f'R1 steps in the timed region: {r1_steps}, ADA updates: {ada_steps}', 'global_batch': total_batch}}
 

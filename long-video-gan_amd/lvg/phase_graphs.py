@@ -28,6 +28,7 @@ class PhaseGraphs:
         self.graphs = {} if graphs is None else graphs
         self.syncs = list(syncs)
         self.capture = capture
+        self.eager_keys = set()
 
     def _run(self, fn: Callable[[], None]):
         """The phase with its cross-rank statistics deferred -> (records, their stacked tensors or None)."""
@@ -36,10 +37,11 @@ class PhaseGraphs:
             stacked = ddp.stack_pending(pending) if pending else None
         return pending, stacked
 
-    def replay(self, key: Hashable, fn: Callable[[], None]) -> None:
+    def replay(self, key: Hashable, fn: Callable[[], None], optional: bool = False) -> None:
         """Run `fn` from its graph; first call for `key`: one eager run on a side stream (lazy initialisation, library plans), rolled back,
-        then the capture. `fn` must read its inputs from static tensors and leave its outputs in static tensors."""
-        if not self.capture:
+        then the capture. `fn` must read its inputs from static tensors and leave its outputs in static tensors. `optional`: a refused
+        capture makes THIS phase eager from then on and leaves the other phases' graphs alone (the R1 phase: a double backward pass)."""
+        if not self.capture or key in self.eager_keys:
             ddp.finish_stat_sync(*self._run(fn))
             return
         entry = self.graphs.get(key)
@@ -70,8 +72,11 @@ class PhaseGraphs:
                 torch.cuda.synchronize()
                 for s, f in zip(self.syncs, fired_before):
                     s._fired = list(f)
-                self.capture = False
-                self.graphs.clear()
+                if optional:
+                    self.eager_keys.add(key)
+                else:
+                    self.capture = False
+                    self.graphs.clear()
                 ddp.finish_stat_sync(*self._run(fn))
                 return
             # which gradients this phase produces (their hooks ran during the capture and will not run again)

@@ -6,6 +6,7 @@ dataset / W&B / checkpoint plumbing is out of scope."
 
 import copy
 import math
+import os
 from typing import Optional
 
 import torch
@@ -17,6 +18,8 @@ from .phase_graphs import PhaseGraphs
 from .augment import crop_time, diff_augment, temporal_scale_apply, temporal_scale_augment, temporal_scale_params, to_device_async
 from .models import lres as lres_models
 from .models.lres import VideoDiscriminator, VideoGenerator
+
+R1_GRAPH = os.environ.get('LVG_R1_GRAPH', '1') != '0'       # graph mode: the R1 pass replayed from a hipGraph too (0: eager, as before round 6)
 
 
 class LowResTrainer:
@@ -194,10 +197,29 @@ class LowResTrainer:
         self.D_sync.finish(gain=1 / self.D_grad_accum)
         self.D_opt.step()
 
+    def _r1_pass(self, chunk: torch.Tensor, stretch=None) -> None:
+        """Gradient penalty of one micro-batch of reals, accumulated into the discriminator's gradients (reference video_gan_lres.py:180-197)."""
+        chunk = chunk.detach().requires_grad_(True)
+        with lres_models.second_order():                      # the gradient below is differentiated again
+            logits = self.run_D(chunk, stretch=stretch)
+        (grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[chunk], create_graph=True)
+        (grad.square().sum(dim=(1, 2, 3, 4)) * (self.r1_gamma / 2)).mean().backward()
+
     def update_r1(self, video: torch.Tensor, gain: float = 1.0) -> None:
         self.D.requires_grad_(True)
         self.D_sync.zero()
         chunks = video.chunk(self.D_grad_accum)
+        if self.use_graphs and R1_GRAPH:
+            # round 6: the pass is ~900 launches for 19 ms of device time per 8 clips -- launch-bound when eager (32 ms). Replayed from a graph
+            # like the other phases; the exchange follows the replays (no overlap with the backward pass, as in update_D's graph mode).
+            b = chunks[0].size(0)
+            st = self._graphs.setdefault(('R1io', b), dict(real_in=torch.empty(b, *video.shape[1:], dtype=video.dtype, device=self.device)))
+            draws = self._static_draws('R1', b)
+            for chunk in chunks:
+                st['real_in'].copy_(chunk)
+                self._fill_stretch(draws['stretch'][0], b)
+                self._phase_graphs.replay(('R1', b), lambda: self._r1_pass(st['real_in'], stretch=draws['stretch'][0]), optional=True)
+            chunks = ()
         for k, chunk in enumerate(chunks):
             chunk = chunk.detach().requires_grad_(True)
             with lres_models.second_order():                  # the gradient below is differentiated again

@@ -8,6 +8,7 @@ The reference's dataset / W&B / checkpoint plumbing is out of scope (SURVEY.md 2
 
 import copy
 import math
+import os
 from typing import Optional
 
 import torch
@@ -20,6 +21,9 @@ from .optim import FlatAdam
 from .phase_graphs import PhaseGraphs
 from .ada_augment import AugmentPipe
 from .models import sres
+
+R1_CLOSED_NODES = os.environ.get('LVG_SRES_R1_CLOSED_NODES', '1') != '0'
+R1_GRAPH = os.environ.get('LVG_R1_GRAPH', '1') != '0'       # graph mode: the R1 pass replayed from a hipGraph too (0: eager, as before round 6)
 
 
 class SuperResTrainer:
@@ -213,9 +217,25 @@ class SuperResTrainer:
         self.D.requires_grad_(True)
         self.D_sync.zero()
         pairs = list(zip(lr_video.chunk(self.D_grad_accum), hr_video.chunk(self.D_grad_accum)))
+        if self.use_graphs and R1_GRAPH:
+            # round 6: ~1000 launches for ~10 ms of device time per micro-batch: replayed from a graph like the other phases
+            for lr, hr in pairs:
+                ins = [self._static_like('R1.lr', lr), self._static_like('R1.hr', hr)]
+
+                def penalty_pass():
+                    h = ins[1].detach().requires_grad_(True)
+                    with conv2d_gradfix.closed_nodes(R1_CLOSED_NODES):
+                        logits = self.run_D(ins[0], h)
+                    (grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[h], create_graph=True)
+                    (grad.square().sum(dim=(1, 2, 3, 4)) * (self.r1_gamma / 2)).mean().backward()
+                self._phase_graphs.replay(('R1', tuple(lr.shape)), penalty_pass, optional=True)
+            pairs = []
         for k, (lr, hr) in enumerate(pairs):
             hr = hr.detach().requires_grad_(True)
-            logits = self.run_D(lr, hr)
+            # the discriminator's dense convolutions as nodes closed under differentiation: the second-order pass then consists of ordinary
+            # forward / backward-data / backward-weight calls (conv2d_gradfix.closed_nodes; LVG_SRES_R1_CLOSED_NODES=0: the library's own graph)
+            with conv2d_gradfix.closed_nodes(R1_CLOSED_NODES):
+                logits = self.run_D(lr, hr)
             (grad,) = torch.autograd.grad(outputs=[logits.sum()], inputs=[hr], create_graph=True)
             penalty = grad.square().sum(dim=(1, 2, 3, 4))
             if k == len(pairs) - 1 and self.D_sync.overlap:

@@ -89,3 +89,33 @@ def test_argument_errors_are_assertions():
         filtered_lrelu.filtered_lrelu(x, gain=-1)
     with pytest.raises(KeyError):
         bias_act.bias_act(x, act='nope')
+
+
+@pytest.mark.parametrize('stride,padding', [(1, 1), (2, 1), (1, 0)])
+def test_conv2d_gradfix_closed_nodes_match_the_library_graph_to_second_order(stride, padding):
+    """conv2d_gradfix.closed_nodes(): value, input gradient and the gradients of an R1-style penalty on that gradient (with respect to the
+    weight AND the input) against torch.nn.functional.conv2d's own graph; outside the scope, with a bias or with groups the call is
+    F.conv2d itself."""
+    import torch.nn.functional as F
+    from torch_utils.ops import conv2d_gradfix
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 9, 8, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(4, 3, 3, 3, dtype=torch.float64) * 0.3).requires_grad_(True)
+
+    def r1(fn):
+        y = fn(x, w)
+        (g,) = torch.autograd.grad(y.tanh().sum(), [x], create_graph=True)
+        gw, gx = torch.autograd.grad(g.square().sum(), [w, x])
+        return y.detach(), g.detach(), gw, gx
+
+    with conv2d_gradfix.closed_nodes():
+        assert conv2d_gradfix.enabled
+        y = conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding)
+        assert type(y.grad_fn).__name__ == '_ConvBackward'
+        got = r1(lambda x, w: conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding))
+        assert type(conv2d_gradfix.conv2d(x, w, bias=torch.zeros(4, dtype=torch.float64)).grad_fn).__name__ != '_ConvBackward'
+    assert not conv2d_gradfix.enabled
+    assert type(conv2d_gradfix.conv2d(x, w).grad_fn).__name__ != '_ConvBackward'
+    want = r1(lambda x, w: F.conv2d(x, w, stride=stride, padding=padding))
+    for a, b, name in zip(got, want, ['y', 'dx', 'd penalty / dw', 'd penalty / dx']):
+        assert float((a - b).abs().max()) <= 1e-10 * float(b.abs().max()) + 1e-12, name

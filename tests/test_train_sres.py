@@ -268,3 +268,44 @@ def test_graph_mode_with_ada_pipelines_gpu():
         assert p0 == pytest.approx(0.3) and p1 != p0, (name, p0, p1)
     for n, b in out['eager'][1].items():                                                        # the pipelines' constants are untouched by the capture
         assert torch.equal(b, out['graph'][1][n]), n
+
+
+@pytest.mark.gpu
+def test_r1_phase_from_a_graph_equals_eager_gpu():
+    """Round 6: in graph mode update_r1 is replayed from a hipGraph as well, with the discriminator's dense convolutions as nodes closed under
+    differentiation (conv2d_gradfix.closed_nodes). float32, every random draw off: the gradients left in the exchange buffer, eager vs
+    graph (first call = warm-up + capture + replay, second call = replay with other inputs), and eager with the library's own
+    second-order graph (closed nodes off) as the third party. Weights tight, biases loose (cancelling sums, see the test above)."""
+    from lvg import train_sres
+    kw = dict(SMALL, augment_p_init=0.0, augment_real_sign_target=None, in_augment_strength=0.0, lr_cond_prob=1.0, D_grad_accum=2)
+    g = torch.Generator(device='cuda').manual_seed(11)
+    data = [(torch.rand(4, 3, 2, 9, 16, device='cuda', generator=g) * 2 - 1, torch.rand(4, 3, 2, 36, 64, device='cuda', generator=g) * 2 - 1) for _ in range(2)]
+    flats, trainers = {}, {}
+    for name, use_graphs, closed in (('eager', False, True), ('graph', True, True), ('library', False, False)):
+        torch.manual_seed(0)
+        tr = SuperResTrainer(device='cuda', compute_dtype=torch.float32, use_graphs=use_graphs, **kw)
+        train_sres.R1_CLOSED_NODES = closed
+        try:
+            flats[name] = []
+            for lr, hr in data:
+                tr.D_opt.lr = 0.0
+                tr.update_r1(lr, hr, gain=16.0)
+                flats[name].append(tr.D_sync.flat.clone())
+        finally:
+            train_sres.R1_CLOSED_NODES = True
+        trainers[name] = tr
+        if use_graphs:
+            assert any(k[0] == 'R1' for k in tr._phase_graphs.graphs) and not tr._phase_graphs.eager_keys
+    sync = trainers['eager'].D_sync
+    is_bias = torch.zeros_like(sync.flat, dtype=torch.bool)
+    for (n, _), v in zip(trainers['eager'].D.named_parameters(), sync.views):
+        if n.endswith('bias'):
+            o = (v.data_ptr() - sync.flat.data_ptr()) // 4
+            is_bias[o:o + v.numel()] = True
+    for other in ('graph', 'library'):
+        for e, o in zip(flats['eager'], flats[other]):
+            m = float(e.abs().max())
+            assert torch.isfinite(o).all() and m > 0
+            d = (e - o).abs()
+            assert float(d[~is_bias].max()) <= 1e-3 * m, (other, 'weights', float(d[~is_bias].max()), m)
+            assert float(d[is_bias].max()) <= 6e-2 * m, (other, 'biases', float(d[is_bias].max()), m)

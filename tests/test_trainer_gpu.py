@@ -222,3 +222,29 @@ def test_flat_sync_assign_mode_inside_a_captured_step():
         assert torch.equal(sync.flat, sync_ref.flat)
         for p, v in zip(net.parameters(), sync.views):
             assert p.grad is v
+
+
+def test_r1_phase_from_a_graph_equals_eager():
+    """Round 6: in graph mode update_r1 (double backward through the discriminator, reference video_gan_lres.py:180-204) is replayed from a
+    hipGraph like the other phases. float32, no DiffAugment (device-side draws are numbered differently under capture), temporal stretch
+    on (host draws through the static buffers): the gradients the update leaves in the exchange buffer, eager vs graph -- first call (eager
+    warm-up, rolled back, capture, replay) and a second call with other reals (replay only)."""
+    from lvg.train_lres import LowResTrainer
+    kw = dict(seq_length=8, height=36, width=64, device='cuda', D_grad_accum=2, overlap_grad_sync=False, with_ema=False,
+              temp_scale_augment=1.0, diffaug_policy='', compute_dtype=torch.float32)
+    reals = [torch.rand(4, 3, 8, 36, 64, device='cuda', generator=torch.Generator(device='cuda').manual_seed(s)) * 2 - 1 for s in (1, 2)]
+    flats = {}
+    for name, use_graphs in (('eager', False), ('graph', True)):
+        torch.manual_seed(0)
+        tr = LowResTrainer(use_graphs=use_graphs, **kw)
+        torch.manual_seed(5)
+        flats[name] = []
+        for real in reals:
+            tr.D_opt.lr = 0.0                                          # (the same parameters for the second call in both modes)
+            tr.update_r1(real, gain=16.0)
+            flats[name].append(tr.D_sync.flat.clone())
+        if use_graphs:
+            assert ('R1', 2) in tr._phase_graphs.graphs and not tr._phase_graphs.eager_keys
+    for e, g in zip(flats['eager'], flats['graph']):
+        assert torch.isfinite(g).all() and float(e.abs().max()) > 0
+        assert float((e - g).abs().max()) <= 2e-3 * float(e.abs().max()), (float((e - g).abs().max()), float(e.abs().max()))

@@ -25,7 +25,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--frames', type=int, default=128)
 ap.add_argument('--top', type=int, default=80)
-ap.add_argument('--net', default='lres', choices=['lres', 'sres', 'train_sres', 'train_lres', 'r1_lres'])
+ap.add_argument('--net', default='lres', choices=['lres', 'sres', 'train_sres', 'train_lres', 'r1_lres', 'r1_sres', 'd_sres'])
 ap.add_argument('--first-iter', type=int, default=1, help='iteration number of the first profiled-run warm-up (train_lres: R1 runs when it divides by the R1 interval)')
 ap.add_argument('--big', type=float, default=15.0, help='also list aten kernels of at least this many us (passes over activations written as tensor expressions)')
 args = ap.parse_args()
@@ -54,6 +54,19 @@ elif args.net == 'train_sres':
     def step():
         tr.train_step(state['n'], lr_clip, hr_clip)
         state['n'] += 1
+elif args.net in ('r1_sres', 'd_sres'):
+    # the R1 update / the discriminator update of SuperResTrainer alone (eager), `--batch` segments
+    from lvg.train_sres import SuperResTrainer
+    tr = SuperResTrainer(device='cuda', compute_dtype=torch.float16, G_grad_accum=1, D_grad_accum=1, augment_p_init=0.2, overlap_grad_sync=False, with_ema=False, use_graphs=False)
+    nb = max(2, args.batch)
+    lr_clip = torch.rand(nb, 3, tr.context_seq_length, 36, 64, device='cuda') * 2 - 1
+    hr_clip = torch.rand(nb, 3, tr.seq_length, 144, 256, device='cuda') * 2 - 1
+
+    def step():
+        if args.net == 'r1_sres':
+            tr.update_r1(tr.crop_to_seq_length(lr_clip), hr_clip, gain=16)
+        else:
+            tr.update_D(lr_clip, lr_clip, hr_clip)
 elif args.net == 'r1_lres':
     # the R1 update alone (second-order pass through the discriminator, reference video_gan_lres.py:180-204)
     from lvg.train_lres import LowResTrainer
