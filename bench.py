@@ -603,10 +603,17 @@ def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dty
 def _train_sres_leg(dev, steps=16, warmup=1, total_batch=16):
     """BASELINE.json configs[4] at N = 1: the step body of train_sres.py:241-264 (SuperResTrainer.train_step: update_G, update_D, R1 on every
     16th step, ADA probability update on every 4th, generator EMA) on synthetic (low-resolution clip with context, high-resolution clip)
-    pairs, total batch 16 in micro-batches of 2 segments, ADA pipeline and conditioning augmentation on. Graph replay per phase (LVG_TRAIN_GRAPHS=0: eager)."""
+    pairs, total batch 16, ADA pipeline and conditioning augmentation on. Graph replay per phase (LVG_TRAIN_GRAPHS=0: eager).
+    Micro-batches of at most 8 segments (round 6; 2 before = the per-GPU share of the 8-GPU recipe run eight times in a row): like the lres leg's
+    rule, accumulation exists in the recipe to fit small memories, the gradient mean is the same, and a rank whose share is 16 segments pays the
+    per-launch cost of ~20 000 launches per iteration once per 8 segments instead of once per 2 (452 / 397 / 374 / 366 ms per iteration at 2 / 4 / 8 / 16
+    segments per micro-batch, profiles/r06_train_sres_microbatch.log; 32 GiB at 8). The discriminator's minibatch-std groups are
+    min(4, micro-batch) segments as in the reference (discriminator_sres.py: group size 4), i.e. its default grouping from 4 segments up.
+    LVG_BENCH_SRES_MICRO overrides."""
     from lvg.train_sres import SuperResTrainer
     torch.manual_seed(0)
-    accum = max(1, total_batch // 2)
+    micro = max(1, min(total_batch, int(os.environ.get('LVG_BENCH_SRES_MICRO', '8'))))
+    accum = max(1, total_batch // micro)
     graphs = os.environ.get('LVG_TRAIN_GRAPHS', '1') != '0'      # one rank: the compute of both updates replayed from hipGraphs (SuperResTrainer(use_graphs=True))
     tr = SuperResTrainer(device=dev, compute_dtype=torch.float16, G_grad_accum=accum, D_grad_accum=accum, augment_p_init=0.2,
                          overlap_grad_sync=True, with_ema=True, use_graphs=graphs)
@@ -639,7 +646,7 @@ def _train_sres_leg(dev, steps=16, warmup=1, total_batch=16):
     return {**extra, 'metric': 'frames/sec train_sres iteration (update_G + update_D + R1/16 + ADA/4 + EMA), 8-frame 144x256 segments', 'value': round(total_batch * 8 / dt, 2),
             'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'warmup': warmup, 'dtype': 'f16',
             'launch_mode': 'hipgraph per phase (update_G micro-batch, fake generation, update_D micro-batch, R1 micro-batch); optimizer, ADA update eager' if graphs else 'eager', 'n_gpus': 1,
-            'config': {'workload': f'train_sres.py step body, total batch {total_batch} ({accum} micro-batches of 2 segments), ADA p = 0.2 + conditioning augmentation, '
+            'config': {'workload': f'train_sres.py step body, total batch {total_batch} ({accum} micro-batches of {total_batch // accum} segments), ADA p = 0.2 + conditioning augmentation, '
                                    f'R1 steps in the timed region: {r1_steps}, ADA updates: {ada_steps}', 'global_batch': total_batch}}
 
 
