@@ -530,16 +530,17 @@ def _train_lres_workload(args, world, rank, dev, dtype):
 
 def _train_lres_run(world, rank, dev, dtype, frames_per_clip, steps, warmup, dtype_name='bf16', total_batch=32, accum=None):
     """-> the result dict (identical on every rank). Micro-batches: 2 per update as in the reference's 8-GPU recipe (batch 32 / 8 GPUs,
-    grad_accum 2 => per-GPU micro-batch 2); at N = 1 the 32 clips are cut into micro-batches of 8 (the size the main line measures)."""
+    grad_accum 2 => per-GPU micro-batch 2); at N = 1 the 32 clips are cut into micro-batches of 16."""
     from lvg.train_lres import LowResTrainer
     assert total_batch % world == 0
     B = total_batch // world
     if accum is None:
-        # micro-batches of at most 8 clips (the size the main line measures); ONE micro-batch whenever the rank's share is 8 clips or
+        # micro-batches of at most 16 clips (round 6; 8 before); ONE micro-batch whenever the rank's share is 16 clips or
         # fewer -- at 8 ranks that is 4 clips in one pass instead of the reference recipe's 2 x 2 (train_lres.py:65-69: its accumulation
         # exists to fit 32 clips into 8 x 32 GB; 288 GB of HBM do not need it, the gradient mean is the same, and the per-launch fixed cost
-        # of the step is paid once instead of twice: VERDICT r03 item 4b)
-        accum = max(1, B // 8)
+        # of the step is paid once instead of twice: VERDICT r03 item 4b). Measured at one rank, 32 clips, no R1, same call
+        # (profiles/r06_train_lres_microbatch.log): 332.7 / 296.8 / 303.6 ms per iteration with 4 / 2 / 1 micro-batches (18 / 30 / 57 GiB).
+        accum = max(1, B // int(os.environ.get('LVG_BENCH_LRES_MICRO', '16')))
     torch.manual_seed(0)
     # At every world size the compute of update_G / update_D is replayed from hipGraphs (LowResTrainer(use_graphs=True); the host draws of
     # the augmentations go through static buffers); the collectives stay outside the captured phases: the gradient exchange follows a
