@@ -651,9 +651,10 @@ def _train_sres_leg(dev, steps=16, warmup=1, total_batch=16):
                                    f'R1 steps in the timed region: {r1_steps}, ADA updates: {ada_steps}', 'global_batch': total_batch}}
 
 
-def _batch_sweep_leg(G, D, dtype, T, batches=(1, 2, 4), steps=6):
+def _batch_sweep_leg(G, D, dtype, T, batches=(1, 2, 4, 16), steps=6):
     """The main step (G forward, D forward, backward; hipGraph) at the per-GPU batch sizes of SURVEY.md 8(d) config 2 (b in {1, 2, 4}; the
-    reference's 8-GPU recipe runs micro-batches of 2): frames/s and ms per step, without the optimizer (parameters stay as they are)."""
+    reference's 8-GPU recipe runs micro-batches of 2) and at 16 (the train_lres leg's micro-batch since round 6): frames/s and ms per step, without the optimizer
+    (parameters stay as they are)."""
     from lvg.models import lres
     out = {}
     for b in batches:
