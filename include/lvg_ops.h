@@ -292,6 +292,10 @@ int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, const void* 
 int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                       int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
                                       int dst_h, int dst_w, int off_y, int off_x, int zero_border, int dtype, void* stream);
+/* ... with a planar reduction partner oth [n][c_oth][src_h][src_w] (the source's own layout; c_oth <= c_a + c_b): partial = per-tile sums of src * oth. */
+int lvg_modconv2d_nchw_to_nhwc_padded_planar(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                                      int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
+                                      int dst_h, int dst_w, int off_y, int off_x, int zero_border, int dtype, void* stream);
 
 /*
  * Dense 3 x 3 contraction of the super-resolution networks as a hand-written implicit GEMM (csrc/conv2d_igemm.hip) and its
@@ -319,6 +323,12 @@ int64_t lvg_conv2d_frames_workgroups(int64_t n, int hi, int wi, int ho, int wo, 
 int lvg_conv2d_frames(const void* x, const void* w, const float* pre, void* out,
                       int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int kh, int kw, int in_off_y, int in_off_x,
                       int64_t x_pixel_stride, int64_t out_pixel_stride, int dtype, int out_dtype, void* stream);
+/* ... with the result stored as NCHW planes for a consumer that tiles planes (filtered_lrelu): out [n][co_out][ho][wo] = pre[n][co_out] * acc for the first
+ * co_out <= co channels (co: the padded channel count of w; pre may be NULL), x's dtype; wo even. Replaces lvg_conv2d_frames + lvg_modconv2d_nhwc_to_nchw
+ * (the demodulation `x * dcoefs` of model/generator_sres.py:54-55, applied to the output). */
+int lvg_conv2d_frames_planes(const void* x, const void* w, const float* pre, void* out,
+                             int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
+                             int64_t x_pixel_stride, int dtype, void* stream);
 int lvg_conv2d_frames_wgrad_splits(int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw);
 int lvg_conv2d_frames_wgrad(const void* x, const void* dy, float* part,
                             int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw,

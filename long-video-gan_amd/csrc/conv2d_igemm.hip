@@ -74,10 +74,10 @@ bool shape_ok2d(int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int k
     return n * hi * wi < ((int64_t)1 << 31) && n * hi * wi * xstride * 2 < ((int64_t)1 << 32) && n * ho * wo < ((int64_t)1 << 31);
 }
 
-template <class T, int BM, int BN, bool OUTF = false>
+template <class T, int BM, int BN, bool OUTF = false, bool PLANES = false>
 int launch2d(const ConvArgs2D& a, const Plan2D& pl, hipStream_t stream)
 {
-    auto kern = conv3d_igemm_kernel<T, BM, BN, 2, 2, true, OUTF>;
+    auto kern = conv3d_igemm_kernel<T, BM, BN, 2, 2, true, OUTF, false, false, PLANES>;
     if (pl.ldsBytes > 64 * 1024)
     {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -94,12 +94,21 @@ int launch2d(const ConvArgs2D& a, const Plan2D& pl, hipStream_t stream)
 }
 
 template <class T>
-int launch2d_tile(const ConvArgs2D& a0, const Plan2D& pl, hipStream_t s, bool outF32)
+int launch2d_tile(const ConvArgs2D& a0, const Plan2D& pl, hipStream_t s, bool outF32, bool planes = false)
 {
     ConvArgs2D a = a0;
     a.coBase = 0;
     a.nTiles = pl.coMain / pl.bn;
     int rc = LVG_OK;
+    if (planes)
+    {
+        // NCHW plane output (8 x 16 tiles): the same two launches -- tiles of 128 channels, then the last 64
+        rc = pl.bn == 128 ? launch2d<T, 128, 128, false, true>(a, pl, s) : launch2d<T, 128, 64, false, true>(a, pl, s);
+        if (rc != LVG_OK || pl.coMain == a.Co) return rc;
+        a.coBase = pl.coMain;
+        a.nTiles = 1;
+        return launch2d<T, 128, 64, false, true>(a, pl, s);
+    }
     if (outF32)             rc = pl.bn == 128 ? launch2d<T, 128, 128, true>(a, pl, s) : launch2d<T, 128, 64, true>(a, pl, s);     // (8 x 16 tiles only)
     else if (pl.bm == 256)  rc = pl.bn == 128 ? launch2d<T, 256, 128>(a, pl, s) : launch2d<T, 256, 64>(a, pl, s);
     else                    rc = pl.bn == 128 ? launch2d<T, 128, 128>(a, pl, s) : launch2d<T, 128, 64>(a, pl, s);
@@ -164,4 +173,48 @@ extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre,
     a.offY = in_off_y; a.offX = in_off_x;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == LVG_BF16 ? launch2d_tile<bf16_t>(a, pl, s, outF32) : launch2d_tile<f16_t>(a, pl, s, outF32);
+}
+
+// The same contraction with the result stored as NCHW planes: out [n][co_out][ho][wo] = pre[n][co_out] * acc for the first co_out <= co channels
+// (co: the padded count of the weight). wo even (the kernel stores pixel pairs at least); 16-bit output.
+extern "C" int lvg_conv2d_frames_planes(const void* x, const void* w, const float* pre, void* out,
+                                        int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
+                                        int64_t x_pixel_stride, int dtype, void* stream)
+{
+    LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv2d_frames_planes: float16 / bfloat16 only (dtype %d)", dtype);
+    LVG_REQUIRE(x && w && out, "conv2d_frames_planes: null tensor");
+    LVG_REQUIRE(lvg_aligned16(x) && lvg_aligned16(w) && lvg_aligned16(out) && lvg_aligned16(pre), "conv2d_frames_planes: pointers must be 16-byte aligned");
+    LVG_REQUIRE(co_out >= 1 && co_out <= co && wo % 2 == 0, "conv2d_frames_planes: 1 <= co_out <= co, even output width (got co_out %d, co %d, width %d)", co_out, co, wo);
+    if (x_pixel_stride == 0) x_pixel_stride = ci;
+    if (!shape_ok2d(n, hi, wi, ho, wo, ci, co, kh, kw, x_pixel_stride, co, in_off_y, in_off_x) || n * (int64_t)co_out * ho * wo >= ((int64_t)1 << 40))
+    {
+        lvg_set_error("conv2d_frames_planes: no kernel for Ci=%d Co=%d taps=%dx%d, %lld frames %dx%d -> %dx%d at (%d, %d)", ci, co, kh, kw, (long long)n, hi, wi, ho, wo, in_off_y, in_off_x);
+        return LVG_ERR_UNSUPPORTED;
+    }
+    Plan2D pl;
+    if (make_plan2d(n, ho, wo, ci, co, pl, true) != 0)                   // (8 x 16 tiles, as for the float32-output kernels)
+    {
+        lvg_set_error("conv2d_frames_planes: no tile plan");
+        return LVG_ERR_UNSUPPORTED;
+    }
+    ConvArgs2D a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.pre = pre; a.out = out;
+    a.M = n * ho * wo;
+    a.H = ho; a.W = wo; a.Ci = ci; a.Co = co; a.kt = 1; a.kh = kh; a.kw = kw;
+    a.xStride = (int)x_pixel_stride;
+    a.bandRows = pl.bandRows;
+    a.nABuf = pl.nABuf;
+    a.nBBuf = 2;
+    a.nTiles = pl.coMain / pl.bn;
+    a.slopeNeg = 1.f;
+    a.gain = 1.f;
+    a.clamp = -1.f;
+    a.Hi = hi; a.Wi = wi;
+    a.tilesX = pl.tilesX; a.tilesY = pl.tilesY;
+    a.oStride = co;
+    a.offY = in_off_y; a.offX = in_off_x;
+    a.coOut = co_out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == LVG_BF16 ? launch2d_tile<bf16_t>(a, pl, s, false, true) : launch2d_tile<f16_t>(a, pl, s, false, true);
 }

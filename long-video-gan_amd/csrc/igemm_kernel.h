@@ -45,6 +45,7 @@ struct ConvArgs2D : ConvArgs
     int          oStride;      // elements between consecutive pixels of out (>= Co)
     int          offY, offX;   // output pixel (0, 0) reads input pixels (offY + dh, offX + dw)
     int          coBase;       // first output channel of this launch (a launch may cover a channel range of the Co channels)
+    int          coOut;        // PLANES kernels: channels of the NCHW output tensor (<= Co; channels past it are computed and dropped)
 };
 
 template <bool T2D> struct ConvArgsOf { typedef ConvArgs type; };
@@ -160,9 +161,15 @@ constexpr int kPatchPitch = kTileW + 2;
 // STATIC1 (time-major kernel, 64-channel tiles): the static-tap K loop for tiles whose LDS footprint (two bands) leaves room for ONE workgroup per
 // CU anyway -- the loop's 236 registers, which cost the two-workgroup case its occupancy, are free there (eight waves = two per SIMD = 256
 // registers each), and the generic loop's band waves (137-165 scalar + 88 vector instructions per K-step against 8 MFMAs) paced those tiles.
-template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false, bool PERSIST = false, bool STATIC1 = false>
+// PLANES (2-D tiles, 16-bit output, round 6): the result leaves as NCHW PLANES, out[n][co][oy][ox] = pre[n][co] * acc, for the consumer that tiles planes
+// (filtered_lrelu) -- instead of channels-last rows followed by a transposing pass over the whole tensor (csrc/modconv2d_layout.hip, 6 % of a super-resolution
+// training iteration). The two MFMA operands have the same register format, so exchanging them yields the transposed result block: a lane then holds ONE output
+// channel and four horizontally adjacent pixels per register quad. Staged as [channel][pixel] rows in LDS, a lane reads eight adjacent pixels of a channel
+// (16 bytes) and stores them into the plane: 32-byte runs per (channel, tile row); the neighbouring tile -- same XCD, next in its order -- completes the line in L2.
+template <class T, int BM, int BN, int PB, int NB, bool T2D = false, bool OUTF = false, bool PERSIST = false, bool STATIC1 = false, bool PLANES = false>
 __global__ __launch_bounds__(BM / (32 * PB) * 128, STATIC1 ? 1 : 2) void conv3d_igemm_kernel(typename ConvArgsOf<T2D>::type p)
 {
+    static_assert(!PLANES || (T2D && !OUTF && PB == 2), "plane output: 2-D tiles, 16-bit output");
     static_assert(!PERSIST || (!T2D && !OUTF), "persistent form: time-major frames, 16-bit output");
     static_assert(!STATIC1 || (!T2D && !OUTF && !PERSIST && NB == 2), "one-workgroup static form: time-major frames, 16-bit output, ring of two");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -460,7 +467,7 @@ next_tile:                                                            // PERSIST
                 for (int pb = 0; pb < PB; pb++)
                     #pragma unroll
                     for (int cb = 0; cb < NCB; cb++)
-                        acc[cb][pb] = Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
+                        acc[cb][pb] = PLANES ? Mma<T>::run(xf[ks & 1][pb], wf[ks & 1][cb], acc[cb][pb]) : Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
             }
             else
             {
@@ -550,7 +557,7 @@ next_tile:                                                            // PERSIST
                 for (int pb = 0; pb < PB; pb++)
                     #pragma unroll
                     for (int cb = 0; cb < NCB; cb++)
-                        acc[cb][pb] = Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
+                        acc[cb][pb] = PLANES ? Mma<T>::run(xf[ks & 1][pb], wf[ks & 1][cb], acc[cb][pb]) : Mma<T>::run(wf[ks & 1][cb], xf[ks & 1][pb], acc[cb][pb]);
                 // this sub-step's share of the staging: the DMA instructions (volatile asm) sit between the MFMA groups in program order
                 if constexpr (kSpreadDma) stage(ksc);
             });
@@ -913,6 +920,54 @@ next_tile:                                                            // PERSIST
                                                   // late pieces land in the LDS of the NEXT workgroup on the CU: intermittent wrong tiles, measured
                                                   // as a 1e-2 gradient error in one run out of two of the float32 model test)
     if constexpr (kLdsStore) __syncthreads();
+    if constexpr (PLANES)
+    {
+        // acc[cb][pb][4 qd + e]: channel co0 + wc * WCO + cb * 32 + l31, pixel pb * 32 + 8 qd + 4 hi + e of this wave's 64 (tile rows 4 wr .. 4 wr + 3, 16 wide)
+        constexpr int PP = ROWS * 2 + 8;              // staged channel row: 64 pixels + 8 bytes (the 32 lanes of a half wave write 8 bytes each to 64 distinct banks)
+        unsigned char* const st = smem + wave * (WCO * PP);
+        #pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+        {
+            const int c = co0 + wc * WCO + cb * 32 + l31;
+            const float scale = (p.pre && c < p.coOut) ? p.pre[(int64_t)n2 * p.coOut + c] : 1.f;
+            #pragma unroll
+            for (int pb = 0; pb < PB; pb++)
+                #pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+                {
+                    T o4[4];
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) o4[e] = from_acc<T>(acc[cb][pb][qd * 4 + e] * scale);
+                    uint2 ov;
+                    __builtin_memcpy(&ov, o4, 8);
+                    *reinterpret_cast<uint2*>(st + (cb * 32 + l31) * PP + (pb * 32 + 8 * qd + 4 * hi) * 2) = ov;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T* const outp = static_cast<T*>(p.out);
+        #pragma unroll
+        for (int i = 0; i < WCO / 8; i++)
+        {
+            const int t = i * 64 + lane, cl = t >> 3, seg = t & 7;             // channel row, 8-pixel segment of its 64 pixels
+            const uint2 lo = *reinterpret_cast<const uint2*>(st + cl * PP + seg * 16);
+            const uint2 hi2 = *reinterpret_cast<const uint2*>(st + cl * PP + seg * 16 + 8);
+            const int c = co0 + wc * WCO + cl;
+            const int oy = y0 + wr * (ROWS / kTileW) + (seg >> 1), ox = x0 + (seg & 1) * 8;
+            if (c < p.coOut && oy < p.H)
+            {
+                T* const dst = outp + (((int64_t)n2 * p.coOut + c) * p.H + oy) * p.W + ox;
+                // W is even (host check): 8, 6, 4 or 2 pixels of the segment are inside the plane; rows are 4-byte aligned (dword-aligned multi-dword stores)
+                const int left = p.W - ox;
+                if (left >= 8) { *reinterpret_cast<uint2*>(dst) = lo; *reinterpret_cast<uint2*>(dst + 4) = hi2; }
+                else if (left >= 6) { *reinterpret_cast<uint2*>(dst) = lo; *reinterpret_cast<uint32_t*>(dst + 4) = hi2.x; }
+                else if (left >= 4) *reinterpret_cast<uint2*>(dst) = lo;
+                else if (left >= 2) *reinterpret_cast<uint32_t*>(dst) = lo.x;
+            }
+        }
+        return;
+    }
     const int flipW = (l31 >> 4) & 1;
     // 16-byte stores of the staged wave tile to `dst` (rows = pixels m0 + wr * ROWS + ..., this wave's channel range)
     auto flush = [&](T* dst) __attribute__((always_inline))

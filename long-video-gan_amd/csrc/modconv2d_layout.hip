@@ -47,7 +47,8 @@ struct LayoutArgs
     int cNhwc;                             // channels (= pixel stride) of the NHWC tensor (source or destination)
     int cDst;                              // nhwc_to_nchw: channels written
     int cOth;                              // nchw_to_nhwc: channels (= pixel stride) of the NHWC reduction partner
-    int vecP;                              // 1: pixel rows of the NCHW tensors may be accessed as 16-byte vectors
+    int vecP;                              // pixel rows of the NCHW tensors: 2 = 16-byte vectors, 1 = dwords (even plane size), 0 = elements (load_row8)
+    int othPlanar;                         // nchw_to_nhwc: the reduction partner is NCHW like the source ([n, cOth, hw]) instead of NHWC
     // nchw_to_nhwc into a LARGER frame (the explicitly zero-padded frames of conv2d_igemm.hip / conv2d_wgrad.hip): source pixel
     // p = y * srcW + x goes to pixel (y + offY) * dstW + (x + offX) of a frame of dstHW pixels; srcW == 0: same frame (pixel p).
     // The border is NOT written here (the caller zero-fills the tensor once).
@@ -56,6 +57,54 @@ struct LayoutArgs
 };
 
 template <class T> __device__ __forceinline__ float ld1(const T* p) { return (float)to_acc(*p); }
+
+// 8 consecutive pixels of an NCHW row from pixel p (a multiple of 8). level 2: one 16-byte access (hw % 8 == 0, aligned bases); level 1: four 4-byte accesses
+// (hw even: every row starts on a dword -- all plane sizes of the super-resolution networks, 38 x 38 .. 278 x 166, are even but not multiples of 8: round 6);
+// level 0: element by element. Pixels at or past hw read as 0 / are not written.
+template <class T> __device__ __forceinline__ Vec16<T> load_row8(const T* row, int p, int hw, int level)
+{
+    Vec16<T> val;
+    if (level == 2 && p + 8 <= hw) return load_vec16<T>(row + p);
+    #pragma unroll
+    for (int e = 0; e < 8; e++) val.v[e] = from_acc<T>(0.0f);
+    if (level >= 1)
+    {
+        #pragma unroll
+        for (int e = 0; e < 8; e += 2)
+            if (p + e + 2 <= hw)
+            {
+                uint32_t w;
+                w = *reinterpret_cast<const uint32_t*>(row + p + e);
+                __builtin_memcpy(&val.v[e], &w, 4);
+            }
+    }
+    else
+    {
+        #pragma unroll
+        for (int e = 0; e < 8; e++) if (p + e < hw) val.v[e] = row[p + e];
+    }
+    return val;
+}
+template <class T> __device__ __forceinline__ void store_row8(T* row, int p, int hw, int level, const Vec16<T>& val)
+{
+    if (level == 2 && p + 8 <= hw) { store_vec16<T>(row + p, val); return; }
+    if (level >= 1)
+    {
+        #pragma unroll
+        for (int e = 0; e < 8; e += 2)
+            if (p + e + 2 <= hw)
+            {
+                uint32_t w;
+                __builtin_memcpy(&w, &val.v[e], 4);
+                *reinterpret_cast<uint32_t*>(row + p + e) = w;
+            }
+    }
+    else
+    {
+        #pragma unroll
+        for (int e = 0; e < 8; e++) if (p + e < hw) row[p + e] = val.v[e];
+    }
+}
 
 // element (c, p) of the channel-concatenated NCHW pair, 0 outside
 template <class T>
@@ -109,16 +158,24 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
         #pragma unroll
         for (int e = 0; e < 8; e++) val.v[e] = from_acc<T>(0.0f);
         const T* row = nchw_ptr<T>(a.srcA, a.srcB, a.cA, a.cB, n, cc, a.hw);
-        if (row)
-        {
-            if (a.vecP && p + 8 <= a.hw) val = load_vec16<T>(row + p);
-            else
-            {
-                #pragma unroll
-                for (int e = 0; e < 8; e++) if (p + e < a.hw) val.v[e] = row[p + e];
-            }
-        }
+        if (row && p < a.hw) val = load_row8<T>(row, p, a.hw, a.vecP);
         store_vec16<T>(tile + c * kLdsStride + 8 * seg, val);
+        if (RED && a.othPlanar)
+        {
+            // planar partner: the product is formed here, where a thread holds 8 pixels of one channel row of both tensors
+            float dsum = 0.0f;
+            if (row && cc < a.cOth)
+            {
+                const T* orow = (const T*)a.othA + (n * a.cOth + cc) * (int64_t)a.hw;
+                if (p < a.hw)
+                {
+                    const Vec16<T> o = load_row8<T>(orow, p, a.hw, a.vecP);          // (pixels past hw: 0 in both operands)
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) dsum += (float)to_acc(val.v[e]) * (float)to_acc(o.v[e]);
+                }
+            }
+            red[c * 65 + seg] = dsum;
+        }
     }
     if (tid < kTile) sc[tid] = (a.scale && c0 + tid < cSrc) ? a.scale[n * cSrc + c0 + tid] : 1.0f;
     __syncthreads();
@@ -153,7 +210,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
             for (int j = 0; j < 8; j++) out.v[j] = from_acc<T>(x[j] * sv[j]);
             store_vec16<T>((T*)a.dst + dp * (int64_t)a.cNhwc + cc, out);
         }
-        if (RED)
+        if (RED && !a.othPlanar)
         {
             float d[8];
             #pragma unroll
@@ -174,7 +231,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(LayoutArgs a)
         if (tid < kTile && c0 + tid < cSrc)
         {
             float t = 0.0f;
-            for (int k = 0; k < kTile; k++) t += red[tid * 65 + k];                // fixed order
+            const int terms = a.othPlanar ? 8 : kTile;
+            for (int k = 0; k < terms; k++) t += red[tid * 65 + k];                // fixed order
             a.partial[(n * gridDim.x + blockIdx.x) * (int64_t)cSrc + c0 + tid] = t;
         }
     }
@@ -243,18 +301,10 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(LayoutArgs a)
         {
             const float s = a.scale ? a.scale[n * a.cDst + cc] : 1.0f;
             T* row = (T*)a.dst + (n * a.cDst + cc) * (int64_t)a.hw;
-            if (a.vecP && p + 8 <= a.hw)
-            {
-                Vec16<T> out;
-                #pragma unroll
-                for (int j = 0; j < 8; j++) out.v[j] = from_acc<T>(x[j] * s);
-                store_vec16<T>(row + p, out);
-            }
-            else
-            {
-                #pragma unroll
-                for (int j = 0; j < 8; j++) if (p + j < a.hw) row[p + j] = from_acc<T>(x[j] * s);
-            }
+            Vec16<T> out;
+            #pragma unroll
+            for (int j = 0; j < 8; j++) out.v[j] = from_acc<T>(x[j] * s);
+            store_row8<T>(row, p, a.hw, a.vecP, out);
         }
         if (a.partial)
         {
@@ -262,17 +312,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(LayoutArgs a)
             const T* orow = nchw_ptr<T>(a.othA, a.othB, a.cA, a.cB, n, cc, a.hw);
             if (orow && p < a.hw)
             {
-                if (a.vecP && p + 8 <= a.hw)
-                {
-                    const Vec16<T> o = load_vec16<T>(orow + p);
-                    #pragma unroll
-                    for (int j = 0; j < 8; j++) d += x[j] * (float)to_acc(o.v[j]);
-                }
-                else
-                {
-                    #pragma unroll
-                    for (int j = 0; j < 8; j++) if (p + j < a.hw) d += x[j] * (float)to_acc(orow[p + j]);
-                }
+                const Vec16<T> o = load_row8<T>(orow, p, a.hw, a.vecP);              // (pixels past hw read as 0)
+                #pragma unroll
+                for (int j = 0; j < 8; j++) d += x[j] * (float)to_acc(o.v[j]);
             }
             // v = 0: channels 0..31 of the tile, v = 1: channels 32..63; 8 pixel segments per channel
             red[seg * kTile + c] = d;
@@ -407,12 +449,12 @@ __global__ __launch_bounds__(256) void nhwc_f32_to_nchw_kernel(UnsplitArgs a)
 
 static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream,
-                               int src_w, int dst_h, int dst_w, int off_y, int off_x, int zero_border);
+                               int src_w, int dst_h, int dst_w, int off_y, int off_x, int zero_border, int oth_planar);
 
 extern "C" int lvg_modconv2d_nchw_to_nhwc(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                           int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream)
 {
-    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, hw, c_a, c_b, c_dst, c_oth, dtype, stream, 0, 0, 0, 0, 0, 0);
+    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, hw, c_a, c_b, c_dst, c_oth, dtype, stream, 0, 0, 0, 0, 0, 0, 0);
 }
 
 // The same pass writing into the interior of a larger channels-last frame [n][dst_h][dst_w][c_dst] at (off_y, off_x): source planes are
@@ -427,24 +469,41 @@ extern "C" int lvg_modconv2d_nchw_to_nhwc_padded(const void* src_a, const void* 
                 "modconv2d_nchw_to_nhwc_padded: the source plane must fit inside the destination frame");
     LVG_REQUIRE((int64_t)dst_h * dst_w <= 0x3fffffffLL, "modconv2d_nchw_to_nhwc_padded: destination frame too large");
     return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, (int64_t)src_h * src_w, c_a, c_b, c_dst, c_oth, dtype, stream,
-                               src_w, dst_h, dst_w, off_y, off_x, zero_border);
+                               src_w, dst_h, dst_w, off_y, off_x, zero_border, 0);
+}
+
+// ... with a PLANAR reduction partner: oth [n][c_oth][src_h][src_w] in the source's own layout (c_oth <= c_a + c_b channels take part), 16-byte aligned:
+// partial[n][tile][c] = sum over the tile's pixels of src * oth. (The convolution that stores planes itself, lvg_conv2d_frames_planes, keeps its OUTPUT for
+// the backward pass -- y * demod as NCHW planes -- where the two-pass route kept the channels-last y.)
+extern "C" int lvg_modconv2d_nchw_to_nhwc_padded_planar(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
+                                                        int64_t n, int src_h, int src_w, int c_a, int c_b, int c_dst, int c_oth,
+                                                        int dst_h, int dst_w, int off_y, int off_x, int zero_border, int dtype, void* stream)
+{
+    LVG_REQUIRE(src_h >= 1 && src_w >= 1 && off_y >= 0 && off_x >= 0 && dst_h >= src_h + off_y && dst_w >= src_w + off_x,
+                "modconv2d_nchw_to_nhwc_padded_planar: the source plane must fit inside the destination frame");
+    LVG_REQUIRE((int64_t)dst_h * dst_w <= 0x3fffffffLL, "modconv2d_nchw_to_nhwc_padded_planar: destination frame too large");
+    return nchw_to_nhwc_launch(src_a, src_b, scale, oth, dst, partial, n, (int64_t)src_h * src_w, c_a, c_b, c_dst, c_oth, dtype, stream,
+                               src_w, dst_h, dst_w, off_y, off_x, zero_border, 1);
 }
 
 static int nchw_to_nhwc_launch(const void* src_a, const void* src_b, const float* scale, const void* oth, void* dst, float* partial,
                                int64_t n, int64_t hw, int c_a, int c_b, int c_dst, int c_oth, int dtype, void* stream,
-                               int src_w, int dst_h, int dst_w, int off_y, int off_x, int zero_border)
+                               int src_w, int dst_h, int dst_w, int off_y, int off_x, int zero_border, int oth_planar)
 {
     if (int rc = check_common("modconv2d_nchw_to_nhwc", n, hw, dtype)) return rc;
     LVG_REQUIRE(src_a && dst && c_a >= 1 && c_b >= 0 && (c_b == 0 || src_b), "modconv2d_nchw_to_nhwc: bad sources");
     LVG_REQUIRE(c_dst >= c_a + c_b && c_dst % 8 == 0, "modconv2d_nchw_to_nhwc: the NHWC channel count must be a multiple of 8 covering the sources");
     LVG_REQUIRE((partial == nullptr) == (oth == nullptr), "modconv2d_nchw_to_nhwc: partial and oth go together");
-    LVG_REQUIRE(!oth || (c_oth % 8 == 0 && c_oth >= c_a + c_b), "modconv2d_nchw_to_nhwc: bad reduction partner");
+    LVG_REQUIRE(!oth || oth_planar || (c_oth % 8 == 0 && c_oth >= c_a + c_b), "modconv2d_nchw_to_nhwc: bad reduction partner");
+    LVG_REQUIRE(!oth || !oth_planar || (c_oth >= 1 && c_oth <= c_a + c_b), "modconv2d_nchw_to_nhwc: a planar reduction partner has at most the source's channels");
     LVG_REQUIRE(lvg_aligned16(dst) && (!oth || lvg_aligned16(oth)), "modconv2d_nchw_to_nhwc: NHWC tensors must be 16-byte aligned");
     LayoutArgs a = {};
     a.srcA = src_a; a.srcB = src_b; a.othA = oth; a.dst = dst; a.scale = scale; a.partial = partial;
     a.n = (int)n; a.hw = (int)hw; a.cA = c_a; a.cB = c_b; a.cNhwc = c_dst; a.cOth = c_oth;
     a.srcW = src_w; a.dstW = dst_w; a.dstHW = dst_h * dst_w; a.offY = off_y; a.offX = off_x;
-    a.vecP = (hw % 8 == 0) && lvg_aligned16(src_a) && (!src_b || lvg_aligned16(src_b));
+    a.vecP = ((hw % 8 == 0) && lvg_aligned16(src_a) && (!src_b || lvg_aligned16(src_b)) && (!(oth && oth_planar) || lvg_aligned16(oth))) ? 2
+             : ((hw % 2 == 0 && ((uintptr_t)src_a % 4) == 0 && (!src_b || ((uintptr_t)src_b % 4) == 0) && (!(oth && oth_planar) || ((uintptr_t)oth % 4) == 0)) ? 1 : 0);
+    a.othPlanar = (oth && oth_planar) ? 1 : 0;
     dim3 grid((unsigned)lvg_ceil_div(hw, kTile), (unsigned)lvg_ceil_div(c_dst, kTile), (unsigned)n);
     a.invW = (src_w > 0 && hw < (1 << 22)) ? 1.0f / (float)src_w : 0.0f;
     if (zero_border)
@@ -476,7 +535,8 @@ extern "C" int lvg_modconv2d_nhwc_to_nchw(const void* src, const float* scale, c
     LayoutArgs a = {};
     a.srcA = src; a.othA = oth_a; a.othB = oth_b; a.dst = dst; a.scale = scale; a.partial = partial;
     a.n = (int)n; a.hw = (int)hw; a.cA = oth_a ? c_a : 0; a.cB = oth_a ? c_b : 0; a.cNhwc = c_src; a.cDst = c_dst;
-    a.vecP = (hw % 8 == 0) && lvg_aligned16(dst) && (!oth_a || lvg_aligned16(oth_a)) && (!oth_b || lvg_aligned16(oth_b));
+    a.vecP = ((hw % 8 == 0) && lvg_aligned16(dst) && (!oth_a || lvg_aligned16(oth_a)) && (!oth_b || lvg_aligned16(oth_b))) ? 2
+             : ((hw % 2 == 0 && ((uintptr_t)dst % 4) == 0 && (!oth_a || ((uintptr_t)oth_a % 4) == 0) && (!oth_b || ((uintptr_t)oth_b % 4) == 0)) ? 1 : 0);
     const int cCover = (oth_a && c_a + c_b > c_dst) ? c_a + c_b : c_dst;
     dim3 grid((unsigned)lvg_ceil_div(hw, kTile), (unsigned)lvg_ceil_div(cCover, kTile), (unsigned)n);
     if (dtype == LVG_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);

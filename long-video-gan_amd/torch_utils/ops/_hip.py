@@ -53,8 +53,10 @@ _SIGNATURES = {
     'lvg_modconv2d_nchw_to_nhwc': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nhwc_to_nchw': [_vp] * 6 + [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     'lvg_modconv2d_nchw_to_nhwc_padded': [_vp] * 6 + [_i64] + [_i32] * 12 + [_vp],
+    'lvg_modconv2d_nchw_to_nhwc_padded_planar': [_vp] * 6 + [_i64] + [_i32] * 12 + [_vp],
     'lvg_conv2d_frames_workgroups': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames': [_vp] * 4 + [_i64] + [_i32] * 10 + [_i64, _i64, _i32, _i32, _vp],
+    'lvg_conv2d_frames_planes': [_vp] * 4 + [_i64] + [_i32] * 11 + [_i64, _i32, _vp],
     'lvg_conv2d_frames_wgrad_splits': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames_wgrad': [_vp] * 3 + [_i64] + [_i32] * 8 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_ada_warp': [_vp] * 5 + [_i32] * 4 + [_vp],

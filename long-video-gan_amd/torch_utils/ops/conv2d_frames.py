@@ -100,6 +100,31 @@ def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None, out_dtype=None, alg_flo
     return y.permute(0, 2, 3, 1).contiguous().to(out_dtype)
 
 
+def conv2d_valid_planes(x, wp, ho, wo, co_out, offset=(0, 0), pre=None, alg_flops=None):
+    """The contraction of `conv2d_valid` with the result as NCHW planes: out [N, co_out, ho, wo] = pre[n, co] * acc for the first co_out of wp's (padded)
+    output channels, in x's dtype with ONE rounding (lvg_conv2d_frames_planes; wo even on the GPU). pre float32 [N, co_out] or None."""
+    n, hi, wi, ci = x.shape
+    co = wp.shape[2]
+    assert ho <= hi - offset[0] - 2 and wo <= wi - offset[1] - 2 and wp.shape == (3, 3, co, ci) and 1 <= co_out <= co
+    if x.device.type == 'cuda' and _init():
+        assert supported(x, wp) and wo % 2 == 0, 'conv2d_frames_planes: no hand-written kernel for this shape / dtype / layout'
+        out = torch.empty([n, co_out, ho, wo], dtype=x.dtype, device=x.device)
+        pre = None if pre is None else pre.float().contiguous()
+        assert pre is None or tuple(pre.shape) == (n, co_out)
+        with torch.cuda.device(x.device):
+            rc = _hip.lib().lvg_conv2d_frames_planes(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), n, hi, wi, ho, wo, ci, co, co_out, 3, 3,
+                                                     offset[0], offset[1], ci, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+        _hip.check(rc, 'conv2d_frames_planes')
+        stats['flops'] += 2 * n * ho * wo * co * ci * 9 if alg_flops is None else alg_flops
+        stats['launches'] += 1
+        return out
+    v = x[:, offset[0]:offset[0] + ho + 2, offset[1]:offset[1] + wo + 2].permute(0, 3, 1, 2).float()
+    y = F.conv2d(v, wp.permute(2, 3, 0, 1).float())[:, :co_out]
+    if pre is not None:
+        y = y * pre.float()[:, :, None, None]
+    return y.contiguous().to(x.dtype)
+
+
 def split16(t, dtype=torch.float16):
     """float32 tensor -> (high, low) parts in `dtype` with high + low = t to ~2^-22 relative (float16: 11 + 11 mantissa bits).
     The operand side of a float32-accurate contraction on the 16-bit matrix cores:

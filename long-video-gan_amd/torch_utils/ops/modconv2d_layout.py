@@ -58,9 +58,10 @@ def _nchw_to_nhwc(src_a, src_b, scale, c_dst, oth=None):
     return dst, partial
 
 
-def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None, zero_border=False):
+def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None, zero_border=False, oth_planar=False):
     """cat(src_a, src_b) * scale -> the interior of the frames dst [N, Hd, Wd, C] at `offset`; -> partial or None
-    (partial[n, tile, c] = sum over the 64 pixels of tile of src[n, c, p] * oth[n, p, c], oth [N, H, W, c_oth] dense frames).
+    (partial[n, tile, c] = sum over the 64 pixels of tile of src[n, c, p] * oth[n, p, c], oth [N, H, W, c_oth] dense frames -- or, with
+    oth_planar, oth [N, c_oth, H, W] in the source's own layout).
     zero_border: the border pixels of dst are zero-filled by the call (dst may be torch.empty); else dst comes zero-filled."""
     n, c_a, h, w = src_a.shape
     c_b = 0 if src_b is None else src_b.shape[1]
@@ -74,17 +75,21 @@ def _nchw_to_nhwc_padded(src_a, src_b, scale, dst, offset, oth=None, zero_border
         dst[:, offset[0]:offset[0] + h, offset[1]:offset[1] + w, :c_a + c_b] = val.permute(0, 2, 3, 1).to(dst.dtype)
         if oth is None:
             return None
+        if oth_planar:
+            return (src[:, :oth.shape[1]].float() * oth.float()).sum(dim=(2, 3))[:, None, :]
         return (src.float().permute(0, 2, 3, 1) * oth[..., :c_a + c_b].float()).sum(dim=(1, 2))[:, None, :]
     partial = None
     if oth is not None:
-        assert oth.is_contiguous() and oth.shape[:3] == (n, h, w)
+        assert oth.is_contiguous() and (tuple(oth.shape) == (n, oth.shape[1], h, w) if oth_planar else oth.shape[:3] == (n, h, w))
         partial = torch.empty([n, (h * w + 63) // 64, c_a + c_b], dtype=torch.float32, device=src_a.device)
+        if oth_planar and oth.shape[1] < c_a + c_b:
+            partial.zero_()
+    fn = _hip.lib().lvg_modconv2d_nchw_to_nhwc_padded_planar if (oth is not None and oth_planar) else _hip.lib().lvg_modconv2d_nchw_to_nhwc_padded
     with torch.cuda.device(src_a.device):
-        rc = _hip.lib().lvg_modconv2d_nchw_to_nhwc_padded(
-            src_a.data_ptr(), None if src_b is None else src_b.data_ptr(), None if scale is None else scale.data_ptr(),
-            None if oth is None else oth.data_ptr(), dst.data_ptr(), None if partial is None else partial.data_ptr(),
-            n, h, w, c_a, c_b, c_dst, 0 if oth is None else oth.shape[3], hd, wd, offset[0], offset[1], 1 if zero_border else 0,
-            _hip.dtype_code(src_a.dtype), _hip.stream(src_a.device))
+        rc = fn(src_a.data_ptr(), None if src_b is None else src_b.data_ptr(), None if scale is None else scale.data_ptr(),
+                None if oth is None else oth.data_ptr(), dst.data_ptr(), None if partial is None else partial.data_ptr(),
+                n, h, w, c_a, c_b, c_dst, 0 if oth is None else (oth.shape[1] if oth_planar else oth.shape[3]), hd, wd, offset[0], offset[1], 1 if zero_border else 0,
+                _hip.dtype_code(src_a.dtype), _hip.stream(src_a.device))
     _hip.check(rc, 'modconv2d_nchw_to_nhwc_padded')
     return partial
 
@@ -202,10 +207,17 @@ class _ModConv2dHand(torch.autograd.Function):
             wp = prepared.wp
         else:
             wp = conv2d_frames.pack_weight(weight, first.dtype, ci_pad, co_pad)
-        y = conv2d_frames.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), alg_flops=alg)
-        out, _ = _frames_to_nchw(y, demod, co)
+        planes = PLANES_OUT and first.is_cuda and geo.wo % 2 == 0 and demod is not None
+        if planes:
+            # the convolution stores the demodulated NCHW planes itself (lvg_conv2d_frames_planes: no transposing pass over the result); the
+            # backward pass gets d demod from these planes, sum d_out * out / demod
+            out = conv2d_frames.conv2d_valid_planes(xp, wp, geo.ho, geo.wo, co, offset=(geo.q, geo.q), pre=demod, alg_flops=alg)
+            y = out
+        else:
+            y = conv2d_frames.conv2d_valid(xp, wp, geo.ho, geo.wo, offset=(geo.q, geo.q), alg_flops=alg)
+            out, _ = _frames_to_nchw(y, demod, co)
         ctx.save_for_backward(first, second, mod, demod, xp, y, weight)
-        ctx.geo, ctx.alg, ctx.prepared = geo, alg, prepared
+        ctx.geo, ctx.alg, ctx.prepared, ctx.planes, ctx.co_pad = geo, alg, prepared, planes, co_pad
         return out
 
     @staticmethod
@@ -216,12 +228,14 @@ class _ModConv2dHand(torch.autograd.Function):
         assert not ctx.needs_input_grad[1], 'modulated_conv2d: no gradient for the conditioning frames on the fused path'
         n, c_first = first.shape[:2]
         co, ci = weight.shape[:2]
-        ci_pad, co_pad = xp.shape[3], y.shape[3]
+        ci_pad, co_pad = xp.shape[3], ctx.co_pad
         need_first, need_weight, need_mod, need_demod = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3], demod is not None and ctx.needs_input_grad[4]
         # gradient frames: d_out * demod at (q, q) of the zero-filled patch-aligned frame; d demod = sum d_out * y from the same pass
         dyp = torch.empty([n, geo.hd, geo.wd, co_pad], dtype=first.dtype, device=first.device)
-        partial = _nchw_to_nhwc_padded(d_out.contiguous(), None, demod, dyp, (geo.q, geo.q), oth=y if need_demod else None, zero_border=True)
+        partial = _nchw_to_nhwc_padded(d_out.contiguous(), None, demod, dyp, (geo.q, geo.q), oth=y if need_demod else None, zero_border=True, oth_planar=ctx.planes)
         d_demod = partial.sum(dim=1) if need_demod else None
+        if need_demod and ctx.planes:
+            d_demod = d_demod / demod                        # the saved planes are y * demod (demod = rsqrt(...) > 0)
         d_weight = None
         prepared = ctx.prepared
         if need_weight:
@@ -380,6 +394,8 @@ class _ModConv2dSplit(torch.autograd.Function):
         return d_first, None, d_weight, d_mod, d_demod, None
 
 
+# 16-bit layers: the convolution writes demodulated NCHW planes itself (lvg_conv2d_frames_planes) instead of channels-last rows + lvg_modconv2d_nhwc_to_nchw (0: the two passes)
+PLANES_OUT = os.environ.get('LVG_SRES_PLANES_OUT', '1') != '0'
 FUSED_SPLIT = os.environ.get('LVG_SRES_FUSED_SPLIT', '1') != '0'     # operands of the float32 layers split in one pass (lvg_split16_frames; 0: tensor expressions)
 SPLIT_F32 = os.environ.get('LVG_SRES_SPLIT_F32', '1') != '0'      # float32 3 x 3 layers on the hand-written kernels through split operands (0: the library convolution)
 

@@ -353,3 +353,64 @@ def test_fused_operand_split_equals_tensor_expressions_gpu(shape, monkeypatch):
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name
             continue
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 64, 128, 20, 36), (1, 128, 362, 21, 54), (3, 192, 64, 9, 150), (2, 64, 181, 33, 22), (1, 64, 3, 8, 16), (1, 64, 128, 11, 38)],
+                         ids=['128ch', '362_of_384_w54', 'wide_64_w150', '181_of_192_w22', 'three_of_64', 'w38'])
+def test_plane_output_equals_channels_last_output_gpu(shape, dtype):
+    """lvg_conv2d_frames_planes (round 6: the convolution stores NCHW planes itself -- exchanged MFMA operands, [channel][pixel] staging) against
+    lvg_conv2d_frames followed by the tensor transposition: the same accumulators, so with pre = None the two agree BIT FOR BIT (one rounding
+    each); with the demodulation scale the plane kernel rounds once where the two-pass route rounds twice: compared with the float32
+    product. Shapes: ragged tile edges in both directions (widths of 16 k + 4 and 16 k + 6 = the network's 38 / 54 / 86 / 150 / 278, heights not multiples of 8), channel counts that are not
+    multiples of 64 (the padded channels are computed and dropped), the last-64-channels launch."""
+    from torch_utils.ops import conv2d_frames as c2
+    n, ci, co, ho, wo = shape
+    co_pad = c2.round_up(co, c2.CH)
+    torch.manual_seed(3)
+    x = torch.randn(n, ho + 4, wo + 5, ci, device='cuda').to(dtype)
+    w = (torch.randn(3, 3, co_pad, ci, device='cuda') / (3 * ci ** 0.5)).to(dtype)
+    ref = c2.conv2d_valid(x, w, ho, wo, offset=(1, 2))                                   # [n, ho, wo, co_pad]
+    got = c2.conv2d_valid_planes(x, w, ho, wo, co, offset=(1, 2))
+    assert got.shape == (n, co, ho, wo) and got.dtype == dtype and got.is_contiguous()
+    assert torch.equal(got, ref[..., :co].permute(0, 3, 1, 2))
+    pre = 0.5 + torch.rand(n, co, device='cuda')
+    conv_acc = c2.conv2d_valid(x, w, ho, wo, offset=(1, 2), out_dtype=torch.float32)[..., :co].permute(0, 3, 1, 2)
+    acc = conv_acc * pre[:, :, None, None]
+    got = c2.conv2d_valid_planes(x, w, ho, wo, co, offset=(1, 2), pre=pre)
+    # one rounding of the float32 accumulator times the scale: of the float32 product (bfloat16: multiply, then convert) or of the exact product
+    # (float16: hipcc contracts multiply + conversion into v_fma_mixlo_f16)
+    exact = conv_acc.double() * pre.double()[:, :, None, None]
+    assert bool(((got.double() - exact).abs() <= (acc.to(dtype).double() - exact).abs()).all())       # at least as close as the float32-rounded product
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 70, 27, 100, 18, 22), (1, 128, 0, 181, 33, 52)], ids=['cond_100_w24', 'no_cond_181_w54'])
+def test_plane_output_route_of_the_modulated_convolution_gpu(shape, dtype, monkeypatch):
+    """The fused 16-bit node with the convolution storing demodulated planes itself (round 6) against the two-pass form it replaces (channels-last
+    result + transposing pass): output within one 16-bit rounding (one rounding instead of two), every gradient within the 16-bit tolerance of
+    the test above -- d demod comes from the saved planes (sum d_out * out / demod) instead of the channels-last y."""
+    n, c1, c2, co, h, w = shape
+    torch.manual_seed(7)
+    x = torch.randn(n, c1, h, w, device='cuda').to(dtype)
+    cond = torch.randn(n, c2, h, w, device='cuda').to(dtype) if c2 else None
+    weight = torch.randn(co, c1 + c2, 3, 3, device='cuda') / ((c1 + c2) * 9) ** 0.5
+    mod = 0.5 + torch.rand(n, c1 + c2, device='cuda')
+    demod = 0.5 + torch.rand(n, co, device='cuda')
+    dy = torch.randn(n, co, h + 2, w + 2, device='cuda').to(dtype)
+
+    def run(planes):
+        monkeypatch.setattr(ml, 'PLANES_OUT', planes)
+        args = [t.detach().clone().requires_grad_(True) for t in (x, weight, mod, demod)]
+        y = ml.modulated_conv2d(args[0], cond, args[1], args[2], args[3], padding=2)
+        return [y.detach()] + list(torch.autograd.grad(y, args, dy))
+    new, old = run(True), run(False)
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    for name, a, b in zip(('y', 'd_x', 'd_weight', 'd_mod', 'd_demod'), new, old):
+        a, b = a.float(), b.float()
+        if name == 'y':
+            assert float(((a - b).abs() / b.abs().clamp_min(1e-3)).max()) <= 1.01 * eps, name
+        else:
+            assert float((a - b).abs().max()) <= 4 * eps * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
