@@ -329,6 +329,15 @@ int lvg_conv2d_frames(const void* x, const void* w, const float* pre, void* out,
 int lvg_conv2d_frames_planes(const void* x, const void* w, const float* pre, void* out,
                              int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
                              int64_t x_pixel_stride, int dtype, void* stream);
+/* ... and, from the same accumulators (before `pre`), dot_partial[n][row][c] = sum over the pixels of half tile `row` of acc * oth[n][c][pixel] for
+ * c < c_dot_a + c_dot_b <= co; oth = dot_a [n][c_dot_a][ho][wo] and dot_b [n][c_dot_b][ho][wo] concatenated along the channels (x's dtype, 4-byte aligned; dot_b may
+ * be NULL with c_dot_b = 0); rows per frame = lvg_conv2d_frames_planes_dot_rows(ho, wo); the caller adds the rows in order (reproducible). The data gradient of the
+ * modulated convolution: dx * styles leaves as planes, d styles = sum dx * x comes from the accumulators (model/generator_sres.py:61 differentiated). */
+int64_t lvg_conv2d_frames_planes_dot_rows(int ho, int wo);
+int lvg_conv2d_frames_planes_dot(const void* x, const void* w, const float* pre, void* out, const void* dot_a, const void* dot_b, float* dot_partial,
+                                 int c_dot_a, int c_dot_b,
+                                 int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
+                                 int64_t x_pixel_stride, int dtype, void* stream);
 int lvg_conv2d_frames_wgrad_splits(int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw);
 int lvg_conv2d_frames_wgrad(const void* x, const void* dy, float* part,
                             int64_t n, int hx, int wx, int hd, int wd, int ci, int co, int kh, int kw,

@@ -177,9 +177,42 @@ extern "C" int lvg_conv2d_frames(const void* x, const void* w, const float* pre,
 
 // The same contraction with the result stored as NCHW planes: out [n][co_out][ho][wo] = pre[n][co_out] * acc for the first co_out <= co channels
 // (co: the padded count of the weight). wo even (the kernel stores pixel pairs at least); 16-bit output.
+static int conv2d_planes_launch(const void* x, const void* w, const float* pre, void* out, const void* dot_a, const void* dot_b, float* dot_partial, int c_dot_a, int c_dot_b,
+                                int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
+                                int64_t x_pixel_stride, int dtype, void* stream);
+
 extern "C" int lvg_conv2d_frames_planes(const void* x, const void* w, const float* pre, void* out,
                                         int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
                                         int64_t x_pixel_stride, int dtype, void* stream)
+{
+    return conv2d_planes_launch(x, w, pre, out, nullptr, nullptr, nullptr, 0, 0, n, hi, wi, ho, wo, ci, co, co_out, kh, kw, in_off_y, in_off_x, x_pixel_stride, dtype, stream);
+}
+
+// Rows of dot_partial per frame for lvg_conv2d_frames_planes_dot (0: no kernel for the shape): two per 8 x 16 pixel tile.
+extern "C" int64_t lvg_conv2d_frames_planes_dot_rows(int ho, int wo)
+{
+    if (ho < 1 || wo < 1) return 0;
+    return 2 * lvg_ceil_div(ho, 8) * lvg_ceil_div(wo, kTileW);
+}
+
+// ... and, from the same accumulators (before `pre`), dot_partial[n][row][c] = sum over the pixels of half tile `row` of acc[n][pixel][c] * oth[n][c][pixel] for
+// c < c_dot_a + c_dot_b <= co, oth = the channel concatenation of dot_a [n][c_dot_a][ho][wo] and dot_b [n][c_dot_b][ho][wo] (x's dtype; dot_b may be NULL with
+// c_dot_b = 0): the caller adds the rows in order (reproducible). The data gradient of the modulated convolution uses it for d styles = sum dx * x
+// (model/generator_sres.py:61 `x * styles` differentiated) while dx * styles leaves as planes.
+extern "C" int lvg_conv2d_frames_planes_dot(const void* x, const void* w, const float* pre, void* out, const void* dot_a, const void* dot_b, float* dot_partial,
+                                            int c_dot_a, int c_dot_b,
+                                            int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
+                                            int64_t x_pixel_stride, int dtype, void* stream)
+{
+    LVG_REQUIRE(dot_a && dot_partial && c_dot_a >= 1 && c_dot_b >= 0 && (c_dot_b == 0 || dot_b) && c_dot_a + c_dot_b <= co,
+                "conv2d_frames_planes_dot: bad reduction partner (channels %d + %d of %d)", c_dot_a, c_dot_b, co);
+    LVG_REQUIRE(((uintptr_t)dot_a % 4) == 0 && ((uintptr_t)dot_b % 4) == 0 && lvg_aligned16(dot_partial), "conv2d_frames_planes_dot: partner planes must be 4-byte aligned");
+    return conv2d_planes_launch(x, w, pre, out, dot_a, dot_b, dot_partial, c_dot_a, c_dot_b, n, hi, wi, ho, wo, ci, co, co_out, kh, kw, in_off_y, in_off_x, x_pixel_stride, dtype, stream);
+}
+
+static int conv2d_planes_launch(const void* x, const void* w, const float* pre, void* out, const void* dot_a, const void* dot_b, float* dot_partial, int c_dot_a, int c_dot_b,
+                                int64_t n, int hi, int wi, int ho, int wo, int ci, int co, int co_out, int kh, int kw, int in_off_y, int in_off_x,
+                                int64_t x_pixel_stride, int dtype, void* stream)
 {
     LVG_REQUIRE(dtype == LVG_F16 || dtype == LVG_BF16, "conv2d_frames_planes: float16 / bfloat16 only (dtype %d)", dtype);
     LVG_REQUIRE(x && w && out, "conv2d_frames_planes: null tensor");
@@ -215,6 +248,7 @@ extern "C" int lvg_conv2d_frames_planes(const void* x, const void* w, const floa
     a.oStride = co;
     a.offY = in_off_y; a.offX = in_off_x;
     a.coOut = co_out;
+    a.dotA = dot_a; a.dotB = dot_b; a.dotPartial = dot_partial; a.cDotA = c_dot_a; a.cDotB = c_dot_b;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == LVG_BF16 ? launch2d_tile<bf16_t>(a, pl, s, false, true) : launch2d_tile<f16_t>(a, pl, s, false, true);
 }

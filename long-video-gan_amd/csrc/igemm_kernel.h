@@ -46,6 +46,11 @@ struct ConvArgs2D : ConvArgs
     int          offY, offX;   // output pixel (0, 0) reads input pixels (offY + dh, offX + dw)
     int          coBase;       // first output channel of this launch (a launch may cover a channel range of the Co channels)
     int          coOut;        // PLANES kernels: channels of the NCHW output tensor (<= Co; channels past it are computed and dropped)
+    // PLANES kernels, optional: dot[(tile, pixel half)][c] = sum over the half tile's pixels of acc * oth[n][c][pixel] for c < cDotA + cDotB, oth = the
+    // channel-concatenation of two NCHW tensors of the output's plane size (the data gradient's d mod = sum dx * x, formed on the accumulators)
+    const void*  dotA; const void* dotB;
+    float*       dotPartial;
+    int          cDotA, cDotB;
 };
 
 template <bool T2D> struct ConvArgsOf { typedef ConvArgs type; };
@@ -924,7 +929,46 @@ next_tile:                                                            // PERSIST
     {
         // acc[cb][pb][4 qd + e]: channel co0 + wc * WCO + cb * 32 + l31, pixel pb * 32 + 8 qd + 4 hi + e of this wave's 64 (tile rows 4 wr .. 4 wr + 3, 16 wide)
         constexpr int PP = ROWS * 2 + 8;              // staged channel row: 64 pixels + 8 bytes (the 32 lanes of a half wave write 8 bytes each to 64 distinct banks)
+        constexpr int NSEG = WCO / 8;                 // 8-pixel segments per lane: lane task t = i * 64 + lane -> channel row t >> 3, segment t & 7
         unsigned char* const st = smem + wave * (WCO * PP);
+        auto seg_of = [&](int i, int& cl, int& oy, int& ox) __attribute__((always_inline))
+        {
+            const int t = i * 64 + lane, seg = t & 7;
+            cl = t >> 3;
+            oy = y0 + wr * (ROWS / kTileW) + (seg >> 1);
+            ox = x0 + (seg & 1) * 8;
+        };
+        // The reduction partner's tile (this wave's channels x 64 pixels of the NCHW tensors) is fetched the way the result is stored -- 16 bytes per lane, 32-byte
+        // runs -- at the very start, so that the loads fly during the output path; it goes through the staging area afterwards. (First version: every lane read its
+        // own channel's pixels as dwords straight from global memory -- 64 cache lines per load instruction: +127 us on a 375 us data gradient.)
+        uint4 partner[NSEG];
+        if (p.dotPartial)
+        {
+            #pragma unroll
+            for (int i = 0; i < NSEG; i++)
+            {
+                int cl, oy, ox;
+                seg_of(i, cl, oy, ox);
+                const int c = co0 + wc * WCO + cl;
+                const T* plane = nullptr;
+                if (c < p.cDotA) plane = static_cast<const T*>(p.dotA) + ((int64_t)n2 * p.cDotA + c) * p.H * p.W;
+                else if (c < p.cDotA + p.cDotB) plane = static_cast<const T*>(p.dotB) + ((int64_t)n2 * p.cDotB + (c - p.cDotA)) * p.H * p.W;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int left = p.W - ox;
+                if (plane && oy < p.H && left >= 2)
+                {
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(plane + (int64_t)oy * p.W + ox);      // (even width: dword-aligned)
+                    if (left >= 8) { const uint2 a = *reinterpret_cast<const uint2*>(src), b = *reinterpret_cast<const uint2*>(src + 2); v = make_uint4(a.x, a.y, b.x, b.y); }
+                    else
+                    {
+                        v.x = src[0];
+                        if (left >= 4) v.y = src[1];
+                        if (left >= 6) v.z = src[2];
+                    }
+                }
+                partner[i] = v;
+            }
+        }
         #pragma unroll
         for (int cb = 0; cb < NCB; cb++)
         {
@@ -948,13 +992,13 @@ next_tile:                                                            // PERSIST
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T* const outp = static_cast<T*>(p.out);
         #pragma unroll
-        for (int i = 0; i < WCO / 8; i++)
+        for (int i = 0; i < NSEG; i++)
         {
-            const int t = i * 64 + lane, cl = t >> 3, seg = t & 7;             // channel row, 8-pixel segment of its 64 pixels
-            const uint2 lo = *reinterpret_cast<const uint2*>(st + cl * PP + seg * 16);
-            const uint2 hi2 = *reinterpret_cast<const uint2*>(st + cl * PP + seg * 16 + 8);
+            int cl, oy, ox;
+            seg_of(i, cl, oy, ox);
+            const uint2 lo = *reinterpret_cast<const uint2*>(st + cl * PP + ((i * 64 + lane) & 7) * 16);
+            const uint2 hi2 = *reinterpret_cast<const uint2*>(st + cl * PP + ((i * 64 + lane) & 7) * 16 + 8);
             const int c = co0 + wc * WCO + cl;
-            const int oy = y0 + wr * (ROWS / kTileW) + (seg >> 1), ox = x0 + (seg & 1) * 8;
             if (c < p.coOut && oy < p.H)
             {
                 T* const dst = outp + (((int64_t)n2 * p.coOut + c) * p.H + oy) * p.W + ox;
@@ -964,6 +1008,43 @@ next_tile:                                                            // PERSIST
                 else if (left >= 6) { *reinterpret_cast<uint2*>(dst) = lo; *reinterpret_cast<uint32_t*>(dst + 4) = hi2.x; }
                 else if (left >= 4) *reinterpret_cast<uint2*>(dst) = lo;
                 else if (left >= 2) *reinterpret_cast<uint32_t*>(dst) = lo.x;
+            }
+        }
+        if (p.dotPartial)
+        {
+            // partner tile -> the staging area (the result rows have been read), then each lane's channel row against its accumulators
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            #pragma unroll
+            for (int i = 0; i < NSEG; i++)
+            {
+                const int t = i * 64 + lane;
+                *reinterpret_cast<uint2*>(st + (t >> 3) * PP + (t & 7) * 16) = make_uint2(partner[i].x, partner[i].y);
+                *reinterpret_cast<uint2*>(st + (t >> 3) * PP + (t & 7) * 16 + 8) = make_uint2(partner[i].z, partner[i].w);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            #pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+            {
+                const int c = co0 + wc * WCO + cb * 32 + l31;
+                float dsum = 0.f;
+                #pragma unroll
+                for (int pb = 0; pb < PB; pb++)
+                    #pragma unroll
+                    for (int qd = 0; qd < 4; qd++)
+                    {
+                        const uint2 raw = *reinterpret_cast<const uint2*>(st + (cb * 32 + l31) * PP + (pb * 32 + 8 * qd + 4 * hi) * 2);
+                        T four[4];
+                        __builtin_memcpy(four, &raw, 8);
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) dsum = fmaf(acc[cb][pb][qd * 4 + e], (float)to_acc(four[e]), dsum);      // (pixels outside the plane: partner 0)
+                    }
+                dsum += __shfl_xor(dsum, 32, 64);                  // the two half waves hold the same channels, different pixels
+                if (hi == 0 && c < p.cDotA + p.cDotB)
+                    p.dotPartial[((int64_t)mt * (BM / ROWS) + wr) * (p.cDotA + p.cDotB) + c] = dsum;
             }
         }
         return;

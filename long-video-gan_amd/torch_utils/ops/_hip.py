@@ -57,6 +57,8 @@ _SIGNATURES = {
     'lvg_conv2d_frames_workgroups': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames': [_vp] * 4 + [_i64] + [_i32] * 10 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_conv2d_frames_planes': [_vp] * 4 + [_i64] + [_i32] * 11 + [_i64, _i32, _vp],
+    'lvg_conv2d_frames_planes_dot_rows': [_i32, _i32],
+    'lvg_conv2d_frames_planes_dot': [_vp] * 7 + [_i32, _i32, _i64] + [_i32] * 11 + [_i64, _i32, _vp],
     'lvg_conv2d_frames_wgrad_splits': [_i64] + [_i32] * 8,
     'lvg_conv2d_frames_wgrad': [_vp] * 3 + [_i64] + [_i32] * 8 + [_i64, _i64, _i32, _i32, _vp],
     'lvg_ada_warp': [_vp] * 5 + [_i32] * 4 + [_vp],
@@ -93,7 +95,7 @@ def lib():
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_conv3d_frames_workgroups_f32out', 'lvg_bias_act_grad_bias_slots', 'lvg_conv2d_frames_workgroups') else ctypes.c_int
+            fn.restype = ctypes.c_int64 if name in ('lvg_conv3d_frames_workgroups', 'lvg_conv3d_frames_workgroups_f32out', 'lvg_bias_act_grad_bias_slots', 'lvg_conv2d_frames_workgroups', 'lvg_conv2d_frames_planes_dot_rows') else ctypes.c_int
         _lib = handle
     return _lib
 

@@ -100,29 +100,47 @@ def conv2d_valid(x, wp, ho, wo, offset=(0, 0), pre=None, out_dtype=None, alg_flo
     return y.permute(0, 2, 3, 1).contiguous().to(out_dtype)
 
 
-def conv2d_valid_planes(x, wp, ho, wo, co_out, offset=(0, 0), pre=None, alg_flops=None):
+def conv2d_valid_planes(x, wp, ho, wo, co_out, offset=(0, 0), pre=None, alg_flops=None, dot=None):
     """The contraction of `conv2d_valid` with the result as NCHW planes: out [N, co_out, ho, wo] = pre[n, co] * acc for the first co_out of wp's (padded)
-    output channels, in x's dtype with ONE rounding (lvg_conv2d_frames_planes; wo even on the GPU). pre float32 [N, co_out] or None."""
+    output channels, in x's dtype with ONE rounding (lvg_conv2d_frames_planes; wo even on the GPU). pre float32 [N, co_out] or None.
+    dot = (a, b): NCHW tensors [N, ca, ho, wo], [N, cb, ho, wo] (b may be None) of x's dtype -> also returns partial [N, rows, ca + cb] float32 with
+    partial.sum(1)[n, c] = sum over the pixels of acc[n, pixel, c] * cat(a, b)[n, c, pixel] (the accumulators BEFORE `pre`)."""
     n, hi, wi, ci = x.shape
     co = wp.shape[2]
     assert ho <= hi - offset[0] - 2 and wo <= wi - offset[1] - 2 and wp.shape == (3, 3, co, ci) and 1 <= co_out <= co
+    da, db = dot if dot is not None else (None, None)
+    ca, cb = (0 if da is None else da.shape[1]), (0 if db is None else db.shape[1])
     if x.device.type == 'cuda' and _init():
         assert supported(x, wp) and wo % 2 == 0, 'conv2d_frames_planes: no hand-written kernel for this shape / dtype / layout'
         out = torch.empty([n, co_out, ho, wo], dtype=x.dtype, device=x.device)
         pre = None if pre is None else pre.float().contiguous()
         assert pre is None or tuple(pre.shape) == (n, co_out)
         with torch.cuda.device(x.device):
-            rc = _hip.lib().lvg_conv2d_frames_planes(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), n, hi, wi, ho, wo, ci, co, co_out, 3, 3,
-                                                     offset[0], offset[1], ci, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+            if da is None:
+                partial = None
+                rc = _hip.lib().lvg_conv2d_frames_planes(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), n, hi, wi, ho, wo, ci, co, co_out, 3, 3,
+                                                         offset[0], offset[1], ci, _hip.dtype_code(x.dtype), _hip.stream(x.device))
+            else:
+                assert da.is_contiguous() and tuple(da.shape) == (n, ca, ho, wo) and da.dtype == x.dtype and ca + cb <= co
+                assert db is None or (db.is_contiguous() and tuple(db.shape) == (n, cb, ho, wo) and db.dtype == x.dtype)
+                rows = int(_hip.lib().lvg_conv2d_frames_planes_dot_rows(ho, wo))
+                partial = torch.empty([n, rows, ca + cb], dtype=torch.float32, device=x.device)
+                rc = _hip.lib().lvg_conv2d_frames_planes_dot(x.data_ptr(), wp.data_ptr(), _hip.ptr(pre), out.data_ptr(), da.data_ptr(), _hip.ptr(db), partial.data_ptr(), ca, cb,
+                                                             n, hi, wi, ho, wo, ci, co, co_out, 3, 3, offset[0], offset[1], ci, _hip.dtype_code(x.dtype), _hip.stream(x.device))
         _hip.check(rc, 'conv2d_frames_planes')
         stats['flops'] += 2 * n * ho * wo * co * ci * 9 if alg_flops is None else alg_flops
         stats['launches'] += 1
-        return out
+        return out if dot is None else (out, partial)
     v = x[:, offset[0]:offset[0] + ho + 2, offset[1]:offset[1] + wo + 2].permute(0, 3, 1, 2).float()
-    y = F.conv2d(v, wp.permute(2, 3, 0, 1).float())[:, :co_out]
+    acc = F.conv2d(v, wp.permute(2, 3, 0, 1).float())
+    y = acc[:, :co_out]
     if pre is not None:
         y = y * pre.float()[:, :, None, None]
-    return y.contiguous().to(x.dtype)
+    y = y.contiguous().to(x.dtype)
+    if dot is None:
+        return y
+    oth = da if db is None else torch.cat((da, db), dim=1)
+    return y, (acc[:, :ca + cb] * oth.float()).sum(dim=(2, 3))[:, None, :]
 
 
 def split16(t, dtype=torch.float16):

@@ -245,8 +245,14 @@ class _ModConv2dHand(torch.autograd.Function):
         if need_first or need_mod:
             wt = prepared.wt if prepared is not None and prepared.wt is not None else \
                 conv2d_frames.pack_weight_dgrad(weight if prepared is None else prepared.wp[:, :, :co, :ci].permute(2, 3, 0, 1), first.dtype, ci_pad, co_pad)
-            dxp = conv2d_frames.conv2d_valid(dyp, wt, geo.h, geo.w, alg_flops=ctx.alg)
-            d_first, partial = _frames_to_nchw(dxp, mod[:, :c_first].contiguous(), c_first, oth_a=first if need_mod else None, oth_b=second if need_mod else None)
+            if PLANES_OUT and first.is_cuda and geo.w % 2 == 0:
+                # the data gradient stores d first = dx * mod as planes itself and forms d mod = sum dx * cat(first, second) on its accumulators
+                res = conv2d_frames.conv2d_valid_planes(dyp, wt, geo.h, geo.w, c_first, pre=mod[:, :c_first].contiguous(), alg_flops=ctx.alg,
+                                                        dot=(first, second) if need_mod else None)
+                d_first, partial = res if need_mod else (res, None)
+            else:
+                dxp = conv2d_frames.conv2d_valid(dyp, wt, geo.h, geo.w, alg_flops=ctx.alg)
+                d_first, partial = _frames_to_nchw(dxp, mod[:, :c_first].contiguous(), c_first, oth_a=first if need_mod else None, oth_b=second if need_mod else None)
             d_mod = partial.sum(dim=1) if need_mod else None
         return (d_first if need_first else None), None, d_weight, d_mod, d_demod, None, None
 

@@ -414,3 +414,30 @@ def test_plane_output_route_of_the_modulated_convolution_gpu(shape, dtype, monke
             assert float(((a - b).abs() / b.abs().clamp_min(1e-3)).max()) <= 1.01 * eps, name
         else:
             assert float((a - b).abs().max()) <= 4 * eps * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 128, 100, 27, 20, 38), (1, 64, 181, 0, 33, 22), (2, 192, 60, 3, 9, 150)], ids=['cond_27', 'single', 'wide_150'])
+def test_plane_output_dot_products_gpu(shape, dtype):
+    """lvg_conv2d_frames_planes_dot: next to the planes, per-half-tile sums of accumulator * partner plane (the data gradient's d styles): the rows added
+    in order against the float64 sum of float32-accumulator * partner; the planes themselves unchanged by the extra output; reproducible."""
+    from torch_utils.ops import conv2d_frames as c2
+    n, ci, ca, cb, ho, wo = shape
+    co_pad = c2.round_up(ca + cb, c2.CH)
+    torch.manual_seed(5)
+    x = torch.randn(n, ho + 2, wo + 2, ci, device='cuda').to(dtype)
+    w = (torch.randn(3, 3, co_pad, ci, device='cuda') / (3 * ci ** 0.5)).to(dtype)
+    a = torch.randn(n, ca, ho, wo, device='cuda').to(dtype)
+    b = torch.randn(n, cb, ho, wo, device='cuda').to(dtype) if cb else None
+    pre = 0.5 + torch.rand(n, ca, device='cuda')
+    planes, partial = c2.conv2d_valid_planes(x, w, ho, wo, ca, pre=pre, dot=(a, b))
+    assert torch.equal(planes, c2.conv2d_valid_planes(x, w, ho, wo, ca, pre=pre))
+    acc = c2.conv2d_valid(x, w, ho, wo, out_dtype=torch.float32)[..., :ca + cb].permute(0, 3, 1, 2).double()
+    oth = (a if b is None else torch.cat((a, b), dim=1)).double()
+    want = (acc * oth).sum(dim=(2, 3))
+    got = partial.double().sum(dim=1)
+    scale = (acc.abs() * oth.abs()).sum(dim=(2, 3))
+    assert partial.shape[2] == ca + cb and bool(((got - want).abs() <= 2e-6 * scale + 1e-6).all()), float(((got - want).abs() / scale).max())
+    _, again = c2.conv2d_valid_planes(x, w, ho, wo, ca, pre=pre, dot=(a, b))
+    assert torch.equal(partial, again)
