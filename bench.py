@@ -139,6 +139,9 @@ class OpTimer:
         from torch_utils.ops import conv2d_frames
         wrap(conv2d_frames, 'conv2d_valid', lambda a: 'conv2d_igemm',
              lambda args, out, kw: kw.get('alg_flops') or 2 * args[0].shape[0] * args[2] * args[3] * args[1].shape[2] * args[1].shape[3] * 9)
+        # (round 6: the 16-bit layers' forward and data-gradient launches store NCHW planes themselves -- the same kernel, same family)
+        wrap(conv2d_frames, 'conv2d_valid_planes', lambda a: 'conv2d_igemm',
+             lambda args, out, kw: kw.get('alg_flops') or 2 * args[0].shape[0] * args[2] * args[3] * args[1].shape[2] * args[1].shape[3] * 9)
         wrap(conv2d_frames, 'conv2d_wgrad', lambda a: 'conv2d_wgrad',
              lambda args, out, kw: kw.get('alg_flops') or 2 * args[1].shape[0] * args[1].shape[1] * args[1].shape[2] * args[1].shape[3] * args[0].shape[3] * 9)
         # round 5: noise filter bank (float32 MFMA: FLOPs on the non-zero taps of the bank), the thin 1 x 1 kernels (streams over the wide tensor) and
