@@ -441,3 +441,33 @@ def test_plane_output_dot_products_gpu(shape, dtype):
     assert partial.shape[2] == ca + cb and bool(((got - want).abs() <= 2e-6 * scale + 1e-6).all()), float(((got - want).abs() / scale).max())
     _, again = c2.conv2d_valid_planes(x, w, ho, wo, ca, pre=pre, dot=(a, b))
     assert torch.equal(partial, again)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(12))
+def test_plane_output_random_shapes_gpu(seed):
+    """Seeded random shapes for the plane-storing convolution (+ dot products): frame counts 1..3, 64..256 input channels, output channel counts that are or are
+    not multiples of 64 / 128 (both launches: tiles of 128 channels and the last 64), heights 3..40, even widths 4..70 (every residue of the 16-pixel tile and of the
+    8-pixel store segment), random input offsets, with and without a second partner tensor; float16 and bfloat16 alternate."""
+    from torch_utils.ops import conv2d_frames as c2
+    rs = np.random.RandomState(400 + seed)
+    dtype = torch.float16 if seed % 2 == 0 else torch.bfloat16
+    n, ci = int(rs.randint(1, 4)), 64 * int(rs.randint(1, 5))
+    co = int(rs.randint(1, 300))
+    ho, wo = int(rs.randint(3, 41)), 2 * int(rs.randint(2, 36))
+    oy, ox = int(rs.randint(0, 3)), int(rs.randint(0, 4))
+    co_pad = c2.round_up(co, c2.CH)
+    ca = int(rs.randint(1, co + 1))
+    cb = int(rs.randint(0, co - ca + 1)) if seed % 3 else 0
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.randn(n, ho + 2 + oy + int(rs.randint(0, 3)), wo + 2 + ox + int(rs.randint(0, 5)), ci, device='cuda', generator=g).to(dtype)
+    w = (torch.randn(3, 3, co_pad, ci, device='cuda', generator=g) / (3 * ci ** 0.5)).to(dtype)
+    a = torch.randn(n, ca, ho, wo, device='cuda', generator=g).to(dtype)
+    b = torch.randn(n, cb, ho, wo, device='cuda', generator=g).to(dtype) if cb else None
+    ref = c2.conv2d_valid(x, w, ho, wo, offset=(oy, ox))
+    got, partial = c2.conv2d_valid_planes(x, w, ho, wo, co, offset=(oy, ox), dot=(a, b))
+    assert torch.equal(got, ref[..., :co].permute(0, 3, 1, 2)), (n, ci, co, ho, wo, oy, ox)
+    acc = c2.conv2d_valid(x, w, ho, wo, offset=(oy, ox), out_dtype=torch.float32)[..., :ca + cb].permute(0, 3, 1, 2).double()
+    oth = (a if b is None else torch.cat((a, b), dim=1)).double()
+    want, scale = (acc * oth).sum(dim=(2, 3)), (acc.abs() * oth.abs()).sum(dim=(2, 3))
+    assert bool(((partial.double().sum(dim=1) - want).abs() <= 2e-6 * scale + 1e-6).all()), (n, ci, co, ca, cb, ho, wo)
