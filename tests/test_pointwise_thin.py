@@ -88,16 +88,16 @@ def test_model_gradients_match_library_route_gpu():
         finally:
             lres.THIN_POINTWISE = True
 
-    thin, lib_a, lib_b = run(True), run(False), run(False)
-    for a, b, c, name in zip(thin, lib_a, lib_b, ('video', 'ToRGB weight gradient', 'first-layer weight gradient')):
-        scale = float(b.abs().max())
-        err, noise = float((a - b).abs().max()) / scale, float((c - b).abs().max()) / scale
-        print(f'[measured] {name}: thin vs library {err:.3g}, library vs library {noise:.3g}')
-        assert err < max(4 * noise, 3e-2), (name, err, noise)
-    # direction of the gradients (insensitive to the handful of elements that carry the run-to-run noise)
-    for a, b in zip(thin[1:], lib_a[1:]):
-        cos = float((a * b).sum() / (a.norm() * b.norm()))
-        assert cos > 0.98, cos
+    # Round 6: the gate used to be max |difference| / max against ONE library-vs-library sample; that statistic is carried by single elements and its yardstick
+    # ranged over 0.02 .. 0.115 from run to run (two of eight runs failed on an unchanged tree). Now: relative L2 distances, three library runs as the yardstick.
+    thin, libs = run(True), [run(False) for _ in range(3)]
+    for k, name in enumerate(('video', 'ToRGB weight gradient', 'first-layer weight gradient')):
+        def dist(a, b):
+            return float((a - b).norm() / b.norm())
+        noise = max(dist(libs[i][k], libs[j][k]) for i in range(3) for j in range(3) if i != j)
+        err = min(dist(thin[k], lib[k]) for lib in libs)
+        print(f'[measured] {name}: thin vs library {err:.3g} (relative L2), library vs library {noise:.3g}')
+        assert err <= 2 * noise + 2e-2, (name, err, noise)
 
 
 # ---- weight gradient of the wide 1 x 1 convolutions (csrc/pointwise_wgrad.hip) ----------------------------------------------------------------
