@@ -1,0 +1,27 @@
+"""MEASUREMENT TOOL (GPU): the streaming kernels of the lres step on step-sized channels-last tensors next to a library elementwise kernel of the same traffic."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'long-video-gan_amd'))
+import torch
+from torch_utils.ops import bias_act, modconv_epilogue
+
+def t(fn, it=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it): fn()
+    b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / it * 1e-3
+
+for shape in ([1024, 64, 36, 64], [1024, 128, 18, 32], [512, 512, 9, 16]):
+    x = torch.randn(*shape, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], device='cuda').to(torch.bfloat16)
+    nbytes = x.numel() * 2
+    y = torch.empty_like(x)
+    dt = t(lambda: torch.add(x, 1.0, out=y)); print(f'{shape}: aten add (1 read + 1 write) {2 * nbytes / dt / 1e12:.2f} TB/s ({dt * 1e6:.0f} us)')
+    dt = t(lambda: bias_act.bias_act(x, b, act='lrelu', clamp=256)); print(f'   bias_act lrelu fwd {2 * nbytes / dt / 1e12:.2f} TB/s ({dt * 1e6:.0f} us)')
+    pre = torch.rand(shape[0], shape[1], device='cuda') + 0.5
+    post = torch.rand(shape[0], shape[1], device='cuda') + 0.5
+    fn = lambda: modconv_epilogue._launch_fwd(x, pre, b, post, True, 3, 0.2, 2.0 ** 0.5, 256.0, True)
+    try:
+        dt = t(fn); print(f'   modconv_epilogue fwd (+msq) {2 * nbytes / dt / 1e12:.2f} TB/s ({dt * 1e6:.0f} us)')
+    except Exception as e:
+        print('   epilogue launch signature differs:', str(e)[:100])
